@@ -1,0 +1,213 @@
+"""ctypes binding of oracle/libsnac_oracle.so.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
+package (snac_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libsnac_oracle.so")
+MAX_CELLS = 676
+
+
+def build(force=False):
+    src = [os.path.join(HERE, f) for f in ("snac_oracle.c", "snac_oracle.h")]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
+        subprocess.check_call(["make", "-s", "-C", HERE, "libsnac_oracle.so"])
+    return LIB
+
+
+class _Env(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "dynamic", "hw", "H", "W", "total_step", "num_actions", "obs_dim")] + [
+        ("grid", C.c_int32 * MAX_CELLS), ("plan", C.c_int32 * MAX_CELLS), ("pos", C.c_int32 * 2),
+        ("cb", C.c_int32), ("cs", C.c_int32), ("tb", C.c_int32), ("step_size", C.c_int32), ("plan_idx", C.c_int32)]
+
+
+class _Batch(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "dynamic", "n", "num_plans", "cells", "obs_dim", "total_step", "num_actions")] + [
+        ("seed", C.c_uint64), ("env_id_base", C.c_int64), ("plans", C.POINTER(C.c_int32)), ("envs", C.POINTER(_Env)),
+        ("episode", C.POINTER(C.c_int32)), ("ep_return", C.POINTER(C.c_int32)), ("need_reset", C.POINTER(C.c_uint8)),
+        ("stat_episodes", C.POINTER(C.c_int64)), ("stat_return", C.POINTER(C.c_int64)),
+        ("stat_iou_fx", C.POINTER(C.c_int64)), ("stat_steps", C.POINTER(C.c_int64))]
+
+
+class _MT(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        L.orc_init.argtypes = [C.POINTER(_Env), C.c_int, C.c_int]
+        L.orc_reset.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_step.argtypes = [C.POINTER(_Env), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.orc_observe.argtypes = [C.POINTER(_Env), C.c_void_p]
+        L.orc_iou.argtypes = [C.POINTER(_Env)]
+        L.orc_iou.restype = C.c_double
+        L.orc_static_plan.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.orc_mt_seed.argtypes = [C.POINTER(_MT), C.c_uint32]
+        L.orc_mt_next.argtypes = [C.POINTER(_MT)]
+        L.orc_mt_next.restype = C.c_uint32
+        L.orc_mt_randint.argtypes = [C.POINTER(_MT), C.c_int64, C.c_int64]
+        L.orc_mt_randint.restype = C.c_int64
+        L.orc_rng_word.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]
+        L.orc_rng_word.restype = C.c_uint32
+        L.orc_batch_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_int64]
+        L.orc_batch_create.restype = C.POINTER(_Batch)
+        L.orc_batch_destroy.argtypes = [C.POINTER(_Batch)]
+        L.orc_batch_reset.argtypes = [C.POINTER(_Batch), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_batch_step.argtypes = [C.POINTER(_Batch), C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int]
+        L.orc_batch_rollout.argtypes = [C.POINTER(_Batch), C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_batch_iou.argtypes = [C.POINTER(_Batch), C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def static_plan(dim, plan_choose):
+    out = np.zeros(MAX_CELLS, np.int32)
+    n = lib().orc_static_plan(dim, plan_choose, _ptr(out))
+    if n < 0:
+        raise ValueError("no such static plan")
+    return out[:n].copy()
+
+
+class MT19937:
+    """np.random.seed(s) / np.random.randint(lo, hi) of numpy's legacy global stream."""
+
+    def __init__(self, seed):
+        self.m = _MT()
+        lib().orc_mt_seed(C.byref(self.m), seed)
+
+    def randint(self, lo, hi):
+        return int(lib().orc_mt_randint(C.byref(self.m), lo, hi))
+
+
+class OracleEnv:
+    """One env; mirrors the reference class surface that the goldens exercise."""
+
+    def __init__(self, dim, dynamic):
+        self.e = _Env()
+        if lib().orc_init(C.byref(self.e), dim, int(dynamic)):
+            raise ValueError("bad dim")
+        self.obs_dim = self.e.obs_dim
+
+    def reset(self, plan, plan_idx=0):
+        plan = np.ascontiguousarray(np.asarray(plan).reshape(-1), np.int32)
+        assert plan.size == (30 if self.e.dim == 1 else 676)
+        obs = np.zeros(self.obs_dim, np.float64)
+        lib().orc_reset(C.byref(self.e), _ptr(plan), plan_idx, _ptr(obs))
+        return obs
+
+    def step(self, action, k):
+        obs = np.zeros(self.obs_dim, np.float64)
+        r, d = C.c_double(0), C.c_int(0)
+        rc = lib().orc_step(C.byref(self.e), int(action), int(k), _ptr(obs), C.byref(r), C.byref(d))
+        if rc:
+            raise ValueError("bad action %d (rc=%d)" % (action, rc))
+        return obs, r.value, bool(d.value)
+
+    def iou(self):
+        return lib().orc_iou(C.byref(self.e))
+
+    @property
+    def grid(self):
+        n = self.e.H * self.e.W
+        return np.array(self.e.grid[:n], np.int32)
+
+    @property
+    def pos(self):
+        return (self.e.pos[0], self.e.pos[1])
+
+
+class OracleBatch:
+    """N independent envs with the batched semantics of include/snac_hip.h."""
+
+    def __init__(self, dim, dynamic, n, plans, seed=1, env_id_base=0):
+        self.plans = np.ascontiguousarray(np.asarray(plans).reshape(len(plans), -1), np.int32)
+        assert self.plans.shape[1] == (30 if dim == 1 else 676)
+        self.b = lib().orc_batch_create(dim, int(dynamic), n, _ptr(self.plans), len(self.plans), seed, env_id_base)
+        if not self.b:
+            raise MemoryError
+        self.n, self.obs_dim, self.dim, self.dynamic = n, self.b.contents.obs_dim, dim, bool(dynamic)
+        self.total_step, self.num_actions = self.b.contents.total_step, self.b.contents.num_actions
+
+    def __del__(self):
+        if getattr(self, "b", None):
+            lib().orc_batch_destroy(self.b)
+            self.b = None
+
+    def reset(self, mask=None, plan_idx=None):
+        obs = np.zeros((self.n, self.obs_dim), np.float64)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        p = None if plan_idx is None else np.ascontiguousarray(plan_idx, np.int32)
+        if lib().orc_batch_reset(self.b, _ptr(m), _ptr(p), _ptr(obs)):
+            raise ValueError("bad plan index")
+        return obs
+
+    def step(self, t, actions=None, step_size=None, auto_reset=False, nthreads=1, want_obs=True):
+        obs = np.zeros((self.n, self.obs_dim), np.float64) if want_obs else None
+        rew = np.zeros(self.n, np.float32)
+        done = np.zeros(self.n, np.uint8)
+        a = None if actions is None else np.ascontiguousarray(actions, np.int8)
+        k = None if step_size is None else np.ascontiguousarray(step_size, np.int8)
+        if lib().orc_batch_step(self.b, t, _ptr(a), _ptr(k), int(auto_reset), _ptr(obs), _ptr(rew), _ptr(done), nthreads):
+            raise ValueError("bad action")
+        return obs, rew, done
+
+    def rollout(self, T, t0=0, actions=None, step_size=None, obs="all", nthreads=1):
+        """obs: 'all' -> [T,n,D]; 'last' -> [n,D]; None."""
+        o = None
+        if obs == "all":
+            o = np.zeros((T, self.n, self.obs_dim), np.float64)
+        elif obs == "last":
+            o = np.zeros((self.n, self.obs_dim), np.float64)
+        rew = np.zeros((T, self.n), np.float32)
+        done = np.zeros((T, self.n), np.uint8)
+        a = None if actions is None else np.ascontiguousarray(actions, np.int8)
+        k = None if step_size is None else np.ascontiguousarray(step_size, np.int8)
+        if lib().orc_batch_rollout(self.b, T, t0, _ptr(a), _ptr(k), _ptr(o), int(obs == "last"), _ptr(rew), _ptr(done), nthreads):
+            raise ValueError("bad action")
+        return o, rew, done
+
+    def iou(self):
+        out = np.zeros(self.n, np.float64)
+        lib().orc_batch_iou(self.b, _ptr(out))
+        return out
+
+    def _arr(self, name, dtype):
+        return np.ctypeslib.as_array(getattr(self.b.contents, name), shape=(self.n,)).astype(dtype, copy=True)
+
+    def stats(self):
+        return dict(episodes=self._arr("stat_episodes", np.int64), ret=self._arr("stat_return", np.int64),
+                    iou_fx=self._arr("stat_iou_fx", np.int64), steps=self._arr("stat_steps", np.int64))
+
+    def state(self):
+        """-> dict of numpy arrays: grid [n,H*W] int32 (bordered), pos [n,2], cb, cs, tb, plan_idx, episode."""
+        envs = self.b.contents.envs
+        n = self.n
+        cells = envs[0].H * envs[0].W
+        grid = np.zeros((n, cells), np.int32)
+        pos = np.zeros((n, 2), np.int32)
+        cb = np.zeros(n, np.int32); cs = np.zeros(n, np.int32); tb = np.zeros(n, np.int32); pi = np.zeros(n, np.int32)
+        for i in range(n):
+            e = envs[i]
+            grid[i] = e.grid[:cells]
+            pos[i] = (e.pos[0], e.pos[1])
+            cb[i], cs[i], tb[i], pi[i] = e.cb, e.cs, e.tb, e.plan_idx
+        return dict(grid=grid, pos=pos, cb=cb, cs=cs, tb=tb, plan_idx=pi, episode=self._arr("episode", np.int32),
+                    need_reset=self._arr("need_reset", np.uint8), ep_return=self._arr("ep_return", np.int32))
