@@ -1,0 +1,170 @@
+"""bench.py -- env-steps/s of the fused rollout on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): 2D dynamic dense (Env/2D/DMP_Env_2D_dynamic_usedata_plan.py, plans = the converted
+data_2d_dynamic_dense_envplan_500_train set), 65 536 envs per GPU, seed 1.  One bench "step" is one pass of the
+reference driver loop (multiprocess.py:82-84): T = total_step = 600 vector steps with uniform random actions,
+step sizes and plan indices from the counter RNG, auto-reset, writing the float64 observation, the reward and the
+done flag of EVERY env-step to HBM -- one snac_rollout launch.  Inputs (state, plan table) are resident in HBM
+before the timed region.  Multi-GPU: envs are sharded by global id (weak scaling, no data-path collective); the
+only collective is one RCCL all-reduce of three int64 episodic sums per pass, inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic bytes per env-step (DESIGN.md "Roofline")
+ALG_BYTES = {(2, "f64"): 481, (2, "f32"): 277, (1, "f64"): 88, (3, "f64"): 574}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(kind, dynamic, n, T, seed):
+    """The C oracle (oracle/snac_oracle.c, OpenMP over the host cores) on the same workload, timed on the host:
+    one full pass of n envs x T steps in chunks, float64 observations of every step written to a reused buffer."""
+    import numpy as np
+
+    from oracle import snac_oracle
+    from snac_amd import plans
+
+    cores = os.cpu_count() or 1
+    full = plans.dataset(kind, "dense", "train") if dynamic else plans.static_plan(kind, 0)[None]
+    table = full.reshape(len(full), -1).astype(np.int32)
+    orc = snac_oracle.OracleBatch(kind, dynamic, n, table, seed=seed)
+    orc.reset()
+    chunk = 10
+    D = orc.obs_dim
+    obs = np.zeros((chunk, n, D), np.float64)
+    rew = np.zeros((chunk, n), np.float32)
+    done = np.zeros((chunk, n), np.uint8)
+    L = snac_oracle.lib()
+    L.orc_batch_rollout(orc.b, chunk, 0, None, None, obs.ctypes.data, 0, rew.ctypes.data, done.ctypes.data, cores)  # warm
+    t0 = time.perf_counter()
+    steps = 0
+    t = chunk
+    while t < T + chunk and time.perf_counter() - t0 < 30.0:
+        L.orc_batch_rollout(orc.b, chunk, t, None, None, obs.ctypes.data, 0, rew.ctypes.data, done.ctypes.data, cores)
+        t += chunk
+        steps += chunk * n
+    dt = time.perf_counter() - t0
+    return dict(value=steps / dt, unit="env-steps/s", cores=cores, kind="port",
+                sample="C oracle, OpenMP x%d, %d envs x %d steps of the same workload (f64 obs of every step written)" % (
+                    cores, n, steps // n))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--kind", type=int, default=2)
+    ap.add_argument("--static", action="store_true")
+    ap.add_argument("--T", type=int, default=0, help="vector steps per pass (default: total_step)")
+    ap.add_argument("--obs-f32", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from snac_amd import BatchedDMPEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    n = args.envs
+    dynamic = not args.static
+    env = BatchedDMPEnv(args.kind, dynamic, n, device=dev, seed=1, env_id_base=rank * n,
+                        obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+    T = args.T or env.total_step
+    obs = torch.empty((T, n, env.obs_dim), dtype=env.obs_dtype, device=dev)
+    env.reset()
+    stats = torch.zeros(3, dtype=torch.int64, device=dev)
+
+    def one_pass():
+        env.rollout(T, obs="all", out=obs)
+        s = env.stats_tensor()
+        if world > 1:
+            dist.all_reduce(s)  # RCCL over xGMI: episodic [episodes, return sum, IoU fixed-point sum]
+        stats.copy_(s)
+
+    for _ in range(args.warmup):
+        one_pass()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        env.rollout(T, obs="all", out=obs)
+        ev[i][1].record()
+        s = env.stats_tensor()
+        if world > 1:
+            dist.all_reduce(s)
+        stats.copy_(s)
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+
+    if rank == 0:
+        total_steps = world * n * T * args.steps
+        dkey = "f32" if args.obs_f32 else "f64"
+        alg = ALG_BYTES.get((args.kind, dkey), ALG_BYTES[(2, "f64")])
+        achieved = alg * n * T / (kern_ms * 1e-3) / 1e9
+        s = stats.tolist()
+        out = {
+            "metric": "env-steps/sec at N=65536 envs (2D dynamic dense); bit-exact vs CPU",
+            "value": total_steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if not args.obs_f32 else "f32",
+            "data": "synthetic",
+            "config": {"workload": "%dD %s %s, %d envs/GPU, %d vector steps/pass, uniform random actions (counter RNG), "
+                                   "auto-reset, %s obs of every step written" % (
+                                       args.kind, "dynamic" if dynamic else "static", "dense", n, T, dkey),
+                       "envs_per_gpu": n, "vector_steps_per_pass": T, "env_steps_per_pass": n * T * world,
+                       "parallelism": "env-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_rollout", "kernel_ms": kern_ms, "alg_bytes_per_env_step": alg},
+            "episodic": {"episodes": s[0], "mean_return": (s[1] / s[0]) if s[0] else None,
+                         "mean_iou": (s[2] / 2.0 ** 40 / s[0]) if s[0] else None},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.kind, dynamic, n, T, 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

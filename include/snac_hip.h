@@ -1,0 +1,165 @@
+/*
+ * snac_hip.h -- C ABI of libsnac_hip.so: the MI355X (gfx950) batched mobile-construction simulator.
+ *
+ * Drop-in boundary for the env hot path of ai4ce/SNAC.  The reference has no FFI or plugin registry:
+ * its "operator API" for this path is the Python class surface
+ *     deep_mobile_printing_{1d1r,2d1r,3d1r}.reset()/step()/iou()
+ *       Env/1D/DMP_Env_1D_static.py:66-151            Env/1D/DMP_Env_1D_dynamic_usedata_plan.py:40-133
+ *       Env/2D/DMP_Env_2D_static.py:54-154            Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:34-147
+ *       Env/3D/DMP_simulator_3d_static_circle.py:67-276
+ *       Env/3D/DMP_simulator_3d_dynamic_triangle_usedata.py:45-277
+ *     VectorizedEnvWrapper.reset()/step()  multiprocess.py:15-32   and its driver loop multiprocess.py:78-84
+ * which snac_amd/ re-exports under the same module and class names on top of the entry points below
+ * (binding stubs: INTEGRATION.md).  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - Plain C types only.  Every pointer inside snac_state and every array argument is a DEVICE pointer
+ *     owned by the caller (e.g. torch tensors); the library allocates nothing and keeps no global state
+ *     except a thread-local error string.
+ *   - All work is enqueued on the caller's hipStream_t (`stream`, passed as void*; NULL = default
+ *     stream), asynchronously, without host synchronisation.
+ *   - Return value: SNAC_OK or a negative snac_status; snac_last_error() describes the last failure on
+ *     the calling thread.
+ *   - One process per GPU; envs are independent, so multi-GPU use shards envs by `env_id_base`.
+ *
+ * State layout in HBM (N = num_envs, all arrays env-major so one wavefront reads one env's record with
+ * unit-stride lanes):
+ *   hdr      snac_env_hdr[N]      16-byte packed scalars (one dwordx4 per env)
+ *   episode  int32[N]             number of resets performed - 1
+ *   grid     1D: int16[N][32]     heights of the 30 interior cells (2 pad); frame cells are implicit -1
+ *            2D: uint32[N][20]    occupancy bit-board, row i = interior row i, bit j = interior col j
+ *            3D: int16[N][400]    heights of the 20x20 interior, row-major
+ *   plans    1D: int16[P][32]  2D: uint32[P][20]  3D: int16[P][400]   (interior cells, same indexing)
+ *   plan_tb  int16[P]             total_brick of each plan (2D: after the floor of 30)
+ *   stats    int64[N] x 3         finished episodes, sum of their integer returns, sum of
+ *                                 llrint(IoU * 2^40) at episode end
+ * The -1 frame of the reference's environment_memory is a pure function of the coordinates and is
+ * never stored.  Interior values are exactly the reference's (2D cells are {0,1} after every step).
+ *
+ * Counter RNG (used when `actions` / `step_size` / plan indices are not supplied explicitly)
+ *   mix32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16          (32-bit wrap-around)
+ *   key(seed,stream) = mix32(lo32(seed) ^ mix32(hi32(seed) + 0x9E3779B9*(stream+1)))
+ *   e0 = mix32(key ^ mix32(lo32(env) + 0x85EBCA6B*hi32(env) + 0x1B873593))
+ *   e1 = mix32((key + 0x27D4EB2F) ^ mix32((lo32(env) ^ 0x165667B1) + 0xC2B2AE35*hi32(env)))
+ *   word(seed,stream,env,t) = mix32(mix32(e0 ^ (0x9E3779B9*t)) + e1)
+ *   stream 0 (per env, tick t):     action = ((word>>16) * num_actions) >> 16
+ *                                   step_size = 1 + (((word & 0xffff) * 3) >> 16)
+ *   stream 1 (per env, episode e):  plan_idx = (word * num_plans) >> 32
+ *   env = env_id_base + local index, so results do not depend on how envs are sharded over GPUs.
+ */
+#ifndef SNAC_HIP_H
+#define SNAC_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNAC_ABI_VERSION 1
+
+typedef enum snac_status {
+    SNAC_OK = 0,
+    SNAC_ERR_ARG = -1,         /* bad argument (null pointer, unknown kind, size mismatch) */
+    SNAC_ERR_HIP = -2,         /* a HIP call failed; message holds hipGetErrorString */
+    SNAC_ERR_UNSUPPORTED = -3
+} snac_status;
+
+enum { SNAC_ENV_1D = 1, SNAC_ENV_2D = 2, SNAC_ENV_3D = 3 };
+enum { SNAC_OBS_F64 = 0, SNAC_OBS_F32 = 1 };
+enum { SNAC_OBS_NONE = 0, SNAC_OBS_ALL = 1, SNAC_OBS_LAST = 2 };
+enum { SNAC_FLAG_NEED_RESET = 1 };   /* snac_env_hdr.flags: the last step returned done */
+
+/* constants of one env kind: the reference's __init__ blocks (Env/1D/DMP_Env_1D_static.py:7-29,
+ * Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:7-32, Env/3D/DMP_simulator_3d_static_circle.py:8-40,
+ * Env/3D/DMP_simulator_3d_dynamic_triangle_usedata.py:7-43) */
+typedef struct snac_sizes {
+    int32_t obs_dim;          /* state_dim: 7 / 51 / 51 */
+    int32_t num_actions;      /* action_dim: 3 / 5 / 8 */
+    int32_t total_step;       /* 750 / 600 / 1300 (3D static) or 1000 (3D dynamic) */
+    int32_t half_window;      /* HALF_WINDOW_SIZE: 2 / 3 / 3 */
+    int32_t env_height, env_width;     /* 1 x 34 / 26 x 26 */
+    int32_t plan_height, plan_width;   /* 1 x 30 / 20 x 20 */
+    int32_t grid_elems, grid_elem_bytes;   /* per-env record of snac_state.grid */
+    int32_t plan_elems, plan_elem_bytes;   /* per-plan record of snac_state.plans */
+} snac_sizes;
+
+typedef struct snac_env_hdr {   /* 16 bytes, 16-byte aligned */
+    int8_t  pos_r, pos_c;       /* position_memory[-1] in bordered coordinates (1D: pos_r, pos_c = 0) */
+    uint8_t flags;              /* SNAC_FLAG_* */
+    uint8_t reserved;
+    int16_t count_brick, count_step, total_brick, plan_idx;
+    int32_t ep_return;          /* integer return of the running episode (rewards are integers) */
+} snac_env_hdr;
+
+typedef struct snac_env_desc {
+    int32_t kind;               /* SNAC_ENV_* */
+    int32_t dynamic;            /* 0: static-plan class (obs scalars cb, cs); 1: *_usedata class (cb/tb, cs/T) */
+    int32_t num_envs;           /* N on this GPU */
+    int32_t num_plans;          /* P rows in plans / plan_tb */
+    int32_t obs_dtype;          /* SNAC_OBS_F64 (reference dtype) or SNAC_OBS_F32 (= (float) of the f64 value) */
+    int32_t static_plan;        /* plan row used by resets when dynamic == 0 or no plan index is supplied */
+    uint64_t seed;              /* counter-RNG seed */
+    int64_t env_id_base;        /* global id of local env 0 */
+} snac_env_desc;
+
+typedef struct snac_state {
+    snac_env_hdr* hdr;          /* [N] */
+    int32_t* episode;           /* [N] */
+    void* grid;                 /* [N][grid_elems] */
+    const void* plans;          /* [P][plan_elems] */
+    const int16_t* plan_tb;     /* [P] */
+    int64_t* stat_episodes;     /* [N] */
+    int64_t* stat_return;       /* [N] */
+    int64_t* stat_iou_fx;       /* [N] */
+} snac_state;
+
+int snac_version(void);
+const char* snac_last_error(void);
+
+/* constants of (kind, dynamic); replaces the attribute reads of the reference constructors */
+int snac_env_sizes(int kind, int dynamic, snac_sizes* out);
+
+/* reset(): Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:34-66 and the five sibling reset()s;
+ * VectorizedEnvWrapper.reset / reset_at (multiprocess.py:20-23).
+ *   mask        uint8[N] or NULL: reset env i iff mask[i] != 0 (NULL = all)
+ *   plan_idx_in int16[N] or NULL: plan row per env (the reference's index_random / sequential index);
+ *               NULL = counter RNG stream 1 when dynamic, desc->static_plan otherwise
+ *   obs         [N][obs_dim] of obs_dtype or NULL: observation of every env after the call */
+int snac_reset(const snac_env_desc* desc, const snac_state* st, const uint8_t* mask, const int16_t* plan_idx_in,
+               void* obs, void* stream);
+
+/* step(): Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:85-147 and siblings, for all N envs
+ * (VectorizedEnvWrapper.step, multiprocess.py:24-32), fused with observation_/_get_obs and the reward.
+ *   t           tick: index of this vector step (keys the counter RNG)
+ *   actions     int8[N] or NULL (counter RNG);  step_size int8[N] in {1,2,3} or NULL (counter RNG) --
+ *               the value the reference draws with np.random.randint(1, 4) at the top of step()
+ *   auto_reset  != 0: an env whose previous step returned done is reset first (plan from the counter RNG)
+ *   obs [N][obs_dim] or NULL, reward float[N] or NULL, done uint8[N] or NULL
+ * Actions outside [0, num_actions) only advance count_step (the reference raises). */
+int snac_step(const snac_env_desc* desc, const snac_state* st, uint32_t t, const int8_t* actions,
+              const int8_t* step_size, int auto_reset, void* obs, float* reward, uint8_t* done, void* stream);
+
+/* the driver loop of multiprocess.py:78-84 -- T vector steps with auto-reset, fused in one launch with the
+ * env state held on chip.
+ *   actions / step_size   int8[T][N] or NULL (counter RNG, ticks t0 .. t0+T-1)
+ *   obs_mode              SNAC_OBS_ALL: obs is [T][N][obs_dim]; SNAC_OBS_LAST: obs is [N][obs_dim] and
+ *                         receives the last step only; SNAC_OBS_NONE: obs ignored
+ *   reward float[T][N] or NULL, done uint8[T][N] or NULL */
+int snac_rollout(const snac_env_desc* desc, const snac_state* st, int32_t T, uint32_t t0, const int8_t* actions,
+                 const int8_t* step_size, int obs_mode, void* obs, float* reward, uint8_t* done, void* stream);
+
+/* current observation of every env without stepping: observation_() + the hstack of
+ * Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:64-72 */
+int snac_observe(const snac_env_desc* desc, const snac_state* st, void* obs, void* stream);
+
+/* iou(): Env/1D/DMP_Env_1D_static.py:138-151, Env/3D/DMP_simulator_3d_static_circle.py:257-276, and the
+ * caller-side boolean IoU of the 2D scripts (script/DQN/2d/DQN_2d_dynamic.py:63-71).  out: double[N] */
+int snac_iou(const snac_env_desc* desc, const snac_state* st, double* out, void* stream);
+
+/* environment_memory as the reference holds it: out is double[N][env_height][env_width] with the -1 frame */
+int snac_export_grid(const snac_env_desc* desc, const snac_state* st, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,87 @@
+"""ctypes binding of libsnac_hip.so (include/snac_hip.h).  There is no CPU fallback: if the HIP
+library is missing or a GPU is not available the product raises."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsnac_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+SNAC_OK = 0
+ENV_1D, ENV_2D, ENV_3D = 1, 2, 3
+OBS_F64, OBS_F32 = 0, 1
+OBS_NONE, OBS_ALL, OBS_LAST = 0, 1, 2
+FLAG_NEED_RESET = 1
+
+EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_reset", "snac_step", "snac_rollout",
+           "snac_observe", "snac_iou", "snac_export_grid")
+
+
+class Sizes(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "obs_dim", "num_actions", "total_step", "half_window", "env_height", "env_width", "plan_height", "plan_width",
+        "grid_elems", "grid_elem_bytes", "plan_elems", "plan_elem_bytes")]
+
+
+class EnvDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dynamic", C.c_int32), ("num_envs", C.c_int32), ("num_plans", C.c_int32),
+                ("obs_dtype", C.c_int32), ("static_plan", C.c_int32), ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
+
+
+class State(C.Structure):
+    _fields_ = [("hdr", C.c_void_p), ("episode", C.c_void_p), ("grid", C.c_void_p), ("plans", C.c_void_p),
+                ("plan_tb", C.c_void_p), ("stat_episodes", C.c_void_p), ("stat_return", C.c_void_p),
+                ("stat_iou_fx", C.c_void_p)]
+
+
+class SnacError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libsnac_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = [os.path.join(CSRC, "snac_hip.hip"), os.path.join(INCLUDE, "snac_hip.h")]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
+        subprocess.check_call(["make", "-s", "-C", CSRC, "-B", "../libsnac_hip.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SnacError("libsnac_hip.so is not built (%s); run __graft_entry__.build() or `make -C snac_amd/csrc`. "
+                            "There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.snac_version.restype = C.c_int
+        L.snac_last_error.restype = C.c_char_p
+        L.snac_env_sizes.argtypes = [C.c_int, C.c_int, C.POINTER(Sizes)]
+        L.snac_reset.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp, vp, vp]
+        L.snac_step.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_uint32, vp, vp, C.c_int, vp, vp, vp, vp]
+        L.snac_rollout.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, C.c_uint32, vp, vp, C.c_int, vp, vp, vp, vp]
+        L.snac_observe.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
+        L.snac_iou.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
+        L.snac_export_grid.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
+        for n in EXPORTS:
+            getattr(L, n)
+        if L.snac_version() != 1:
+            raise SnacError("libsnac_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != SNAC_OK:
+        raise SnacError("libsnac_hip: %s (code %d)" % (lib().snac_last_error().decode(), rc))
+
+
+def env_sizes(kind, dynamic):
+    s = Sizes()
+    check(lib().snac_env_sizes(kind, int(bool(dynamic)), C.byref(s)))
+    return s

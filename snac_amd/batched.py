@@ -1,0 +1,246 @@
+"""BatchedDMPEnv: N independent mobile-construction envs resident in MI355X HBM.
+
+Host-side Python over PyTorch-ROCm tensors (device memory + streams only); every transition, observation,
+reward and IoU is computed by the HIP kernels behind the C ABI of include/snac_hip.h.  The semantics per env
+are those of the reference classes (file:line in include/snac_hip.h); the batched additions are documented
+there too: explicit or counter-RNG step sizes / actions / plan indices, and auto-reset.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import plans as _plans
+
+_KINDS = {1: 1, 2: 2, 3: 3, "1d": 1, "2d": 2, "3d": 3, "1D": 1, "2D": 2, "3D": 3}
+_GRID_DTYPE = {1: torch.int16, 2: torch.int32, 3: torch.int16}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedDMPEnv:
+    """N envs of one kind.
+
+    kind      1 | 2 | 3 (or "1d" ...)
+    dynamic   False: the static-plan classes (obs scalars count_brick, count_step);
+              True: the *_usedata_plan classes (count_brick/total_brick, count_step/total_step)
+    plans     [P, 30] / [P, 26, 26] array of full plans as the reference stores them; default: the static plan
+              `plan_choose` (static) or the converted training set of `density` (dynamic)
+    seed      counter-RNG seed (include/snac_hip.h); env_id_base: global id of local env 0 (multi-GPU shards)
+    """
+
+    def __init__(self, kind, dynamic, num_envs, plans=None, plan_choose=0, density="dense", split="train",
+                 device="cuda", seed=1, obs_dtype=torch.float64, env_id_base=0):
+        if not torch.cuda.is_available():
+            raise _lib.SnacError("BatchedDMPEnv needs a ROCm GPU: there is no CPU fallback")
+        self.kind = _KINDS[kind]
+        self.dynamic = bool(dynamic)
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.SnacError("device must be a cuda (ROCm) device")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if obs_dtype not in (torch.float64, torch.float32):
+            raise ValueError("obs_dtype must be torch.float64 or torch.float32")
+        self.obs_dtype = obs_dtype
+        self.seed = int(seed)
+        self.env_id_base = int(env_id_base)
+        self._lib = _lib.lib()
+        sz = _lib.env_sizes(self.kind, self.dynamic)
+        self.sizes = sz
+        self.obs_dim, self.num_actions, self.total_step = sz.obs_dim, sz.num_actions, sz.total_step
+        if plans is None:
+            if self.dynamic:
+                plans = _plans.dataset(self.kind, density, split)
+            else:
+                plans = _plans.static_plan(self.kind, plan_choose)[None]
+        self.plans_full = np.asarray(plans, np.float64)
+        packed, tb = _plans.pack_plans(self.kind, self.plans_full)
+        self.num_plans = len(packed)
+        dev, N = self.device, self.num_envs
+        self._plans = torch.from_numpy(packed.view(np.int32) if self.kind == 2 else packed).to(dev)
+        self._plan_tb = torch.from_numpy(tb).to(dev)
+        self._hdr = torch.zeros((N, 4), dtype=torch.int32, device=dev)
+        self._episode = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        self._grid = torch.zeros((N, sz.grid_elems), dtype=_GRID_DTYPE[self.kind], device=dev)
+        self._stats = torch.zeros((3, N), dtype=torch.int64, device=dev)
+        self._desc = _lib.EnvDesc(self.kind, int(self.dynamic), N, self.num_plans,
+                                  _lib.OBS_F64 if obs_dtype == torch.float64 else _lib.OBS_F32, 0,
+                                  self.seed & 0xFFFFFFFFFFFFFFFF, self.env_id_base)
+        self._state = _lib.State(self._hdr.data_ptr(), self._episode.data_ptr(), self._grid.data_ptr(),
+                                 self._plans.data_ptr(), self._plan_tb.data_ptr(), self._stats[0].data_ptr(),
+                                 self._stats[1].data_ptr(), self._stats[2].data_ptr())
+        self.t = 0  # tick: number of vector steps taken (keys the counter RNG)
+        self._was_reset = False
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _i8(self, x, shape, what):
+        if x is None:
+            return None
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(np.asarray(x), device=self.device)
+        if x.device != self.device:
+            x = x.to(self.device)
+        if tuple(x.shape) != tuple(shape):
+            raise ValueError("%s must have shape %s, got %s" % (what, tuple(shape), tuple(x.shape)))
+        return x.to(torch.int8).contiguous()
+
+    def _new_obs(self, *lead):
+        return torch.empty(tuple(lead) + (self.num_envs, self.obs_dim), dtype=self.obs_dtype, device=self.device)
+
+    # ---- API -----------------------------------------------------------------------------------
+    def reset(self, mask=None, plan_idx=None):
+        """Reset all envs (or those with mask != 0).  plan_idx: per-env plan row; default counter RNG (dynamic)
+        or the single static plan.  Returns the observation of every env [N, obs_dim]."""
+        N = self.num_envs
+        m = p = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device)
+            if tuple(m.shape) != (N,):
+                raise ValueError("mask must have shape (N,)")
+            m = (m != 0).to(torch.uint8).contiguous()
+        if plan_idx is not None:
+            p = torch.as_tensor(plan_idx, device=self.device)
+            if tuple(p.shape) != (N,):
+                raise ValueError("plan_idx must have shape (N,)")
+            if int(p.min()) < 0 or int(p.max()) >= self.num_plans:
+                raise ValueError("plan_idx out of range")
+            p = p.to(torch.int16).contiguous()
+        obs = self._new_obs()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_reset(C.byref(self._desc), C.byref(self._state), _ptr(m), _ptr(p), _ptr(obs),
+                                            self._stream()))
+        self._was_reset = True
+        return obs
+
+    def step(self, actions=None, step_size=None, auto_reset=False, want_obs=True):
+        """One vector step.  actions int[N] (None: counter RNG), step_size int[N] in {1,2,3} (None: counter RNG).
+        Returns (obs [N, obs_dim], reward float32 [N], done bool [N])."""
+        if not self._was_reset:
+            raise _lib.SnacError("step() before reset()")
+        N = self.num_envs
+        a = self._i8(actions, (N,), "actions")
+        k = self._i8(step_size, (N,), "step_size")
+        obs = self._new_obs() if want_obs else None
+        reward = torch.empty((N,), dtype=torch.float32, device=self.device)
+        done = torch.empty((N,), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_step(C.byref(self._desc), C.byref(self._state), self.t & 0xFFFFFFFF, _ptr(a), _ptr(k),
+                                           int(bool(auto_reset)), _ptr(obs), _ptr(reward), _ptr(done), self._stream()))
+        self.t += 1
+        return obs, reward, done.view(torch.bool)
+
+    def rollout(self, T, actions=None, step_size=None, obs="all", out=None, want_reward=True, want_done=True):
+        """T vector steps with auto-reset in ONE launch (the loop of multiprocess.py:82-84).
+        actions / step_size: int[T, N] or None (counter RNG).  obs: "all" -> [T, N, D], "last" -> [N, D], None.
+        out: optional preallocated obs tensor.  Returns (obs, reward [T, N] float32, done [T, N] bool)."""
+        if not self._was_reset:
+            raise _lib.SnacError("rollout() before reset()")
+        N, T = self.num_envs, int(T)
+        a = self._i8(actions, (T, N), "actions")
+        k = self._i8(step_size, (T, N), "step_size")
+        mode = {"all": _lib.OBS_ALL, "last": _lib.OBS_LAST, None: _lib.OBS_NONE}[obs]
+        o = None
+        if mode != _lib.OBS_NONE:
+            shape = (T, N, self.obs_dim) if mode == _lib.OBS_ALL else (N, self.obs_dim)
+            if out is not None:
+                if tuple(out.shape) != shape or out.dtype != self.obs_dtype or out.device != self.device or not out.is_contiguous():
+                    raise ValueError("out must be a contiguous %s tensor of shape %s on %s" % (self.obs_dtype, shape, self.device))
+                o = out
+            else:
+                o = torch.empty(shape, dtype=self.obs_dtype, device=self.device)
+        reward = torch.empty((T, N), dtype=torch.float32, device=self.device) if want_reward else None
+        done = torch.empty((T, N), dtype=torch.uint8, device=self.device) if want_done else None
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_rollout(C.byref(self._desc), C.byref(self._state), T, self.t & 0xFFFFFFFF, _ptr(a), _ptr(k),
+                                              mode, _ptr(o), _ptr(reward), _ptr(done), self._stream()))
+        self.t += T
+        return o, reward, (done.view(torch.bool) if done is not None else None)
+
+    def observe(self):
+        obs = self._new_obs()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_observe(C.byref(self._desc), C.byref(self._state), _ptr(obs), self._stream()))
+        return obs
+
+    def iou(self):
+        """float64 [N]: env.iou() (1D, 3D) / the caller-side boolean IoU of the 2D scripts."""
+        out = torch.empty((self.num_envs,), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_iou(C.byref(self._desc), C.byref(self._state), _ptr(out), self._stream()))
+        return out
+
+    def environment_memory(self):
+        """float64 [N, H, W] with the -1 frame, as the reference holds it."""
+        sz = self.sizes
+        out = torch.empty((self.num_envs, sz.env_height, sz.env_width), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_export_grid(C.byref(self._desc), C.byref(self._state), _ptr(out), self._stream()))
+        return out
+
+    # ---- state views (decoded from the packed 16-byte header) -------------------------------------
+    def _h8(self):
+        return self._hdr.view(torch.int8)
+
+    def _h16(self):
+        return self._hdr.view(torch.int16)
+
+    @property
+    def position(self):
+        """[N, 2] (row, col) in bordered coordinates; 1D: column 0 is the position."""
+        return self._h8()[:, 0:2].to(torch.int64)
+
+    @property
+    def need_reset(self):
+        return (self._h8()[:, 2] & _lib.FLAG_NEED_RESET) != 0
+
+    @property
+    def count_brick(self):
+        return self._h16()[:, 2].to(torch.int64)
+
+    @property
+    def count_step(self):
+        return self._h16()[:, 3].to(torch.int64)
+
+    @property
+    def total_brick(self):
+        return self._h16()[:, 4].to(torch.int64)
+
+    @property
+    def plan_idx(self):
+        return self._h16()[:, 5].to(torch.int64)
+
+    @property
+    def episode_return(self):
+        return self._hdr[:, 3].to(torch.int64)
+
+    @property
+    def episode(self):
+        return self._episode.to(torch.int64)
+
+    def plan(self):
+        """float64 [N, ...]: the full plan of every env (reference attribute `plan`)."""
+        table = torch.from_numpy(self.plans_full).to(self.device)
+        return table[self.plan_idx]
+
+    def input_plan(self):
+        """float64 [N, 20, 20] (2D/3D): plan[3:23, 3:23], the reference's `input_plan`."""
+        if self.kind == 1:
+            return self.plan()
+        return self.plan()[:, 3:23, 3:23]
+
+    def episodic_stats(self):
+        """Local sums over finished episodes: dict(episodes, return_sum, iou_fx_sum) of python ints (iou in 2^-40 units)."""
+        s = self._stats.sum(dim=1).tolist()
+        return dict(episodes=int(s[0]), return_sum=int(s[1]), iou_fx_sum=int(s[2]))
+
+    def stats_tensor(self):
+        """int64 [3] on device: [episodes, return_sum, iou_fx_sum]; what snac_amd.dist all-reduces."""
+        return self._stats.sum(dim=1)
