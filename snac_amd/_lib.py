@@ -57,6 +57,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SnacError("libsnac_hip.so is not built (%s); run __graft_entry__.build() or `make -C snac_amd/csrc`. "
                             "There is no CPU fallback." % LIB_PATH)
+        # torch first: libsnac_hip.so needs libamdhip64.so.7 and must bind to the HIP runtime that PyTorch-ROCm
+        # bundles (same SONAME) -- loading the system copy beside it would put two runtimes in one process.
+        import torch  # noqa: F401
+
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.snac_version.restype = C.c_int
