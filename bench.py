@@ -34,29 +34,37 @@ def cpu_baseline(kind, dynamic, n, T, seed):
     from oracle import snac_oracle
     from snac_amd import plans
 
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
     full = plans.dataset(kind, "dense", "train") if dynamic else plans.static_plan(kind, 0)[None]
     table = full.reshape(len(full), -1).astype(np.int32)
-    orc = snac_oracle.OracleBatch(kind, dynamic, n, table, seed=seed)
-    orc.reset()
-    chunk = 10
-    D = orc.obs_dim
-    obs = np.zeros((chunk, n, D), np.float64)
-    rew = np.zeros((chunk, n), np.float32)
-    done = np.zeros((chunk, n), np.uint8)
     L = snac_oracle.lib()
-    L.orc_batch_rollout(orc.b, chunk, 0, None, None, obs.ctypes.data, 0, rew.ctypes.data, done.ctypes.data, cores)  # warm
-    t0 = time.perf_counter()
-    steps = 0
-    t = chunk
-    while t < T + chunk and time.perf_counter() - t0 < 30.0:
-        L.orc_batch_rollout(orc.b, chunk, t, None, None, obs.ctypes.data, 0, rew.ctypes.data, done.ctypes.data, cores)
-        t += chunk
-        steps += chunk * n
-    dt = time.perf_counter() - t0
-    return dict(value=steps / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample="C oracle, OpenMP x%d, %d envs x %d steps of the same workload (f64 obs of every step written)" % (
-                    cores, n, steps // n))
+    chunk = 10
+    best = None
+    # all host threads the process may use, and a single thread (the scalar port); report the faster
+    for cores, budget in ((avail, 12.0), (1, 6.0)):
+        orc = snac_oracle.OracleBatch(kind, dynamic, n, table, seed=seed)
+        orc.reset()
+        obs = np.zeros((chunk, n, orc.obs_dim), np.float64)
+        rew = np.zeros((chunk, n), np.float32)
+        done = np.zeros((chunk, n), np.uint8)
+        args = (None, None, obs.ctypes.data, 0, rew.ctypes.data, done.ctypes.data, cores)
+        L.orc_batch_rollout(orc.b, chunk, 0, *args)  # warm-up chunk
+        t0 = time.perf_counter()
+        steps, t = 0, chunk
+        while t < T and time.perf_counter() - t0 < budget:
+            L.orc_batch_rollout(orc.b, chunk, t, *args)
+            t += chunk
+            steps += chunk * n
+        rate = steps / (time.perf_counter() - t0)
+        if best is None or rate > best["value"]:
+            best = dict(value=rate, unit="env-steps/s", cores=cores, kind="port",
+                        sample="C oracle (oracle/snac_oracle.c), %d OpenMP thread(s), %d envs x %d vector steps of the same "
+                               "workload, f64 obs/reward/done of every step written" % (cores, n, steps // n))
+        del orc
+    return best
 
 
 def main():

@@ -1,0 +1,43 @@
+"""Summarise a tools/profile.sh output directory: per-kernel time stats and per-dispatch PMC averages."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+
+for f in find("trace/**/*kernel_stats.csv"):
+    print("== kernel stats:", os.path.relpath(f, out))
+    with open(f) as fh:
+        for i, row in enumerate(csv.reader(fh)):
+            if i < 12:
+                print(", ".join(row))
+for f in find("trace/**/*kernel_trace.csv"):
+    durs = defaultdict(list)
+    meta = {}
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            name = row["Kernel_Name"]
+            durs[name].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            meta[name] = {k: row.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size")}
+    print("== kernel trace:", os.path.relpath(f, out))
+    for name, d in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
+        short = name[:90]
+        print("%-90s n=%d avg=%.1f us min=%.1f max=%.1f total=%.3f ms %s" % (short, len(d), sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3, sum(d) / 1e6, meta[name]))
+for f in find("pmc_*/**/*counter_collection.csv"):
+    acc = defaultdict(lambda: defaultdict(list))
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    print("== pmc:", os.path.relpath(f, out))
+    for name, cs in acc.items():
+        if "rollout" not in name and "k_" not in name:
+            continue
+        for c, v in cs.items():
+            print("%-60s %-24s n=%d avg=%.6g" % (name[:60], c, len(v), sum(v) / len(v)))
