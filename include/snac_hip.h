@@ -88,7 +88,8 @@ typedef struct snac_env_hdr {   /* 16 bytes, 16-byte aligned */
     uint8_t flags;              /* SNAC_FLAG_* */
     uint8_t reserved;
     int16_t count_brick, count_step, total_brick, plan_idx;
-    int32_t ep_return;          /* integer return of the running episode (rewards are integers) */
+    int16_t ep_return;          /* integer return of the running episode (rewards are integers) */
+    int16_t cross;              /* 3D: running sum of min(height, plan) over the interior (numerator of iou()) */
 } snac_env_hdr;
 
 typedef struct snac_env_desc {

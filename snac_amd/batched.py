@@ -219,7 +219,7 @@ class BatchedDMPEnv:
 
     @property
     def episode_return(self):
-        return self._hdr[:, 3].to(torch.int64)
+        return self._h16()[:, 6].to(torch.int64)
 
     @property
     def episode(self):

@@ -1,18 +1,20 @@
 // snac_hip.hip -- gfx950 (MI355X) kernels and the C ABI of include/snac_hip.h.
 //
-// One wavefront (64 lanes) owns one env.  The env record is read once (16-byte header by scalar load,
-// grid row(s) with unit-stride lanes), kept on chip for all T steps of a launch, and written back once:
-//   1D  30 heights, one per lane, in a VGPR; the 5-cell window is a cross-lane read
-//   2D  20x20 occupancy bit-board, one 20-bit row per lane in a VGPR; the 7x7 window is one
-//       ds_bpermute (LDS crossbar) + shift/mask per lane
-//   3D  20x20 height map and its plan staged in LDS (2 x 800 B per wave); the 7x7 window is one
-//       ds_read_u16 per lane and stays in a VGPR as the collision neighbourhood of the next step
-// Lanes 0..W-1 (W = 5 or 49) each produce one window cell of the observation, lanes W and W+1 the two
-// scalar slots, so the observation row of an env is one contiguous store of obs_dim elements.
-// Integer / indexing work only -- no MFMA; the bound is HBM (obs writes).  See DESIGN.md.
+// Execution shape (DESIGN.md "Kernel"): one wavefront owns a TILE of E consecutive envs (E = 16/32/64).
+//   phase 1  lane l steps env (tile base + l): counter RNG, move / drop / build transition, reward, done,
+//            auto-reset, episodic sums -- plain per-lane VALU code, the env grids live in this wave's LDS
+//   phase 2  the whole wave writes the tile's observations: for each env, lanes 0..48 fetch one window cell
+//            each from LDS, lanes 49/50 the two scalar slots, and the 51 values leave as one contiguous
+//            store; a tile therefore writes E x 408 contiguous bytes per step (5.9 TB/s store shape,
+//            profiles/r01_wr_bench.txt), against 3.7-3.9 TB/s for one 408-byte row per wave.
+// The env records are read from HBM once per launch, kept on chip for all T steps, written back once.
+// Round-1's first kernel ran one env per wave with the env scalars in SGPRs: it was bound by the CU's
+// single scalar ALU (67 SALU instructions per env-step, profiles/r01_a_*) and by the store shape.
+// Integer / indexing work only -- no MFMA; the bound is HBM (observation writes).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "snac_hip.h"
@@ -42,7 +44,7 @@ inline uint32_t stream_key(uint64_t seed, uint32_t stream) {
 }
 struct EnvKeys { uint32_t e0, e1; };
 __device__ inline EnvKeys env_keys(uint32_t key, uint64_t env) {
-    uint32_t elo = (uint32_t)env, ehi = (uint32_t)(env >> 32);
+    const uint32_t elo = (uint32_t)env, ehi = (uint32_t)(env >> 32);
     EnvKeys k;
     k.e0 = mix32(key ^ mix32(elo + 0x85EBCA6Bu * ehi + 0x1B873593u));
     k.e1 = mix32((key + 0x27D4EB2Fu) ^ mix32((elo ^ 0x165667B1u) + 0xC2B2AE35u * ehi));
@@ -55,7 +57,7 @@ struct KArgs {
     int32_t n, num_plans, static_plan, T, auto_reset, obs_mode;
     uint32_t t0, key_step, key_plan;
     int64_t env_id_base;
-    snac_env_hdr* hdr;
+    int4* hdr;                 // snac_env_hdr[N] as 16-byte words
     int32_t* episode;
     void* grid;
     const void* plans;
@@ -68,340 +70,398 @@ struct KArgs {
     void* obs;
     float* reward;
     uint8_t* done;
-    // reset kernel only
+    // aux kernel only
+    int32_t aux_op;            // AUX_*
     const uint8_t* mask;
     const int16_t* plan_idx_in;
-    int32_t observe_only;
     double* out_f64;
 };
-
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+enum { AUX_RESET = 0, AUX_OBSERVE = 1, AUX_IOU = 2 };
 
 constexpr double FX40 = 1099511627776.0;  // 2^40
 
-// Scalar part of an env, shared by the three kinds.  Everything here is wave-uniform.
-struct Scalars {
-    int r, c, cb, cs, tb, pidx, ep_ret, flags;
-    __device__ void from(const snac_env_hdr& h) {
-        r = h.pos_r; c = h.pos_c; flags = h.flags; cb = h.count_brick; cs = h.count_step; tb = h.total_brick;
-        pidx = h.plan_idx; ep_ret = h.ep_return;
+// per-lane env scalars (one env per lane in phase 1)
+struct Lane {
+    int r, c, flags, cb, cs, tb, pidx, ep_ret, cross;
+    __device__ void unpack(const int4 h) {
+        r = (int)(int8_t)(h.x & 0xff); c = (int)(int8_t)((h.x >> 8) & 0xff); flags = (h.x >> 16) & 0xff;
+        cb = (int)(int16_t)(h.y & 0xffff); cs = h.y >> 16;
+        tb = (int)(int16_t)(h.z & 0xffff); pidx = h.z >> 16;
+        ep_ret = (int)(int16_t)(h.w & 0xffff); cross = h.w >> 16;
     }
-    __device__ snac_env_hdr to() const {
-        snac_env_hdr h;
-        h.pos_r = (int8_t)r; h.pos_c = (int8_t)c; h.flags = (uint8_t)flags; h.reserved = 0;
-        h.count_brick = (int16_t)cb; h.count_step = (int16_t)cs; h.total_brick = (int16_t)tb; h.plan_idx = (int16_t)pidx;
-        h.ep_return = ep_ret;
+    __device__ int4 pack() const {
+        int4 h;
+        h.x = (r & 0xff) | ((c & 0xff) << 8) | ((flags & 0xff) << 16);
+        h.y = (cb & 0xffff) | (cs << 16);
+        h.z = (tb & 0xffff) | (pidx << 16);
+        h.w = (ep_ret & 0xffff) | (cross << 16);
         return h;
+    }
+    __device__ void clear() { r = c = flags = cb = cs = tb = pidx = ep_ret = cross = 0; }
+};
+
+// ================================================================================================
+// 2D: Env/2D/DMP_Env_2D_static.py, Env/2D/DMP_Env_2D_dynamic_usedata_plan.py
+// LDS per wave: G[(row + 3) * RS + e], row in [-3, 22] (guard rows stay 0), RS = E + 1 (odd dword stride: the
+// 7 rows one env's window touches fall in 7 different banks); then SC[e][2] float64.
+template <bool DYN_, int E_>
+struct K2D {
+    static constexpr bool DYN = DYN_;
+    static constexpr int E = E_, D = 51, W = 49, A = 5, TS = 600, GE = 20, RS = E + 1;
+    static constexpr int G_WORDS = 26 * RS + ((26 * RS) & 1);     // keep SC 8-byte aligned
+    static constexpr int LDS_WORDS = G_WORDS + 4 * E;
+
+    __device__ static double* sc(uint32_t* lds) { return (double*)(lds + G_WORDS); }
+
+    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+        for (int i = lane; i < 3 * RS; i += 64) { lds[i] = 0u; lds[23 * RS + i] = 0u; }
+        const uint32_t* src = (const uint32_t*)a.grid + (size_t)env0 * GE;
+        for (int i = lane; i < nenv * GE; i += 64) {
+            const int e = i / GE, row = i - e * GE;
+            lds[(row + 3) * RS + e] = src[i];
+        }
+    }
+    __device__ static void store_grid(const uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+        uint32_t* dst = (uint32_t*)a.grid + (size_t)env0 * GE;
+        for (int i = lane; i < nenv * GE; i += 64) {
+            const int e = i / GE, row = i - e * GE;
+            dst[i] = lds[(row + 3) * RS + e];
+        }
+    }
+    // reset: DMP_Env_2D_dynamic_usedata_plan.py:34-66 (the total_brick floor of 30 is folded into plan_tb)
+    __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
+        s.pidx = pidx; s.tb = a.plan_tb[pidx];
+        s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
+    }
+    __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave zeroes env e's grid
+        if (lane < GE) lds[(lane + 3) * RS + e] = 0u;
+    }
+    // step: DMP_Env_2D_dynamic_usedata_plan.py:85-147
+    __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int lane, int& reward, bool& done) {
+        const int row = s.r - 3;
+        const uint32_t bit = 1u << (s.c - 3);
+        const uint32_t gbits = lds[(row + 3) * RS + lane];
+        const uint32_t pbits = ((const uint32_t*)a.plans)[s.pidx * GE + row];
+        const bool drop = act == 4;
+        s.cs += 1;
+        if (drop) {
+            s.cb += 1;
+            lds[(row + 3) * RS + lane] = gbits | bit;               // += 1 then clamp to 1 (:115, :134-135)
+        }
+        if (act == 0) s.c = max(s.c - k, 3);                         // clip_position :74-83
+        if (act == 1) s.c = min(s.c + k, 22);
+        if (act == 2) s.r = min(s.r + k, 22);                        // "up" is row + k (:100-103)
+        if (act == 3) s.r = max(s.r - k, 3);
+        const bool term = drop && s.cb >= s.tb;                      // :117-126, tested before the time limit
+        done = term || s.cs >= TS;
+        // un-clamped cell vs plan (:129-133): 5 iff the cell was empty and is planned
+        reward = (drop && !term && (gbits & bit) == 0u && (pbits & bit) != 0u) ? 5 : 0;
+    }
+    // boolean IoU: script/DQN/2d/DQN_2d_dynamic.py:63-71
+    __device__ static double iou(const uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
+        int inter = 0, uni = 0;
+        for (int row = 0; row < GE; ++row) {
+            const uint32_t g = lds[(row + 3) * RS + lane];
+            const uint32_t p = want ? ((const uint32_t*)a.plans)[s.pidx * GE + row] : 0u;
+            inter += __popc(g & p); uni += __popc(g | p);
+        }
+        return (double)inter / (double)uni;
+    }
+    // one window cell of env e: DMP_Env_2D_dynamic_usedata_plan.py:68-72
+    __device__ static int window(const uint32_t* lds, int e, int pr, int pc, int wi, int wj) {
+        const int row = pr - 6 + wi, col = pc - 6 + wj;              // interior coordinates
+        const uint32_t bits = lds[(row + 3) * RS + e];
+        const bool inside = (unsigned)row < 20u && (unsigned)col < 20u;
+        return inside ? (int)((bits >> (col & 31)) & 1u) : -1;
     }
 };
 
-// ------------------------------------------------------------------------------------------------
-// 1D: Env/1D/DMP_Env_1D_static.py, Env/1D/DMP_Env_1D_dynamic_usedata_plan.py
-template <bool DYN_>
-struct Env1D {
+// ================================================================================================
+// 3D: Env/3D/DMP_simulator_3d_static_circle.py, Env/3D/DMP_simulator_3d_dynamic_triangle_usedata.py
+// LDS per wave: H[e * ES + cell] int16 heights of the 20x20 interior, ES = 402 (odd dword stride); then SC.
+template <bool DYN_, int E_>
+struct K3D {
     static constexpr bool DYN = DYN_;
-    static constexpr int D = 7, W = 5, A = 3, TS = 750, GE = 32, LDS_BYTES = 0;
-    Scalars s;
-    int g, p;  // lane l < 30: height / plan of interior cell l (bordered index l + 2)
+    static constexpr int E = E_, D = 51, W = 49, A = 8, TS = DYN_ ? 1000 : 1300, GE = 400, ES = 402;
+    static constexpr int G_WORDS = E * ES / 2 + ((E * ES / 2) & 1);
+    static constexpr int LDS_WORDS = G_WORDS + 4 * E;
 
-    __device__ void bind(char*, int) {}
-    __device__ void load(const KArgs& a, int env, int lane) {
-        s.from(a.hdr[env]);
-        g = lane < GE ? ((const int16_t*)a.grid)[(size_t)env * GE + lane] : 0;
-        load_plan(a, lane);
-    }
-    __device__ void load_plan(const KArgs& a, int lane) {
-        p = lane < GE ? ((const int16_t*)a.plans)[(size_t)s.pidx * GE + lane] : 0;
-    }
-    __device__ void store(const KArgs& a, int env, int lane) const {
-        if (lane == 0) a.hdr[env] = s.to();
-        if (lane < GE) ((int16_t*)a.grid)[(size_t)env * GE + lane] = (int16_t)g;
-    }
-    // reset: DMP_Env_1D_static.py:66-83, DMP_Env_1D_dynamic_usedata_plan.py:40-70
-    __device__ void reset(const KArgs& a, int pidx, int lane) {
-        s.pidx = pidx; s.tb = a.plan_tb[pidx];
-        s.r = 2; s.c = 0; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.flags = 0;
-        g = 0;
-        load_plan(a, lane);
-    }
-    // step: DMP_Env_1D_static.py:85-136
-    __device__ void step(int act, int k, int lane, int& reward, bool& done) {
-        s.cs += 1;
-        reward = 0;
-        done = s.cs >= TS;
-        if (act == 0) s.r = max(s.r - k, 2);            // clip_position :57-64
-        else if (act == 1) s.r = min(s.r + k, 31);
-        else if (act == 2) {
-            const int cell = s.r - 2;
-            s.cb += 1;
-            const int h = rdlane(g, cell) + 1;
-            const int pl = rdlane(p, cell);
-            if (lane == cell) g = h;
-            if (s.cb >= s.tb) { reward = 0; done = true; }      // :107-114, before the time limit
-            else reward = h > pl ? -1 : (h == pl ? 10 : 1);     // :117-123
+    __device__ static double* sc(uint32_t* lds) { return (double*)(lds + G_WORDS); }
+
+    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+        const uint32_t* src = (const uint32_t*)((const int16_t*)a.grid + (size_t)env0 * GE);
+        for (int i = lane; i < nenv * (GE / 2); i += 64) {
+            const int e = i / (GE / 2), d = i - e * (GE / 2);
+            lds[e * (ES / 2) + d] = src[i];
         }
     }
-    __device__ double obs_value(int lane) const {
-        const int cell = s.r - 2 + lane - 2;                    // interior index of window cell `lane`
-        const int v = __shfl(g, cell, 64);
-        const bool inside = (unsigned)cell < 30u;
-        const double num = lane == W ? (double)s.cb : (double)s.cs;
-        const double den = lane == W ? (double)s.tb : (double)TS;
-        const double sc = DYN ? num / den : num;
-        return lane < W ? (double)(inside ? v : -1) : sc;
+    __device__ static void store_grid(const uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+        uint32_t* dst = (uint32_t*)((int16_t*)a.grid + (size_t)env0 * GE);
+        for (int i = lane; i < nenv * (GE / 2); i += 64) {
+            const int e = i / (GE / 2), d = i - e * (GE / 2);
+            dst[i] = lds[e * (ES / 2) + d];
+        }
+    }
+    __device__ static int cell(const int16_t* h, int rr, int cc) {   // interior coordinates; frame = -1
+        const bool inside = (unsigned)rr < 20u && (unsigned)cc < 20u;
+        return inside ? (int)h[rr * 20 + cc] : -1;
+    }
+    // reset: DMP_simulator_3d_dynamic_triangle_usedata.py:45-75
+    __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
+        s.pidx = pidx; s.tb = a.plan_tb[pidx];
+        s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
+    }
+    __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave zeroes env e's grid
+        uint32_t* h = lds + e * (ES / 2);
+#pragma unroll
+        for (int d = lane; d < GE / 2; d += 64) h[d] = 0u;
+    }
+    // step: DMP_simulator_3d_static_circle.py:153-230, DMP_simulator_3d_dynamic_triangle_usedata.py:142-231
+    __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int lane, int& reward, bool& done) {
+        int16_t* h = (int16_t*)lds + lane * ES;
+        const int rr = s.r - 3, cc = s.c - 3;
+        s.cs += 1;
+        reward = 0;
+        // check_sur (:88-102 / :77-91): left, right, "up" (row + 1), "down" (row - 1)
+        const int n0 = cell(h, rr, cc - 1), n1 = cell(h, rr, cc + 1), n2 = cell(h, rr + 1, cc), n3 = cell(h, rr - 1, cc);
+        const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
+        done = (s.cs >= TS) || (!DYN && boxed_pre);                  // bottom of step(): static :226, dynamic :226
+        const int d = act & 3;
+        const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
+        const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
+        const bool valid = (unsigned)act < 8u;
+        if (valid && act < 4) {
+            if (nd == 0) {                                           // check[act] == 0
+                // move_step (:104-134): consecutive free cells, at most k; clip_position is then a no-op
+                const int c2 = cell(h, rr + 2 * dr, cc + 2 * dc), c3 = cell(h, rr + 3 * dr, cc + 3 * dc);
+                int m = 1;
+                if (k >= 2 && c2 == 0) { m = 2; if (k >= 3 && c3 == 0) m = 3; }
+                s.r += dr * m; s.c += dc * m;
+            }
+        } else if (valid) {
+            const bool built = nd != -1;                             // check[act] == 0 for act in 4..7
+            const int newh = nd + 1;
+            const int tcell = (rr + dr) * 20 + (cc + dc);
+            int pl = 0;
+            if (built) {
+                s.cb += 1;
+                h[tcell] = (int16_t)newh;
+                pl = ((const int16_t*)a.plans)[s.pidx * GE + tcell];
+                s.cross += newh <= pl ? 1 : 0;                       // running sum of min(height, plan) for iou()
+            }
+            bool fin = false;
+            if (DYN) {
+                // neighbours re-evaluated AFTER the build (:199-206)
+                const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0))
+                                              : boxed_pre;
+                if (boxed_post) { reward = -100; done = true; fin = true; }
+                else if (s.cb >= s.tb) { reward = 0; done = true; fin = true; }          // :207-213
+            } else {
+                if (s.cb >= s.tb || boxed_pre) { reward = 0; done = true; fin = true; }  // :210-215
+            }
+            if (!fin && built) {                                     // reward_check (:232-239); time limit NOT tested
+                reward = newh > pl ? -1 : (newh == pl ? 10 : 1);
+                done = false;
+            }
+        }
+    }
+    // iou (:257-276) = sum(min(g, plan)) / (tb + cb - sum); the sum is tracked incrementally in s.cross
+    __device__ static double iou(const uint32_t*, const KArgs&, const Lane& s, bool, int) {
+        return (double)s.cross / (double)(s.tb + s.cb - s.cross);
+    }
+    // the same from the grid (snac_iou)
+    __device__ static double iou_full(const uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
+        const int16_t* h = (const int16_t*)lds + lane * ES;
+        int cross = 0;
+        for (int i = 0; i < GE; ++i) {
+            const int p = want ? (int)((const int16_t*)a.plans)[s.pidx * GE + i] : 0;
+            cross += min((int)h[i], p);
+        }
+        return (double)cross / (double)(s.tb + s.cb - cross);
+    }
+    __device__ static int window(const uint32_t* lds, int e, int pr, int pc, int wi, int wj) {
+        return cell((const int16_t*)lds + e * ES, pr - 6 + wi, pc - 6 + wj);
+    }
+};
+
+// ================================================================================================
+// 1D: Env/1D/DMP_Env_1D_static.py, Env/1D/DMP_Env_1D_dynamic_usedata_plan.py
+// LDS per wave: H[e * ES + cell] int16, ES = 34 (odd dword stride); then SC; then POS[e].
+template <bool DYN_, int E_>
+struct K1D {
+    static constexpr bool DYN = DYN_;
+    static constexpr int E = E_, D = 7, W = 5, A = 3, TS = 750, GE = 32, ES = 34;
+    static constexpr int G_WORDS = E * ES / 2 + ((E * ES / 2) & 1);
+    static constexpr int LDS_WORDS = G_WORDS + 4 * E + E;
+
+    __device__ static double* sc(uint32_t* lds) { return (double*)(lds + G_WORDS); }
+    __device__ static int* pos(uint32_t* lds) { return (int*)(lds + G_WORDS + 4 * E); }
+
+    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+        const uint32_t* src = (const uint32_t*)((const int16_t*)a.grid + (size_t)env0 * GE);
+        for (int i = lane; i < nenv * (GE / 2); i += 64) {
+            const int e = i / (GE / 2), d = i - e * (GE / 2);
+            lds[e * (ES / 2) + d] = src[i];
+        }
+    }
+    __device__ static void store_grid(const uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+        uint32_t* dst = (uint32_t*)((int16_t*)a.grid + (size_t)env0 * GE);
+        for (int i = lane; i < nenv * (GE / 2); i += 64) {
+            const int e = i / (GE / 2), d = i - e * (GE / 2);
+            dst[i] = lds[e * (ES / 2) + d];
+        }
+    }
+    // reset: DMP_Env_1D_static.py:66-83, DMP_Env_1D_dynamic_usedata_plan.py:40-70
+    __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
+        s.pidx = pidx; s.tb = a.plan_tb[pidx];
+        s.r = 2; s.c = 0; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
+    }
+    __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave zeroes env e's grid
+        if (lane < GE / 2) lds[e * (ES / 2) + lane] = 0u;
+    }
+    // step: DMP_Env_1D_static.py:85-136
+    __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int lane, int& reward, bool& done) {
+        int16_t* h = (int16_t*)lds + lane * ES;
+        const int cellidx = s.r - 2;
+        const int hnew = (int)h[cellidx] + 1;
+        const int pl = ((const int16_t*)a.plans)[s.pidx * GE + cellidx];
+        const bool drop = act == 2;
+        s.cs += 1;
+        if (drop) { s.cb += 1; h[cellidx] = (int16_t)hnew; }
+        if (act == 0) s.r = max(s.r - k, 2);                         // clip_position :57-64
+        if (act == 1) s.r = min(s.r + k, 31);
+        const bool term = drop && s.cb >= s.tb;                      // :107-114, before the time limit
+        done = term || s.cs >= TS;
+        reward = (drop && !term) ? (hnew > pl ? -1 : (hnew == pl ? 10 : 1)) : 0;   // :117-123
     }
     // iou: DMP_Env_1D_static.py:138-151
-    __device__ double iou(int lane) const {
-        const int a1 = wave_sum(p), a2 = wave_sum(g), k = wave_sum(max(g - p, 0));
-        const int cross = a2 - k;
+    __device__ static double iou(const uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
+        const int16_t* h = (const int16_t*)lds + lane * ES;
+        int a1 = 0, a2 = 0, kk = 0;
+        for (int i = 0; i < 30; ++i) {
+            const int g = h[i];
+            const int p = want ? (int)((const int16_t*)a.plans)[s.pidx * GE + i] : 0;
+            a1 += p; a2 += g; kk += max(g - p, 0);
+        }
+        const int cross = a2 - kk;
         return (double)cross / (double)(a1 + a2 - cross);
     }
 };
 
 // ------------------------------------------------------------------------------------------------
-// 2D: Env/2D/DMP_Env_2D_static.py, Env/2D/DMP_Env_2D_dynamic_usedata_plan.py
-template <bool DYN_>
-struct Env2D {
-    static constexpr bool DYN = DYN_;
-    static constexpr int D = 51, W = 49, A = 5, TS = 600, GE = 20, LDS_BYTES = 0;
-    Scalars s;
-    uint32_t g, p;  // lane l < 20: occupancy / plan bits of interior row l
-    int wi, wj;     // window coordinates of this lane
-
-    __device__ void bind(char*, int lane) { wi = lane / 7; wj = lane - 7 * wi; }
-    __device__ void load(const KArgs& a, int env, int lane) {
-        s.from(a.hdr[env]);
-        g = lane < GE ? ((const uint32_t*)a.grid)[(size_t)env * GE + lane] : 0u;
-        load_plan(a, lane);
-    }
-    __device__ void load_plan(const KArgs& a, int lane) {
-        p = lane < GE ? ((const uint32_t*)a.plans)[(size_t)s.pidx * GE + lane] : 0u;
-    }
-    __device__ void store(const KArgs& a, int env, int lane) const {
-        if (lane == 0) a.hdr[env] = s.to();
-        if (lane < GE) ((uint32_t*)a.grid)[(size_t)env * GE + lane] = g;
-    }
-    // reset: DMP_Env_2D_dynamic_usedata_plan.py:34-66 (total_brick floor of 30 is folded into plan_tb)
-    __device__ void reset(const KArgs& a, int pidx, int lane) {
-        s.pidx = pidx; s.tb = a.plan_tb[pidx];
-        s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.flags = 0;
-        g = 0u;
-        load_plan(a, lane);
-    }
-    // step: DMP_Env_2D_dynamic_usedata_plan.py:85-147
-    __device__ void step(int act, int k, int lane, int& reward, bool& done) {
-        s.cs += 1;
-        reward = 0;
-        done = s.cs >= TS;
-        if (act == 0) s.c = max(s.c - k, 3);                    // clip_position :74-83
-        else if (act == 1) s.c = min(s.c + k, 22);
-        else if (act == 2) s.r = min(s.r + k, 22);              // "up" is row + k (:100-103)
-        else if (act == 3) s.r = max(s.r - k, 3);
-        else if (act == 4) {
-            const int row = s.r - 3;
-            const uint32_t bit = 1u << (s.c - 3);
-            s.cb += 1;
-            const bool was = (rdlane((int)g, row) & bit) != 0u;
-            const bool planned = (rdlane((int)p, row) & bit) != 0u;
-            if (lane == row) g |= bit;                          // += 1 then clamp to 1 (:115, :134-135)
-            if (s.cb >= s.tb) { reward = 0; done = true; }      // :117-126, before the time limit
-            else reward = (!was && planned) ? 5 : 0;            // un-clamped cell vs plan (:129-133)
+// phase 2: write the observation rows of the tile's envs.  orow points at [env0][0] of the target step.
+template <class K, typename OT>
+__device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int pos_packed, int lane) {
+    if constexpr (K::D == 51) {
+        const int wl = lane < K::W ? lane : 0;
+        const int wi = wl / 7, wj = wl - 7 * wi;
+        const double* scp = K::sc(lds);
+        const int sidx = lane >= K::W ? min(lane - K::W, 1) : 0;
+        OT* p = orow + lane;
+#pragma unroll 4
+        for (int e = 0; e < nenv; ++e) {
+            const int pp = __builtin_amdgcn_readlane(pos_packed, e);
+            const int v = K::window(lds, e, pp & 0xff, pp >> 8, wi, wj);
+            const double s = scp[2 * e + sidx];
+            const double val = lane < K::W ? (double)v : s;
+            if (lane < K::D) p[e * K::D] = (OT)val;
         }
-    }
-    __device__ double obs_value(int lane) const {
-        const int row = s.r - 6 + wi, col = s.c - 6 + wj;       // interior coordinates of the window cell
-        const uint32_t bits = (uint32_t)__shfl((int)g, row, 64);
-        const bool inside = (unsigned)row < 20u && (unsigned)col < 20u;
-        const int v = inside ? (int)((bits >> (col & 31)) & 1u) : -1;
-        const double num = lane == W ? (double)s.cb : (double)s.cs;
-        const double den = lane == W ? (double)s.tb : (double)TS;
-        const double sc = DYN ? num / den : num;
-        return lane < W ? (double)v : sc;
-    }
-    // boolean IoU: script/DQN/2d/DQN_2d_dynamic.py:63-71
-    __device__ double iou(int lane) const {
-        const int inter = wave_sum(__popc(g & p)), uni = wave_sum(__popc(g | p));
-        return (double)inter / (double)uni;
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-// 3D: Env/3D/DMP_simulator_3d_static_circle.py, Env/3D/DMP_simulator_3d_dynamic_triangle_usedata.py
-template <bool DYN_>
-struct Env3D {
-    static constexpr bool DYN = DYN_;
-    static constexpr int D = 51, W = 49, A = 8, TS = DYN_ ? 1000 : 1300, GE = 400, LDS_BYTES = 2 * GE * 2;
-    Scalars s;
-    int16_t* lg;    // LDS: this wave's 20x20 height map
-    int16_t* lp;    // LDS: this wave's plan
-    int win;        // lane < 49: current window cell (frame = -1)
-    int wi, wj;
-
-    __device__ void bind(char* lds, int lane) { lg = (int16_t*)lds; lp = lg + GE; wi = lane / 7; wj = lane - 7 * wi; }
-    __device__ int window_cell() const {
-        const int row = s.r - 6 + wi, col = s.c - 6 + wj;
-        const bool inside = (unsigned)row < 20u && (unsigned)col < 20u;
-        return inside ? (int)lg[row * 20 + col] : -1;
-    }
-    __device__ void load(const KArgs& a, int env, int lane) {
-        s.from(a.hdr[env]);
-        const uint32_t* src = (const uint32_t*)((const int16_t*)a.grid + (size_t)env * GE);
-        for (int i = lane; i < GE / 2; i += 64) ((uint32_t*)lg)[i] = src[i];
-        load_plan(a, lane);
-        win = lane < W ? window_cell() : 0;
-    }
-    __device__ void load_plan(const KArgs& a, int lane) {
-        const uint32_t* src = (const uint32_t*)((const int16_t*)a.plans + (size_t)s.pidx * GE);
-        for (int i = lane; i < GE / 2; i += 64) ((uint32_t*)lp)[i] = src[i];
-    }
-    __device__ void store(const KArgs& a, int env, int lane) const {
-        if (lane == 0) a.hdr[env] = s.to();
-        uint32_t* dst = (uint32_t*)((int16_t*)a.grid + (size_t)env * GE);
-        for (int i = lane; i < GE / 2; i += 64) dst[i] = ((const uint32_t*)lg)[i];
-    }
-    // reset: DMP_simulator_3d_dynamic_triangle_usedata.py:45-75
-    __device__ void reset(const KArgs& a, int pidx, int lane) {
-        s.pidx = pidx; s.tb = a.plan_tb[pidx];
-        s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.flags = 0;
-        for (int i = lane; i < GE / 2; i += 64) ((uint32_t*)lg)[i] = 0u;
-        load_plan(a, lane);
-        win = lane < W ? window_cell() : 0;
-    }
-    // step: DMP_simulator_3d_static_circle.py:153-230, DMP_simulator_3d_dynamic_triangle_usedata.py:142-231
-    __device__ void step(int act, int k, int lane, int& reward, bool& done) {
-        s.cs += 1;
-        reward = 0;
-        // check_sur (:88-102 / :77-91) from the window of the previous observation: lanes (3,2) (3,4) (4,3) (2,3)
-        int nb[4] = { rdlane(win, 23), rdlane(win, 25), rdlane(win, 31), rdlane(win, 17) };
-        const bool boxed_pre = nb[0] != 0 && nb[1] != 0 && nb[2] != 0 && nb[3] != 0;
-        done = (s.cs >= TS) || (!DYN && boxed_pre);             // static :226, dynamic :226
-        if ((unsigned)act > 7u) return;
-        const int d = act & 3;
-        const int dl = d == 0 ? -1 : (d == 1 ? 1 : (d == 2 ? 7 : -7));   // window-lane step of the direction
-        const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
-        const int nd = d == 0 ? nb[0] : (d == 1 ? nb[1] : (d == 2 ? nb[2] : nb[3]));
-        if (act < 4) {
-            if (nd == 0) {                                      // check[act] == 0
-                // move_step (:104-134): consecutive free cells, at most k
-                const int c2 = rdlane(win, 24 + 2 * dl), c3 = rdlane(win, 24 + 3 * dl);
-                int m = 1;
-                if (k >= 2 && c2 == 0) { m = 2; if (k >= 3 && c3 == 0) m = 3; }
-                s.r += dr * m; s.c += dc * m;                   // clip_position is a no-op: walls stop the move
-                win = lane < W ? window_cell() : 0;
-            }
-            return;
-        }
-        bool built = false;
-        int newh = 0, tcell = 0;
-        if (nd != -1) {                                         // check[act] == 0 for act in 4..7
-            built = true;
-            s.cb += 1;
-            newh = nd + 1;
-            tcell = (s.r - 3 + dr) * 20 + (s.c - 3 + dc);
-            if (lane == 0) lg[tcell] = (int16_t)newh;
-            if (lane == 24 + dl) win = newh;
-        }
-        if (DYN) {
-            // neighbours re-evaluated AFTER the build (:199-206)
-            const bool boxed_post = built ? ((d == 0 || nb[0] != 0) && (d == 1 || nb[1] != 0) && (d == 2 || nb[2] != 0) &&
-                                             (d == 3 || nb[3] != 0))
-                                          : boxed_pre;
-            if (boxed_post) { reward = -100; done = true; return; }
-            if (s.cb >= s.tb) { reward = 0; done = true; return; }        // :207-213
-        } else {
-            if (s.cb >= s.tb || boxed_pre) { reward = 0; done = true; return; }   // :210-215
-        }
-        if (built) {                                            // reward_check (:232-239); time limit NOT tested
-            const int pl = lp[tcell];
-            reward = newh > pl ? -1 : (newh == pl ? 10 : 1);
-            done = false;
-        }
-    }
-    __device__ double obs_value(int lane) const {
-        const double num = lane == W ? (double)s.cb : (double)s.cs;
-        const double den = lane == W ? (double)s.tb : (double)TS;
-        const double sc = DYN ? num / den : num;
-        return lane < W ? (double)win : sc;
-    }
-    // iou: DMP_simulator_3d_static_circle.py:257-276
-    __device__ double iou(int lane) const {
-        int cross = 0;
-        for (int i = lane; i < GE; i += 64) cross += min((int)lg[i], (int)lp[i]);
-        cross = wave_sum(cross);
-        return (double)cross / (double)(s.tb + s.cb - cross);
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-template <class E, int WPB>
-__device__ __forceinline__ char* wave_lds() {
-    if constexpr (E::LDS_BYTES > 0) {
-        __shared__ __attribute__((aligned(16))) char lds[WPB * E::LDS_BYTES];
-        return lds + (threadIdx.x >> 6) * E::LDS_BYTES;
     } else {
-        return nullptr;
+        // 1D: 7 values per env -- flat, one element per lane: q = e * 7 + el
+        const int16_t* h = (const int16_t*)lds;
+        const double* scp = K::sc(lds);
+        const int* posp = K::pos(lds);
+        const int total = nenv * K::D;
+        for (int q = lane; q < total; q += 64) {
+            const int e = q / K::D, el = q - e * K::D;
+            const int cellidx = posp[e] - 4 + el;                    // interior index of window cell el
+            const bool inside = (unsigned)cellidx < 30u && el < K::W;
+            const int v = inside ? (int)h[e * K::ES + cellidx] : -1;
+            const double s = scp[2 * e + (el >= K::W ? el - K::W : 0)];
+            orow[q] = (OT)(el < K::W ? (double)v : s);
+        }
     }
 }
 
-template <class E>
+template <class K>
+__device__ __forceinline__ void stage_scalars(uint32_t* lds, const Lane& s, int lane) {
+    const double num0 = (double)s.cb, num1 = (double)s.cs;
+    double2 v;
+    v.x = K::DYN ? num0 / (double)s.tb : num0;
+    v.y = K::DYN ? num1 / (double)K::TS : num1;
+    if (lane < K::E) {
+        *(double2*)(K::sc(lds) + 2 * lane) = v;
+        if constexpr (K::D == 7) K::pos(lds)[lane] = s.r;
+    }
+}
+
+template <class K>
 __device__ __forceinline__ int pick_plan(const KArgs& a, EnvKeys pk, int episode) {
-    if (E::DYN) return (int)__umulhi(rng_word(pk, (uint32_t)episode), (uint32_t)a.num_plans);
+    if (K::DYN) return (int)__umulhi(rng_word(pk, (uint32_t)episode), (uint32_t)a.num_plans);
     return a.static_plan;
 }
 
-// T fused vector steps (T = 1: one step() call).  One wave per env.
-template <class E, typename OT, int WPB>
+template <class K, int WPB>
+__device__ __forceinline__ uint32_t* wave_lds() {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[WPB * K::LDS_WORDS];
+    return lds + (threadIdx.x >> 6) * K::LDS_WORDS;
+}
+
+// T fused vector steps (T = 1: one step() call) for one tile of E envs per wave.
+template <class K, typename OT, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
+    constexpr int E = K::E;
     const int lane = threadIdx.x & 63;
-    const int env = rfl((int)blockIdx.x * WPB + (int)(threadIdx.x >> 6));
-    if (env >= a.n) return;
-    E e;
-    e.bind(wave_lds<E, WPB>(), lane);
-    e.load(a, env, lane);
-    int episode = a.episode[env];
+    const int tile = (int)blockIdx.x * WPB + (int)(threadIdx.x >> 6);
+    const int env0 = __builtin_amdgcn_readfirstlane(tile * E);
+    if (env0 >= a.n) return;
+    const int nenv = min(E, a.n - env0);
+    const bool active = lane < nenv;
+    const int env = env0 + (active ? lane : 0);
+    uint32_t* lds = wave_lds<K, WPB>();
+    Lane s;
+    s.clear();
+    int episode = 0;
+    if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
+    K::load_grid(lds, a, env0, nenv, lane);
     const uint64_t gid = (uint64_t)(a.env_id_base + env);
     const EnvKeys sk = env_keys(a.key_step, gid), pk = env_keys(a.key_plan, gid);
     int d_eps = 0, d_ret = 0;
     long long d_iou = 0;
     OT* const obs = (OT*)a.obs;
     for (int t = 0; t < a.T; ++t) {
-        if (a.auto_reset && (e.s.flags & SNAC_FLAG_NEED_RESET)) {
-            episode += 1;
-            e.reset(a, pick_plan<E>(a, pk, episode), lane);
+        const size_t row = (size_t)t * (size_t)a.n + (size_t)env0;
+        int reward = 0;
+        bool done = false;
+        const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+        for (unsigned long long m = __ballot(nr); m; m &= m - 1) K::clear(lds, __ffsll(m) - 1, lane);
+        if (active) {
+            if (nr) {
+                episode += 1;
+                K::reset(a, s, pick_plan<K>(a, pk, episode));
+            }
+            const uint32_t w = rng_word(sk, a.t0 + (uint32_t)t);
+            const int act = a.actions ? (int)a.actions[row + lane] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
+            const int k = a.step_size ? (int)a.step_size[row + lane] : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+            K::step(lds, a, s, act, k, lane, reward, done);
+            s.ep_ret += reward;
+            s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+            if (a.reward) a.reward[row + lane] = (float)reward;
+            if (a.done) a.done[row + lane] = done ? 1 : 0;
         }
-        const uint32_t w = rng_word(sk, a.t0 + (uint32_t)t);
-        const size_t row = (size_t)t * (size_t)a.n + (size_t)env;
-        const int act = a.actions ? (int)a.actions[row] : (int)(((w >> 16) * (uint32_t)E::A) >> 16);
-        const int k = a.step_size ? (int)a.step_size[row] : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
-        int reward;
-        bool done;
-        e.step(act, k, lane, reward, done);
-        e.s.ep_ret += reward;
-        e.s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
-        if (done) {
-            d_eps += 1;
-            d_ret += e.s.ep_ret;
-            d_iou += __double2ll_rn(e.iou(lane) * FX40);
+        if (__any(done)) {
+            const double v = K::iou(lds, a, s, done, lane);
+            if (done) { d_eps += 1; d_ret += s.ep_ret; d_iou += __double2ll_rn(v * FX40); }
         }
         if (a.obs_mode == SNAC_OBS_ALL || (a.obs_mode == SNAC_OBS_LAST && t == a.T - 1)) {
-            const double v = e.obs_value(lane);
-            const size_t orow = a.obs_mode == SNAC_OBS_ALL ? row : (size_t)env;
-            if (lane < E::D) obs[orow * E::D + lane] = (OT)v;
-        }
-        if (lane == 0) {
-            if (a.reward) a.reward[row] = (float)reward;
-            if (a.done) a.done[row] = done ? 1 : 0;
+            stage_scalars<K>(lds, s, lane);
+            const size_t orow = a.obs_mode == SNAC_OBS_ALL ? row : (size_t)env0;
+            write_obs<K, OT>(lds, obs + orow * K::D, nenv, s.r | (s.c << 8), lane);
         }
     }
-    e.store(a, env, lane);
-    if (lane == 0) {
+    K::store_grid(lds, a, env0, nenv, lane);
+    if (active) {
+        a.hdr[env] = s.pack();
         a.episode[env] = episode;
         if (d_eps) {
             a.stat_episodes[env] += d_eps;
@@ -411,43 +471,48 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
     }
 }
 
-// reset(mask, plan_idx_in) + observation of every env
-template <class E, typename OT, int WPB>
-__global__ __launch_bounds__(WPB * 64) void k_reset(const KArgs a) {
+// reset(mask, plan_idx_in) / observe / iou on the same tile machinery
+template <class K, typename OT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
+    constexpr int E = K::E;
     const int lane = threadIdx.x & 63;
-    const int env = rfl((int)blockIdx.x * WPB + (int)(threadIdx.x >> 6));
-    if (env >= a.n) return;
-    E e;
-    e.bind(wave_lds<E, WPB>(), lane);
-    const bool doit = !a.observe_only && (a.mask ? a.mask[env] != 0 : true);
-    if (doit) {
-        const int episode = a.episode[env] + 1;
-        int pidx;
-        if (a.plan_idx_in) pidx = a.plan_idx_in[env];
-        else pidx = pick_plan<E>(a, env_keys(a.key_plan, (uint64_t)(a.env_id_base + env)), episode);
-        pidx = min(max(pidx, 0), a.num_plans - 1);
-        e.reset(a, pidx, lane);   // reads nothing from the old state
-        e.store(a, env, lane);
-        if (lane == 0) a.episode[env] = episode;
-    } else if (a.obs) {
-        e.load(a, env, lane);
+    const int tile = (int)blockIdx.x * WPB + (int)(threadIdx.x >> 6);
+    const int env0 = __builtin_amdgcn_readfirstlane(tile * E);
+    if (env0 >= a.n) return;
+    const int nenv = min(E, a.n - env0);
+    const bool active = lane < nenv;
+    const int env = env0 + (active ? lane : 0);
+    uint32_t* lds = wave_lds<K, WPB>();
+    Lane s;
+    s.clear();
+    if (active) s.unpack(a.hdr[env]);
+    K::load_grid(lds, a, env0, nenv, lane);
+    if (a.aux_op == AUX_RESET) {
+        const bool doit = active && (a.mask ? a.mask[env] != 0 : true);
+        for (unsigned long long m = __ballot(doit); m; m &= m - 1) K::clear(lds, __ffsll(m) - 1, lane);
+        if (doit) {
+            const int episode = a.episode[env] + 1;
+            int pidx;
+            if (a.plan_idx_in) pidx = a.plan_idx_in[env];
+            else pidx = pick_plan<K>(a, env_keys(a.key_plan, (uint64_t)(a.env_id_base + env)), episode);
+            pidx = min(max(pidx, 0), a.num_plans - 1);
+            K::reset(a, s, pidx);
+            a.hdr[env] = s.pack();
+            a.episode[env] = episode;
+        }
+        K::store_grid(lds, a, env0, nenv, lane);
+    }
+    if (a.aux_op == AUX_IOU) {
+        double v;
+        if constexpr (K::A == 8) v = K::iou_full(lds, a, s, active, lane);
+        else v = K::iou(lds, a, s, active, lane);
+        if (active) a.out_f64[env] = v;
+        return;
     }
     if (a.obs) {
-        const double v = e.obs_value(lane);
-        if (lane < E::D) ((OT*)a.obs)[(size_t)env * E::D + lane] = (OT)v;
+        stage_scalars<K>(lds, s, lane);
+        write_obs<K, OT>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s.r | (s.c << 8), lane);
     }
-}
-
-template <class E, int WPB>
-__global__ __launch_bounds__(WPB * 64) void k_iou(const KArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int env = rfl((int)blockIdx.x * WPB + (int)(threadIdx.x >> 6));
-    if (env >= a.n) return;
-    E e;
-    e.bind(wave_lds<E, WPB>(), lane);
-    e.load(a, env, lane);
-    const double v = e.iou(lane);
-    if (lane == 0) a.out_f64[env] = v;
 }
 
 // environment_memory with its -1 frame, float64 [N][H][W]; one thread per cell
@@ -456,8 +521,8 @@ __global__ void k_export(const KArgs a, long long total) {
     constexpr int H = KIND == 1 ? 1 : 26, Wd = KIND == 1 ? 34 : 26, HW = KIND == 1 ? 2 : 3;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long env = i / (H * Wd);
-        const int cell = (int)(i - env * (H * Wd));
-        const int r = cell / Wd, c = cell - r * Wd;
+        const int cellidx = (int)(i - env * (H * Wd));
+        const int r = cellidx / Wd, c = cellidx - r * Wd;
         int v = -1;
         if (KIND == 1) {
             if (c >= HW && c < Wd - HW) v = ((const int16_t*)a.grid)[env * 32 + (c - HW)];
@@ -490,35 +555,54 @@ KArgs make_args(const snac_env_desc* d, const snac_state* st) {
     a.n = d->num_envs; a.num_plans = d->num_plans; a.static_plan = d->static_plan;
     a.key_step = stream_key(d->seed, 0); a.key_plan = stream_key(d->seed, 1);
     a.env_id_base = d->env_id_base;
-    a.hdr = st->hdr; a.episode = st->episode; a.grid = st->grid; a.plans = st->plans; a.plan_tb = st->plan_tb;
+    a.hdr = (int4*)st->hdr; a.episode = st->episode; a.grid = st->grid; a.plans = st->plans; a.plan_tb = st->plan_tb;
     a.stat_episodes = st->stat_episodes; a.stat_return = st->stat_return; a.stat_iou_fx = st->stat_iou_fx;
     return a;
 }
 
-enum Op { OP_ROLLOUT, OP_RESET, OP_IOU };
+enum Op { OP_ROLLOUT, OP_AUX };
 
-template <class E, typename OT, int WPB>
-void launch_op(Op op, const KArgs& a, hipStream_t s) {
-    const dim3 grid((unsigned)((a.n + WPB - 1) / WPB)), block(WPB * 64);
-    if (op == OP_ROLLOUT) hipLaunchKernelGGL((k_rollout<E, OT, WPB>), grid, block, 0, s, a);
-    else if (op == OP_RESET) hipLaunchKernelGGL((k_reset<E, OT, WPB>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_iou<E, WPB>), grid, block, 0, s, a);
+template <class K, typename OT, int WPB>
+void launch_k(Op op, const KArgs& a, hipStream_t s) {
+    const int tiles = (a.n + K::E - 1) / K::E;
+    const dim3 grid((unsigned)((tiles + WPB - 1) / WPB)), block(WPB * 64);
+    if (op == OP_ROLLOUT) hipLaunchKernelGGL((k_rollout<K, OT, WPB>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_aux<K, OT, WPB>), grid, block, 0, s, a);
 }
 
-template <class E>
+template <template <bool, int> class KT, bool DYN, int E, int WPB>
 void launch_dt(Op op, int obs_dtype, const KArgs& a, hipStream_t s) {
-    constexpr int WPB = 4;
-    if (obs_dtype == SNAC_OBS_F32) launch_op<E, float, WPB>(op, a, s);
-    else launch_op<E, double, WPB>(op, a, s);
+    if (obs_dtype == SNAC_OBS_F32) launch_k<KT<DYN, E>, float, WPB>(op, a, s);
+    else launch_k<KT<DYN, E>, double, WPB>(op, a, s);
+}
+
+// tile size: enough tiles to give every SIMD of the 256 CUs a few waves; SNAC_TILE overrides (tuning)
+int pick_tile(int kind, int n) {
+    static const int forced = [] { const char* e = std::getenv("SNAC_TILE"); return e ? std::atoi(e) : 0; }();
+    if (kind == SNAC_ENV_3D) return 16;
+    if (forced == 16 || forced == 32 || forced == 64) return forced;
+    if (n >= 64 * 4096) return 64;
+    if (n >= 32 * 2048) return 32;
+    return 16;
+}
+
+template <template <bool, int> class KT, int WPB>
+void launch_tile(Op op, bool dyn, int E, int obs_dtype, const KArgs& a, hipStream_t s) {
+    if (E == 64) dyn ? launch_dt<KT, true, 64, WPB>(op, obs_dtype, a, s) : launch_dt<KT, false, 64, WPB>(op, obs_dtype, a, s);
+    else if (E == 32) dyn ? launch_dt<KT, true, 32, WPB>(op, obs_dtype, a, s) : launch_dt<KT, false, 32, WPB>(op, obs_dtype, a, s);
+    else dyn ? launch_dt<KT, true, 16, WPB>(op, obs_dtype, a, s) : launch_dt<KT, false, 16, WPB>(op, obs_dtype, a, s);
 }
 
 int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool dyn = d->dynamic != 0;
+    const int E = pick_tile(d->kind, d->num_envs);
     switch (d->kind) {
-        case SNAC_ENV_1D: dyn ? launch_dt<Env1D<true>>(op, d->obs_dtype, a, s) : launch_dt<Env1D<false>>(op, d->obs_dtype, a, s); break;
-        case SNAC_ENV_2D: dyn ? launch_dt<Env2D<true>>(op, d->obs_dtype, a, s) : launch_dt<Env2D<false>>(op, d->obs_dtype, a, s); break;
-        default:          dyn ? launch_dt<Env3D<true>>(op, d->obs_dtype, a, s) : launch_dt<Env3D<false>>(op, d->obs_dtype, a, s); break;
+        case SNAC_ENV_1D: launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
+        case SNAC_ENV_2D: launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
+        default:
+            dyn ? launch_dt<K3D, true, 16, 4>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 16, 4>(op, d->obs_dtype, a, s);
+            break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
@@ -553,8 +637,8 @@ int snac_reset(const snac_env_desc* d, const snac_state* st, const uint8_t* mask
                void* stream) {
     if (int rc = check_common(d, st)) return rc;
     KArgs a = make_args(d, st);
-    a.mask = mask; a.plan_idx_in = plan_idx_in; a.obs = obs;
-    return launch(OP_RESET, d, a, stream);
+    a.aux_op = AUX_RESET; a.mask = mask; a.plan_idx_in = plan_idx_in; a.obs = obs;
+    return launch(OP_AUX, d, a, stream);
 }
 
 int snac_rollout(const snac_env_desc* d, const snac_state* st, int32_t T, uint32_t t0, const int8_t* actions,
@@ -583,17 +667,16 @@ int snac_observe(const snac_env_desc* d, const snac_state* st, void* obs, void* 
     if (int rc = check_common(d, st)) return rc;
     if (!obs) return fail(SNAC_ERR_ARG, "null obs");
     KArgs a = make_args(d, st);
-    a.obs = obs;
-    a.observe_only = 1;   // k_reset with no env selected: load + observe
-    return launch(OP_RESET, d, a, stream);
+    a.aux_op = AUX_OBSERVE; a.obs = obs;
+    return launch(OP_AUX, d, a, stream);
 }
 
 int snac_iou(const snac_env_desc* d, const snac_state* st, double* out, void* stream) {
     if (int rc = check_common(d, st)) return rc;
     if (!out) return fail(SNAC_ERR_ARG, "null out");
     KArgs a = make_args(d, st);
-    a.out_f64 = out;
-    return launch(OP_IOU, d, a, stream);
+    a.aux_op = AUX_IOU; a.out_f64 = out;
+    return launch(OP_AUX, d, a, stream);
 }
 
 int snac_export_grid(const snac_env_desc* d, const snac_state* st, double* out, void* stream) {
