@@ -103,12 +103,15 @@ struct Lane {
 // ================================================================================================
 // 2D: Env/2D/DMP_Env_2D_static.py, Env/2D/DMP_Env_2D_dynamic_usedata_plan.py
 // LDS per wave: G[(row + 3) * RS + e], row in [-3, 22] (guard rows stay 0), RS = E + 1 (odd dword stride: the
-// 7 rows one env's window touches fall in 7 different banks); then SC[e][2] float64.
+// 7 rows one env's window touches fall in 7 different banks); P[row * RS + e] the env's plan rows (so the step
+// loop issues no global load: vmcnt is in-order, a load would drain every observation store before it);
+// then SC[e][2] float64.
 template <bool DYN_, int E_>
 struct K2D {
     static constexpr bool DYN = DYN_;
     static constexpr int E = E_, D = 51, W = 49, A = 5, TS = 600, GE = 20, RS = E + 1;
-    static constexpr int G_WORDS = 26 * RS + ((26 * RS) & 1);     // keep SC 8-byte aligned
+    static constexpr int P_OFF = 26 * RS;
+    static constexpr int G_WORDS = 46 * RS + ((46 * RS) & 1);     // grid + plan rows; keeps SC 8-byte aligned
     static constexpr int LDS_WORDS = G_WORDS + 4 * E;
 
     __device__ static double* sc(uint32_t* lds) { return (double*)(lds + G_WORDS); }
@@ -120,6 +123,9 @@ struct K2D {
             const int e = i / GE, row = i - e * GE;
             lds[(row + 3) * RS + e] = src[i];
         }
+    }
+    __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
+        if (lane < GE) lds[P_OFF + lane * RS + e] = ((const uint32_t*)a.plans)[pidx * GE + lane];
     }
     __device__ static void store_grid(const uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
         uint32_t* dst = (uint32_t*)a.grid + (size_t)env0 * GE;
@@ -141,7 +147,7 @@ struct K2D {
         const int row = s.r - 3;
         const uint32_t bit = 1u << (s.c - 3);
         const uint32_t gbits = lds[(row + 3) * RS + lane];
-        const uint32_t pbits = ((const uint32_t*)a.plans)[s.pidx * GE + row];
+        const uint32_t pbits = lds[P_OFF + row * RS + lane];
         const bool drop = act == 4;
         s.cs += 1;
         if (drop) {
@@ -162,31 +168,44 @@ struct K2D {
         int inter = 0, uni = 0;
         for (int row = 0; row < GE; ++row) {
             const uint32_t g = lds[(row + 3) * RS + lane];
-            const uint32_t p = want ? ((const uint32_t*)a.plans)[s.pidx * GE + row] : 0u;
+            const uint32_t p = lds[P_OFF + row * RS + lane];
             inter += __popc(g & p); uni += __popc(g | p);
         }
         return (double)inter / (double)uni;
     }
     // one window cell of env e: DMP_Env_2D_dynamic_usedata_plan.py:68-72
-    __device__ static int window(const uint32_t* lds, int e, int pr, int pc, int wi, int wj) {
+    // split in an address part and a value part so that the caller can batch the LDS reads of several envs
+    __device__ static int window_addr(int e, int pr, int pc, int wi, int wj, int& aux) {
         const int row = pr - 6 + wi, col = pc - 6 + wj;              // interior coordinates
-        const uint32_t bits = lds[(row + 3) * RS + e];
         const bool inside = (unsigned)row < 20u && (unsigned)col < 20u;
-        return inside ? (int)((bits >> (col & 31)) & 1u) : -1;
+        aux = inside ? (col & 31) : 32;                              // 32: frame cell
+        return (row + 3) * RS + e;                                   // guard rows keep every address valid
+    }
+    __device__ static int window_value(uint32_t word, int aux) {
+        const int m = -(aux >> 5);                                   // -1 for a frame cell, else 0
+        return (int)((word >> (aux & 31)) & 1u) | m;
     }
 };
 
 // ================================================================================================
 // 3D: Env/3D/DMP_simulator_3d_static_circle.py, Env/3D/DMP_simulator_3d_dynamic_triangle_usedata.py
-// LDS per wave: H[e * ES + cell] int16 heights of the 20x20 interior, ES = 402 (odd dword stride); then SC.
+// LDS per wave: H[e * ES + cell] int16 heights of the 20x20 interior, ES = 402 (odd dword stride); PL the
+// env's plan in the same layout (no global load inside the step loop); then SC.
 template <bool DYN_, int E_>
 struct K3D {
     static constexpr bool DYN = DYN_;
     static constexpr int E = E_, D = 51, W = 49, A = 8, TS = DYN_ ? 1000 : 1300, GE = 400, ES = 402;
-    static constexpr int G_WORDS = E * ES / 2 + ((E * ES / 2) & 1);
+    static constexpr int P_OFF = E * ES / 2;                         // dwords
+    static constexpr int G_WORDS = E * ES + ((E * ES) & 1);
     static constexpr int LDS_WORDS = G_WORDS + 4 * E;
 
     __device__ static double* sc(uint32_t* lds) { return (double*)(lds + G_WORDS); }
+    __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
+        const uint32_t* src = (const uint32_t*)((const int16_t*)a.plans + (size_t)pidx * GE);
+        uint32_t* dst = lds + P_OFF + e * (ES / 2);
+#pragma unroll
+        for (int d = lane; d < GE / 2; d += 64) dst[d] = src[d];
+    }
 
     __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
         const uint32_t* src = (const uint32_t*)((const int16_t*)a.grid + (size_t)env0 * GE);
@@ -204,7 +223,8 @@ struct K3D {
     }
     __device__ static int cell(const int16_t* h, int rr, int cc) {   // interior coordinates; frame = -1
         const bool inside = (unsigned)rr < 20u && (unsigned)cc < 20u;
-        return inside ? (int)h[rr * 20 + cc] : -1;
+        const int v = ((const volatile int16_t*)h)[inside ? rr * 20 + cc : 0];   // unconditional read, no branch
+        return v | (inside ? 0 : -1);
     }
     // reset: DMP_simulator_3d_dynamic_triangle_usedata.py:45-75
     __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
@@ -246,7 +266,7 @@ struct K3D {
             if (built) {
                 s.cb += 1;
                 h[tcell] = (int16_t)newh;
-                pl = ((const int16_t*)a.plans)[s.pidx * GE + tcell];
+                pl = ((const int16_t*)(lds + P_OFF))[lane * ES + tcell];
                 s.cross += newh <= pl ? 1 : 0;                       // running sum of min(height, plan) for iou()
             }
             bool fin = false;
@@ -272,27 +292,33 @@ struct K3D {
     // the same from the grid (snac_iou)
     __device__ static double iou_full(const uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
         const int16_t* h = (const int16_t*)lds + lane * ES;
+        const int16_t* pl = (const int16_t*)(lds + P_OFF) + lane * ES;
         int cross = 0;
-        for (int i = 0; i < GE; ++i) {
-            const int p = want ? (int)((const int16_t*)a.plans)[s.pidx * GE + i] : 0;
-            cross += min((int)h[i], p);
-        }
+        for (int i = 0; i < GE; ++i) cross += min((int)h[i], (int)pl[i]);
         return (double)cross / (double)(s.tb + s.cb - cross);
     }
-    __device__ static int window(const uint32_t* lds, int e, int pr, int pc, int wi, int wj) {
-        return cell((const int16_t*)lds + e * ES, pr - 6 + wi, pc - 6 + wj);
+    __device__ static int window_addr(int e, int pr, int pc, int wi, int wj, int& aux) {
+        const int rr = pr - 6 + wi, cc = pc - 6 + wj;
+        const bool inside = (unsigned)rr < 20u && (unsigned)cc < 20u;
+        aux = inside ? 0 : -1;
+        return e * ES + (inside ? rr * 20 + cc : 0);                 // int16 index
     }
+    __device__ static int window_value(int h, int aux) { return h | aux; }
 };
 
 // ================================================================================================
 // 1D: Env/1D/DMP_Env_1D_static.py, Env/1D/DMP_Env_1D_dynamic_usedata_plan.py
-// LDS per wave: H[e * ES + cell] int16, ES = 34 (odd dword stride); then SC; then POS[e].
+// LDS per wave: H[e * ES + cell] int16, ES = 34 (odd dword stride); PL plan, same layout; then SC; then POS[e].
 template <bool DYN_, int E_>
 struct K1D {
     static constexpr bool DYN = DYN_;
     static constexpr int E = E_, D = 7, W = 5, A = 3, TS = 750, GE = 32, ES = 34;
-    static constexpr int G_WORDS = E * ES / 2 + ((E * ES / 2) & 1);
+    static constexpr int P_OFF = E * ES / 2;                         // dwords
+    static constexpr int G_WORDS = E * ES + ((E * ES) & 1);
     static constexpr int LDS_WORDS = G_WORDS + 4 * E + E;
+    __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
+        if (lane < GE / 2) lds[P_OFF + e * (ES / 2) + lane] = ((const uint32_t*)((const int16_t*)a.plans + (size_t)pidx * GE))[lane];
+    }
 
     __device__ static double* sc(uint32_t* lds) { return (double*)(lds + G_WORDS); }
     __device__ static int* pos(uint32_t* lds) { return (int*)(lds + G_WORDS + 4 * E); }
@@ -324,7 +350,7 @@ struct K1D {
         int16_t* h = (int16_t*)lds + lane * ES;
         const int cellidx = s.r - 2;
         const int hnew = (int)h[cellidx] + 1;
-        const int pl = ((const int16_t*)a.plans)[s.pidx * GE + cellidx];
+        const int pl = ((const int16_t*)(lds + P_OFF))[lane * ES + cellidx];
         const bool drop = act == 2;
         s.cs += 1;
         if (drop) { s.cb += 1; h[cellidx] = (int16_t)hnew; }
@@ -337,10 +363,10 @@ struct K1D {
     // iou: DMP_Env_1D_static.py:138-151
     __device__ static double iou(const uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
         const int16_t* h = (const int16_t*)lds + lane * ES;
+        const int16_t* pl = (const int16_t*)(lds + P_OFF) + lane * ES;
         int a1 = 0, a2 = 0, kk = 0;
         for (int i = 0; i < 30; ++i) {
-            const int g = h[i];
-            const int p = want ? (int)((const int16_t*)a.plans)[s.pidx * GE + i] : 0;
+            const int g = h[i], p = pl[i];
             a1 += p; a2 += g; kk += max(g - p, 0);
         }
         const int cross = a2 - kk;
@@ -353,18 +379,32 @@ struct K1D {
 template <class K, typename OT>
 __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int pos_packed, int lane) {
     if constexpr (K::D == 51) {
+        constexpr int U = 8;                                         // envs per batch (K::E is a multiple of U)
         const int wl = lane < K::W ? lane : 0;
         const int wi = wl / 7, wj = wl - 7 * wi;
-        const double* scp = K::sc(lds);
+        const volatile double* scp = K::sc(lds);
         const int sidx = lane >= K::W ? min(lane - K::W, 1) : 0;
+        const bool is_win = lane < K::W;
         OT* p = orow + lane;
-#pragma unroll 4
-        for (int e = 0; e < nenv; ++e) {
-            const int pp = __builtin_amdgcn_readlane(pos_packed, e);
-            const int v = K::window(lds, e, pp & 0xff, pp >> 8, wi, wj);
-            const double s = scp[2 * e + sidx];
-            const double val = lane < K::W ? (double)v : s;
-            if (lane < K::D) p[e * K::D] = (OT)val;
+        for (int e0 = 0; e0 < nenv; e0 += U) {
+            int aux[U];
+            double sv[U];
+            int word[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u;                                // < K::E: LDS reads stay in range past nenv
+                const int pp = __builtin_amdgcn_readlane(pos_packed, e);
+                const int addr = K::window_addr(e, pp & 0xff, pp >> 8, wi, wj, aux[u]);
+                if constexpr (K::A == 8) word[u] = ((const volatile int16_t*)lds)[addr];
+                else word[u] = (int)((const volatile uint32_t*)lds)[addr];
+                sv[u] = scp[2 * e + sidx];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int v = K::window_value(word[u], aux[u]);
+                const double val = is_win ? (double)v : sv[u];
+                if (lane < K::D && e0 + u < nenv) p[(e0 + u) * K::D] = (OT)val;
+            }
         }
     } else {
         // 1D: 7 values per env -- flat, one element per lane: q = e * 7 + el
@@ -424,6 +464,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
     int episode = 0;
     if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
     K::load_grid(lds, a, env0, nenv, lane);
+    for (int e = 0; e < nenv; ++e) K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane);
     const uint64_t gid = (uint64_t)(a.env_id_base + env);
     const EnvKeys sk = env_keys(a.key_step, gid), pk = env_keys(a.key_plan, gid);
     int d_eps = 0, d_ret = 0;
@@ -434,12 +475,18 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
         int reward = 0;
         bool done = false;
         const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
-        for (unsigned long long m = __ballot(nr); m; m &= m - 1) K::clear(lds, __ffsll(m) - 1, lane);
-        if (active) {
+        if (__any(nr)) {
             if (nr) {
                 episode += 1;
                 K::reset(a, s, pick_plan<K>(a, pk, episode));
             }
+            for (unsigned long long m = __ballot(nr); m; m &= m - 1) {
+                const int e = __ffsll(m) - 1;
+                K::clear(lds, e, lane);
+                K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane);
+            }
+        }
+        if (active) {
             const uint32_t w = rng_word(sk, a.t0 + (uint32_t)t);
             const int act = a.actions ? (int)a.actions[row + lane] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
             const int k = a.step_size ? (int)a.step_size[row + lane] : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
@@ -487,6 +534,8 @@ __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
     s.clear();
     if (active) s.unpack(a.hdr[env]);
     K::load_grid(lds, a, env0, nenv, lane);
+    if (a.aux_op == AUX_IOU)
+        for (int e = 0; e < nenv; ++e) K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane);
     if (a.aux_op == AUX_RESET) {
         const bool doit = active && (a.mask ? a.mask[env] != 0 : true);
         for (unsigned long long m = __ballot(doit); m; m &= m - 1) K::clear(lds, __ffsll(m) - 1, lane);
@@ -601,7 +650,7 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
         case SNAC_ENV_1D: launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D: launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         default:
-            dyn ? launch_dt<K3D, true, 16, 4>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 16, 4>(op, d->obs_dtype, a, s);
+            dyn ? launch_dt<K3D, true, 16, 2>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 16, 2>(op, d->obs_dtype, a, s);
             break;
     }
     hipError_t e = hipGetLastError();
