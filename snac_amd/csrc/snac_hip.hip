@@ -223,7 +223,7 @@ struct K3D {
     }
     __device__ static int cell(const int16_t* h, int rr, int cc) {   // interior coordinates; frame = -1
         const bool inside = (unsigned)rr < 20u && (unsigned)cc < 20u;
-        const int v = ((const volatile int16_t*)h)[inside ? rr * 20 + cc : 0];   // unconditional read, no branch
+        const int v = h[inside ? rr * 20 + cc : 0];                  // unconditional read (address select only)
         return v | (inside ? 0 : -1);
     }
     // reset: DMP_simulator_3d_dynamic_triangle_usedata.py:45-75
@@ -382,7 +382,7 @@ __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int
         constexpr int U = 8;                                         // envs per batch (K::E is a multiple of U)
         const int wl = lane < K::W ? lane : 0;
         const int wi = wl / 7, wj = wl - 7 * wi;
-        const volatile double* scp = K::sc(lds);
+        const double* scp = K::sc(lds);
         const int sidx = lane >= K::W ? min(lane - K::W, 1) : 0;
         const bool is_win = lane < K::W;
         OT* p = orow + lane;
@@ -395,10 +395,14 @@ __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int
                 const int e = e0 + u;                                // < K::E: LDS reads stay in range past nenv
                 const int pp = __builtin_amdgcn_readlane(pos_packed, e);
                 const int addr = K::window_addr(e, pp & 0xff, pp >> 8, wi, wj, aux[u]);
-                if constexpr (K::A == 8) word[u] = ((const volatile int16_t*)lds)[addr];
-                else word[u] = (int)((const volatile uint32_t*)lds)[addr];
+                if constexpr (K::A == 8) word[u] = ((const int16_t*)lds)[addr];
+                else word[u] = (int)lds[addr];
                 sv[u] = scp[2 * e + sidx];
             }
+            // one fence for the whole batch: all 2U LDS reads are in flight before the first store is built
+            // (without it the compiler sinks each read into its store's exec-masked block and serialises them)
+            asm volatile("" ::"v"(word[0]), "v"(word[1]), "v"(word[2]), "v"(word[3]), "v"(word[4]), "v"(word[5]), "v"(word[6]),
+                         "v"(word[7]), "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]));
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int v = K::window_value(word[u], aux[u]);
