@@ -5,7 +5,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsnac_hip.so")
+LIB_PATH = os.environ.get("SNAC_HIP_LIB") or os.path.join(HERE, "libsnac_hip.so")  # override: A/B builds
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 

@@ -174,17 +174,6 @@ struct K2D {
         return (double)inter / (double)uni;
     }
     // one window cell of env e: DMP_Env_2D_dynamic_usedata_plan.py:68-72
-    // split in an address part and a value part so that the caller can batch the LDS reads of several envs
-    __device__ static int window_addr(int e, int pr, int pc, int wi, int wj, int& aux) {
-        const int row = pr - 6 + wi, col = pc - 6 + wj;              // interior coordinates
-        const bool inside = (unsigned)row < 20u && (unsigned)col < 20u;
-        aux = inside ? (col & 31) : 32;                              // 32: frame cell
-        return (row + 3) * RS + e;                                   // guard rows keep every address valid
-    }
-    __device__ static int window_value(uint32_t word, int aux) {
-        const int m = -(aux >> 5);                                   // -1 for a frame cell, else 0
-        return (int)((word >> (aux & 31)) & 1u) | m;
-    }
 };
 
 // ================================================================================================
@@ -297,13 +286,6 @@ struct K3D {
         for (int i = 0; i < GE; ++i) cross += min((int)h[i], (int)pl[i]);
         return (double)cross / (double)(s.tb + s.cb - cross);
     }
-    __device__ static int window_addr(int e, int pr, int pc, int wi, int wj, int& aux) {
-        const int rr = pr - 6 + wi, cc = pc - 6 + wj;
-        const bool inside = (unsigned)rr < 20u && (unsigned)cc < 20u;
-        aux = inside ? 0 : -1;
-        return e * ES + (inside ? rr * 20 + cc : 0);                 // int16 index
-    }
-    __device__ static int window_value(int h, int aux) { return h | aux; }
 };
 
 // ================================================================================================
@@ -376,28 +358,31 @@ struct K1D {
 
 // ------------------------------------------------------------------------------------------------
 // phase 2: write the observation rows of the tile's envs.  orow points at [env0][0] of the target step.
-template <class K, typename OT>
-__device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int pos_packed, int lane) {
+// r6 / c6: per-lane (position - 6) of the lane's env, i.e. the interior coordinate of its window's corner.
+// FULL: the tile holds K::E envs (no per-store bound test).
+template <class K, typename OT, bool FULL>
+__device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int r6, int c6, int lane) {
     if constexpr (K::D == 51) {
         constexpr int U = 8;                                         // envs per batch (K::E is a multiple of U)
         const int wl = lane < K::W ? lane : 0;
         const int wi = wl / 7, wj = wl - 7 * wi;
-        const double* scp = K::sc(lds);
-        const int sidx = lane >= K::W ? min(lane - K::W, 1) : 0;
+        const double* scp = K::sc(lds) + (lane >= K::W ? min(lane - K::W, 1) : 0);
         const bool is_win = lane < K::W;
         OT* p = orow + lane;
-        for (int e0 = 0; e0 < nenv; e0 += U) {
-            int aux[U];
+        for (int e0 = 0; e0 < (FULL ? K::E : nenv); e0 += U) {
+            bool inside[U];
+            int col[U];
             double sv[U];
             int word[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int e = e0 + u;                                // < K::E: LDS reads stay in range past nenv
-                const int pp = __builtin_amdgcn_readlane(pos_packed, e);
-                const int addr = K::window_addr(e, pp & 0xff, pp >> 8, wi, wj, aux[u]);
-                if constexpr (K::A == 8) word[u] = ((const int16_t*)lds)[addr];
-                else word[u] = (int)lds[addr];
-                sv[u] = scp[2 * e + sidx];
+                const int row = __builtin_amdgcn_readlane(r6, e) + wi;   // interior coordinates of this lane's cell
+                col[u] = __builtin_amdgcn_readlane(c6, e) + wj;
+                inside[u] = max((unsigned)row, (unsigned)col[u]) < 20u;
+                if constexpr (K::A == 8) word[u] = ((const int16_t*)lds)[e * K::ES + (inside[u] ? row * 20 + col[u] : 0)];
+                else word[u] = (int)lds[(row + 3) * K::RS + e];      // guard rows keep every address valid
+                sv[u] = scp[2 * e];
             }
             // one fence for the whole batch: all 2U LDS reads are in flight before the first store is built
             // (without it the compiler sinks each read into its store's exec-masked block and serialises them)
@@ -405,9 +390,12 @@ __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int
                          "v"(word[7]), "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]));
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int v = K::window_value(word[u], aux[u]);
+                int v;
+                if constexpr (K::A == 8) v = inside[u] ? word[u] : -1;
+                else v = inside[u] ? (int)(((unsigned)word[u] >> (col[u] & 31)) & 1u) : -1;
                 const double val = is_win ? (double)v : sv[u];
-                if (lane < K::D && e0 + u < nenv) p[(e0 + u) * K::D] = (OT)val;
+                // plain stores: nontemporal ones measured 22 % slower here (3.65 vs 2.99 ms per pass)
+                if (lane < K::D && (FULL || e0 + u < nenv)) p[(e0 + u) * K::D] = (OT)val;
             }
         }
     } else {
@@ -507,7 +495,8 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
         if (a.obs_mode == SNAC_OBS_ALL || (a.obs_mode == SNAC_OBS_LAST && t == a.T - 1)) {
             stage_scalars<K>(lds, s, lane);
             const size_t orow = a.obs_mode == SNAC_OBS_ALL ? row : (size_t)env0;
-            write_obs<K, OT>(lds, obs + orow * K::D, nenv, s.r | (s.c << 8), lane);
+            if (nenv == E) write_obs<K, OT, true>(lds, obs + orow * K::D, nenv, s.r - 6, s.c - 6, lane);
+            else write_obs<K, OT, false>(lds, obs + orow * K::D, nenv, s.r - 6, s.c - 6, lane);
         }
     }
     K::store_grid(lds, a, env0, nenv, lane);
@@ -564,7 +553,7 @@ __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
     }
     if (a.obs) {
         stage_scalars<K>(lds, s, lane);
-        write_obs<K, OT>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s.r | (s.c << 8), lane);
+        write_obs<K, OT, false>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s.r - 6, s.c - 6, lane);
     }
 }
 
@@ -634,8 +623,8 @@ int pick_tile(int kind, int n) {
     static const int forced = [] { const char* e = std::getenv("SNAC_TILE"); return e ? std::atoi(e) : 0; }();
     if (kind == SNAC_ENV_3D) return 16;
     if (forced == 16 || forced == 32 || forced == 64) return forced;
-    if (n >= 64 * 4096) return 64;
-    if (n >= 32 * 2048) return 32;
+    if (n >= 64 * 1024) return 64;   // >= one wave per SIMD on 256 CUs; measured best at N = 65536 (profiles/)
+    if (n >= 32 * 1024) return 32;
     return 16;
 }
 
