@@ -1,0 +1,12 @@
+"""Import shim: the reference's module name for Env/1D/DMP_Env_1D_static.py, backed by the HIP path.
+
+Scripts that do `sys.path.append('<...>/Env/1D/')` and `from DMP_Env_1D_static import deep_mobile_printing_1d1r` run unchanged when the path
+points here (snac_amd/Env/1D/) instead of the reference tree."""
+import os
+import sys
+
+_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if _root not in sys.path:
+    sys.path.insert(0, _root)
+
+from snac_amd.envs import deep_mobile_printing_1d1r_static as deep_mobile_printing_1d1r  # noqa: E402,F401

@@ -1,0 +1,449 @@
+"""Single-env facades with the reference's class surface, backed by the HIP path (N = 1).
+
+Same constructor arguments, method names, return shapes / dtypes and public attributes as
+  Env/1D/DMP_Env_1D_static.py, Env/1D/DMP_Env_1D_dynamic_usedata_plan.py,
+  Env/2D/DMP_Env_2D_static.py, Env/2D/DMP_Env_2D_dynamic_usedata_plan.py,
+  Env/3D/DMP_simulator_3d_static_circle.py, Env/3D/DMP_simulator_3d_dynamic_triangle_usedata.py
+so that the DQN / DRQN style scripts run unchanged (snac_amd/Env/<dim>/ holds import shims under the
+reference's module names).  Randomness is consumed exactly like the reference: every step() draws
+`np.random.randint(1, 4)` and every random-mode dynamic reset() draws `np.random.randint(0, len(dataset))`
+from numpy's global stream on the host, and hands the value to the kernel -- so a script that calls
+`np.random.seed(s)` sees the same trajectory as with the reference.  There is no CPU fallback.
+"""
+import os
+
+import numpy as np
+
+from . import plans as _plans
+
+try:  # the reference classes derive from gym.Env; keep that when gym is installed
+    import gym as _gym
+
+    _Base = _gym.Env
+except Exception:  # pragma: no cover - gym is optional
+    _Base = object
+
+_KNOWN = {
+    "data_1d_dynamic_sin_envplan_500_": (1, "sin"),
+    "data_2d_dynamic_dense_envplan_500_": (2, "dense"), "data_2d_dynamic_sparse_envplan_500_": (2, "sparse"),
+    "data_3d_dynamic_dense_envplan_500_": (3, "dense"), "data_3d_dynamic_sparse_envplan_500_": (3, "sparse"),
+}
+
+
+def _load_dataset(dim, data_path):
+    """joblib pickle as in the reference; when the file is absent but names one of the reference's 15 datasets,
+    the converted copy shipped in snac_amd/data/plans.npz is used."""
+    if os.path.exists(data_path):
+        return _plans.load_plan_file(data_path)
+    base = os.path.basename(data_path)
+    for prefix, (d, dens) in _KNOWN.items():
+        if base.startswith(prefix) and d == dim:
+            split = base[len(prefix):].split(".")[0]
+            return _plans.dataset(dim, dens, split)
+    raise FileNotFoundError(data_path)
+
+
+class _Facade(_Base):
+    _dim = 0
+    _dynamic = False
+
+    def _setup(self, plans_full):
+        from .batched import BatchedDMPEnv  # imports torch; raises without a ROCm GPU
+
+        self._env = BatchedDMPEnv(self._dim, self._dynamic, 1, plans=plans_full)
+        self._table = np.asarray(plans_full, np.float64)
+
+    # ---- shared plumbing ---------------------------------------------------------------------------
+    def _hdr(self):
+        h8 = self._env._hdr.cpu().numpy().view(np.int8).reshape(-1)
+        h16 = h8.view(np.int16)
+        return int(h8[0]), int(h8[1]), int(h16[2]), int(h16[3]), int(h16[4])
+
+    def _do_reset(self, plan_idx):
+        obs = self._env.reset(plan_idx=np.asarray([plan_idx], np.int16)).cpu().numpy()
+        self.plan = self._table[plan_idx]
+        r, c, cb, cs, tb = self._hdr()
+        self.total_brick = float(tb)
+        self.count_step = 0
+        self.observation = None
+        self._set_cb(0)
+        return obs, (r, c)
+
+    def _do_step(self, action):
+        import torch
+
+        self.step_size = int(np.random.randint(1, 4))          # drawn on EVERY step, like the reference
+        a = int(action)
+        bad = not (0 <= a < self.action_dim) and self._dim != 3
+        send = a if -128 <= a <= 127 else 127
+        obs, reward, done = self._env.step(torch.tensor([send], dtype=torch.int8), torch.tensor([self.step_size], dtype=torch.int8))
+        if bad:  # the reference leaves `position` unbound here, after count_step and the RNG have advanced
+            self.count_step += 1
+            raise UnboundLocalError("local variable 'position' referenced before assignment")
+        r, c, cb, cs, tb = self._hdr()
+        self.count_step = cs
+        self._set_cb(cb)
+        return obs.cpu().numpy(), float(reward.item()), bool(done.item()), (r, c)
+
+    def _set_cb(self, cb):
+        self.count_brick = cb
+
+    @property
+    def environment_memory(self):
+        return self._env.environment_memory()[0].cpu().numpy()
+
+    def _pick_plan(self):
+        """DMP_Env_2D_dynamic_usedata_plan.py:35-44: random index from the global stream, or sequential with wrap."""
+        if self.random_choose_paln:
+            self.index_random = int(np.random.randint(0, self.plan_dataset_len))
+            return self.index_random
+        idx = self.index_for_non_random
+        self.index_for_non_random += 1
+        if self.index_for_non_random == self.plan_dataset_len:
+            self.index_for_non_random = 0
+        return idx
+
+
+# ================================================================================================ 1D
+class _Env1D(_Facade):
+    _dim = 1
+
+    def _init_common(self):
+        # Env/1D/DMP_Env_1D_static.py:9-28
+        self.step_size = 1
+        self.plan_width = 30
+        self.plan_height = 20
+        self.environment_height = 100
+        self.conut_brick = None
+        self.brick_memory = None
+        self.HALF_WINDOW_SIZE = 2
+        self.environment_width = self.plan_width + 2 * self.HALF_WINDOW_SIZE
+        self.wall = np.ones((1, 2)) * (-1)
+        self.position_memory = None
+        self.observation = None
+        self.count_step = 0
+        self.total_step = 750
+        self.plan = None
+        self.total_brick = 0
+        self.one_hot = None
+        self.action_dim = 3
+        self.state_dim = self.HALF_WINDOW_SIZE * 2 + 1 + 2
+
+    def _set_cb(self, cb):
+        self.conut_brick = cb       # the reference's spelling (DMP_Env_1D_static.py:14)
+        self.count_brick = cb
+
+    def clip_position(self, position):
+        if position <= self.HALF_WINDOW_SIZE:
+            return self.HALF_WINDOW_SIZE
+        if position >= self.plan_width + self.HALF_WINDOW_SIZE - 1:
+            return self.plan_width + self.HALF_WINDOW_SIZE - 1
+        return position
+
+    def iou(self):
+        return float(self._env.iou().item())
+
+    def _after_step(self, action, pos):
+        self.position_memory.append(pos)
+        if action == 2:
+            self.brick_memory.append([pos, float(self.environment_memory[0, pos])])
+        else:
+            self.brick_memory.append([-1, -1])
+
+    def render(self, axe, iou_min=None, iou_average=None, iter_times=1, **kw):
+        axe.clear()
+        axe.set_xlabel('X-axis')
+        axe.set_xlim(-1, 30)
+        axe.set_ylabel('Y-axis')
+        axe.set_ylim(0, 50)
+        x = np.arange(self.plan_width)
+        iou = self.iou()
+        env = self.environment_memory[0][self.HALF_WINDOW_SIZE:self.plan_width + self.HALF_WINDOW_SIZE]
+        axe.title.set_text('step=%d, used_paint=%d, IOU=%.3f' % (self.count_step, self.conut_brick, iou))
+        axe.plot(x, np.asarray(self.plan), color='b')
+        axe.bar(x, env, color='r')
+        axe.scatter(self.position_memory[-1] - self.HALF_WINDOW_SIZE, 0, color='g')
+
+
+class deep_mobile_printing_1d1r_static(_Env1D):
+    """Env/1D/DMP_Env_1D_static.py :: deep_mobile_printing_1d1r(plan_choose=0)"""
+    _dynamic = False
+
+    def __init__(self, plan_choose=0):
+        self._init_common()
+        self.plan_choose = plan_choose
+        if plan_choose not in (0, 1, 2):
+            self._err = ValueError('0: Sin, 1: Gaussian, 2: Step')   # the reference raises in create_plan(), i.e. at reset()
+            return
+        self._err = None
+        self._setup(_plans.static_plan(1, plan_choose)[None])
+
+    def create_plan(self):
+        if self._err is not None:
+            raise self._err
+        self.one_hot = self.plan_choose
+        y = _plans.static_plan(1, self.plan_choose)
+        return y, sum(y)
+
+    def reset(self):
+        self.one_hot = None
+        self.create_plan()
+        self.one_hot = None
+        obs, (r, _) = self._do_reset(0)
+        self.total_brick = float(self.total_brick)
+        self.brick_memory = [[-1, -1]]
+        self.position_memory = [r]
+        return obs.reshape(1, 7)
+
+    def step(self, action):
+        obs, reward, done, (r, _) = self._do_step(action)
+        self._after_step(action, r)
+        return obs.reshape(1, 7), reward, done
+
+
+class deep_mobile_printing_1d1r_dynamic(_Env1D):
+    """Env/1D/DMP_Env_1D_dynamic_usedata_plan.py :: deep_mobile_printing_1d1r(data_path, random_choose_paln=True)"""
+    _dynamic = True
+
+    def __init__(self, data_path, random_choose_paln=True):
+        self._init_common()
+        self.plan_dataset = list(_load_dataset(1, data_path))
+        self.plan_dataset_len = len(self.plan_dataset)
+        self.random_choose_paln = random_choose_paln
+        self.index_for_non_random = 0
+        self._setup(np.asarray(self.plan_dataset))
+
+    def _lists(self, obs):
+        norm = obs.reshape(1, 7)
+        raw = norm.copy()
+        raw[0, 5] = self.conut_brick
+        raw[0, 6] = self.count_step
+        return raw, norm
+
+    def reset(self):
+        idx = self._pick_plan()
+        obs, (r, _) = self._do_reset(idx)
+        self.total_brick = float(self.total_brick)
+        self.plan_withborder = np.zeros((1, self.environment_width))
+        self.plan_withborder[:, :self.HALF_WINDOW_SIZE] = -1
+        self.plan_withborder[:, -self.HALF_WINDOW_SIZE:] = -1
+        self.plan_withborder[:, self.HALF_WINDOW_SIZE:self.HALF_WINDOW_SIZE + self.plan_width] = self.plan
+        self.brick_memory = [[-1, -1]]
+        self.position_memory = [r]
+        raw, norm = self._lists(obs)
+        return [raw, norm, self.plan, r]                         # 4 elements on reset, 3 on step (:66-70 vs :92-96)
+
+    def step(self, action):
+        obs, reward, done, (r, _) = self._do_step(action)
+        self._after_step(action, r)
+        raw, norm = self._lists(obs)
+        return [raw, norm, self.plan], reward, done
+
+
+# ================================================================================================ 2D / 3D
+class _EnvGrid(_Facade):
+    def _init_grid(self):
+        self.step_size = 1
+        self.plan_width = 20
+        self.plan_height = 20
+        self.count_brick = None
+        self.brick_memory = None
+        self.HALF_WINDOW_SIZE = 3
+        self.environment_width = self.plan_width + 2 * self.HALF_WINDOW_SIZE
+        self.environment_height = self.plan_height + 2 * self.HALF_WINDOW_SIZE
+        self.position_memory = None
+        self.observation = None
+        self.count_step = 0
+        self.plan = None
+        self.input_plan = None
+        self.total_brick = 0
+        self.one_hot = None
+        self.state_dim = (2 * self.HALF_WINDOW_SIZE + 1) ** 2 + 2
+
+    def observation_(self, position):
+        h = self.HALF_WINDOW_SIZE
+        g = self.environment_memory
+        return g[position[0] - h:position[0] + h + 1, position[1] - h:position[1] + h + 1].flatten().reshape(1, -1)
+
+    def clip_position(self, position):
+        lo, hi = self.HALF_WINDOW_SIZE, self.plan_width + self.HALF_WINDOW_SIZE - 1
+        position[0] = min(max(position[0], lo), hi)
+        position[1] = min(max(position[1], lo), hi)
+        return position
+
+    def _grid_reset(self, plan_idx):
+        obs, (r, c) = self._do_reset(plan_idx)
+        h = self.HALF_WINDOW_SIZE
+        self.input_plan = self.plan[h:h + self.plan_height, h:h + self.plan_width]
+        self.position_memory = [[r, c]]
+        return obs.reshape(1, 51), [r, c]
+
+    def _grid_step(self, action):
+        obs, reward, done, (r, c) = self._do_step(action)
+        self.position_memory.append([r, c])
+        return obs.reshape(1, 51), reward, done, self.position_memory[-1]
+
+    def iou(self):
+        """3D: the class method of the reference; 2D: the caller-side boolean IoU (script/DQN/2d/DQN_2d_dynamic.py:63-71)."""
+        return float(self._env.iou().item())
+
+    def render(self, axe, *args, **kw):
+        ax = axe
+        ax.clear()
+        h = self.HALF_WINDOW_SIZE
+        g = self.environment_memory[h:h + self.plan_height, h:h + self.plan_width]
+        p = self.plan[h:h + self.plan_height, h:h + self.plan_width]
+        ax.set_xlim(0, self.plan_width)
+        ax.set_ylim(0, self.plan_height)
+        ax.title.set_text('step=%d, used_paint=%d, IOU=%.3f' % (self.count_step, self.count_brick, self.iou()))
+        ax.imshow(np.where(g > 0, 2.0, 0.0) + np.where(p > 0, 1.0, 0.0), origin='lower', extent=(0, self.plan_width, 0, self.plan_height))
+        ax.scatter(self.position_memory[-1][1] - h + 0.5, self.position_memory[-1][0] - h + 0.5, color='r')
+
+
+class deep_mobile_printing_2d1r_static(_EnvGrid):
+    """Env/2D/DMP_Env_2D_static.py :: deep_mobile_printing_2d1r(plan_choose=0)"""
+    _dim, _dynamic = 2, False
+
+    def __init__(self, plan_choose=0):
+        self._init_grid()
+        self.total_step = 600
+        self.action_dim = 5
+        self.plan_choose = plan_choose
+        self._err = None
+        if plan_choose not in (0, 1):
+            self._err = ValueError('0: Dense circle, 1: Sparse circle')
+            return
+        self._setup(_plans.static_plan(2, plan_choose)[None])
+
+    def create_plan(self):
+        if self._err is not None:
+            raise self._err
+        plan = _plans.static_plan(2, self.plan_choose)
+        return plan, plan.sum()
+
+    def reset(self):
+        self.create_plan()
+        obs, _ = self._grid_reset(0)
+        self.total_brick = float(self.total_brick)
+        return obs
+
+    def step(self, action):
+        obs, reward, done, _ = self._grid_step(action)
+        return obs, reward, done
+
+
+class deep_mobile_printing_2d1r_dynamic(_EnvGrid):
+    """Env/2D/DMP_Env_2D_dynamic_usedata_plan.py :: deep_mobile_printing_2d1r(data_path, random_choose_paln=True)"""
+    _dim, _dynamic = 2, True
+
+    def __init__(self, data_path, random_choose_paln=True):
+        self._init_grid()
+        self.total_step = 600
+        self.action_dim = 5
+        self.plan_dataset = list(_load_dataset(2, data_path))
+        self.plan_dataset_len = len(self.plan_dataset)
+        self.random_choose_paln = random_choose_paln
+        self.index_for_non_random = 0
+        self._setup(np.asarray(self.plan_dataset))
+
+    def reset(self):
+        obs, pos = self._grid_reset(self._pick_plan())
+        self.total_brick = float(self.total_brick)
+        return [obs, self.input_plan, pos]
+
+    def step(self, action):
+        obs, reward, done, pos = self._grid_step(action)
+        return [obs, self.input_plan, pos], reward, done
+
+
+class _Env3D(_EnvGrid):
+    _dim = 3
+
+    def _init_3d(self):
+        self._init_grid()
+        self.plan_length = 10
+        self.z = 6
+        self.environment_length = self.plan_length + 2 * self.HALF_WINDOW_SIZE
+        self.start = None
+        self.check = []
+        self.action_dim = 8
+        self.blank_size = 2
+
+    def check_sur(self, position):
+        """Env/3D/DMP_simulator_3d_static_circle.py:88-102 on the current height map (host copy)."""
+        g = self.environment_memory
+        check = [0] * 8
+        nb = [g[position[0], position[1] - 1], g[position[0], position[1] + 1], g[position[0] + 1, position[1]],
+              g[position[0] - 1, position[1]]]
+        for i, v in enumerate(nb):
+            if v == -1:
+                check[i] = 1
+                check[i + 4] = 1
+            elif v > 0:
+                check[i] = 1
+        return check
+
+    def reward_check(self, position):
+        g = self.environment_memory
+        if g[position[0], position[1]] > self.plan[position[0], position[1]]:
+            return -1.0
+        if g[position[0], position[1]] == self.plan[position[0], position[1]]:
+            return 10.0
+        return 1.0
+
+
+class deep_mobile_printing_3d1r_static(_Env3D):
+    """Env/3D/DMP_simulator_3d_static_circle.py :: deep_mobile_printing_3d1r(plan_choose=1)"""
+    _dynamic = False
+
+    def __init__(self, plan_choose=1):
+        self._init_3d()
+        self.total_step = 1300
+        self.plan_choose = plan_choose
+        self._err = None
+        if plan_choose not in (0, 1):
+            self._err = ValueError('0: Dense circle, 1: Sparse circle')
+            return
+        self._setup(_plans.static_plan(3, plan_choose)[None])
+
+    def create_plan(self):
+        if self._err is not None:
+            raise self._err
+        plan = _plans.static_plan(3, self.plan_choose)
+        return plan, plan.sum()
+
+    def reset(self):
+        self.create_plan()
+        self.check = []
+        self.step_size = 1
+        obs, _ = self._grid_reset(0)
+        return obs
+
+    def step(self, action):
+        obs, reward, done, _ = self._grid_step(action)
+        return obs, reward, done
+
+
+class deep_mobile_printing_3d1r_dynamic(_Env3D):
+    """Env/3D/DMP_simulator_3d_dynamic_triangle_usedata.py :: deep_mobile_printing_3d1r(data_path, random_choose_paln=True)"""
+    _dynamic = True
+
+    def __init__(self, data_path, random_choose_paln=True):
+        self._init_3d()
+        self.total_step = 1000
+        self.plan_dataset = list(_load_dataset(3, data_path))
+        self.plan_dataset_len = len(self.plan_dataset)
+        self.random_choose_paln = random_choose_paln
+        self.index_for_non_random = 0
+        self._setup(np.asarray(self.plan_dataset))
+
+    def reset(self):
+        idx = self._pick_plan()
+        self.check = []
+        self.step_size = 1
+        obs, pos = self._grid_reset(idx)
+        return [obs, self.input_plan, pos]
+
+    def step(self, action):
+        obs, reward, done, pos = self._grid_step(action)
+        return [obs, self.input_plan, pos], reward, done

@@ -1,0 +1,75 @@
+"""VectorizedEnvWrapper: the batching loop of the reference (multiprocess.py:15-32) on the HIP path.
+
+The reference wrapper aliases ONE env object N times (multiprocess.py:19), so its "vector step" is N sequential
+steps of a single env; its dynamic modes also fail on numpy >= 1.24 (ragged np.asarray).  This wrapper implements
+the intended semantics -- N independent envs -- with the same call surface and return shapes:
+
+    reset()            -> observations  (N, 1, D) float64
+    reset_at(i)        -> observation of env i (1, D)
+    step(actions)      -> (observations (N, 1, D), rewards (N,), dones (N,))      no auto-reset, like the reference
+
+Host randomness is consumed as N sequential reference envs would consume it: one np.random.randint(1, 4) per env
+per step (drawn as one size-N array: numpy fills arrays in element order from the same stream) and one
+np.random.randint(0, len(dataset)) per env on a dynamic reset.  `wrapper.batched` is the underlying
+BatchedDMPEnv for callers that want device tensors, the counter RNG or fused rollouts.
+"""
+import numpy as np
+
+from .batched import BatchedDMPEnv
+
+
+class VectorizedEnvWrapper:
+    def __init__(self, env_, num_envs=1, device="cuda", obs_dtype=None):
+        """env_: one of the snac_amd.envs facades (its kind, plan set and plan mode are copied), or a
+        (kind, dynamic, plans) tuple."""
+        import torch
+
+        self.env = env_
+        self.num_envs = int(num_envs)
+        if isinstance(env_, tuple):
+            kind, dynamic, plans = env_
+            self._random = True
+        else:
+            kind, dynamic, plans = env_._dim, env_._dynamic, env_._table
+            self._random = getattr(env_, "random_choose_paln", True)
+        self._seq = 0
+        self.batched = BatchedDMPEnv(kind, dynamic, self.num_envs, plans=plans, device=device,
+                                     obs_dtype=obs_dtype or torch.float64)
+        self.envs = [self.batched] * self.num_envs        # len(wrapper.envs) and envs[0].total_step keep working
+        self.action_dim = self.batched.num_actions
+        self.total_step = self.batched.total_step
+
+    def _plan_indices(self, n):
+        b = self.batched
+        if not b.dynamic:
+            return np.zeros(n, np.int16)
+        if self._random:
+            return np.random.randint(0, b.num_plans, size=n).astype(np.int16)
+        idx = (self._seq + np.arange(n)) % b.num_plans
+        self._seq = int((self._seq + n) % b.num_plans)
+        return idx.astype(np.int16)
+
+    def reset(self):
+        obs = self.batched.reset(plan_idx=self._plan_indices(self.num_envs))
+        return obs.cpu().numpy().reshape(self.num_envs, 1, -1)
+
+    def reset_at(self, env_index):
+        mask = np.zeros(self.num_envs, np.uint8)
+        mask[env_index] = 1
+        pidx = np.zeros(self.num_envs, np.int16)
+        pidx[env_index] = self._plan_indices(1)[0]
+        obs = self.batched.reset(mask=mask, plan_idx=pidx)
+        return obs[env_index].cpu().numpy().reshape(1, -1)
+
+    def step(self, actions):
+        import torch
+
+        actions = np.asarray(actions)
+        if actions.shape != (self.num_envs,):
+            raise ValueError("actions must have shape (%d,)" % self.num_envs)
+        if actions.min() < 0 or actions.max() >= self.action_dim:
+            raise ValueError("action outside [0, %d)" % self.action_dim)
+        k = np.random.randint(1, 4, size=self.num_envs)
+        obs, rew, done = self.batched.step(torch.from_numpy(actions.astype(np.int8)), torch.from_numpy(k.astype(np.int8)))
+        return (obs.cpu().numpy().reshape(self.num_envs, 1, -1), rew.cpu().numpy().astype(np.float64),
+                done.cpu().numpy())

@@ -1,0 +1,145 @@
+"""GPU: BASELINE.json configurations at full size, bit-compared with the CPU oracle, plus edge cases (ragged tile
+tails, single env, masks, output modes)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _threads():
+    try:
+        return max(1, min(32, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return 4
+
+
+def _pair(dim, dyn, n, tag, seed=1, base=0, **kw):
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(dim, dyn, tag)
+    full = table.reshape(len(table), 30) if dim == 1 else table.reshape(len(table), 26, 26)
+    env = BatchedDMPEnv(dim, dyn, n, plans=full, seed=seed, env_id_base=base, **kw)
+    orc = helpers.oracle().OracleBatch(dim, dyn, n, table, seed=seed, env_id_base=base)
+    return env, orc
+
+
+def _compare_chunks(env, orc, T, chunk):
+    import torch
+
+    nt = _threads()
+    assert env.reset().cpu().numpy().tobytes() == orc.reset().tobytes()
+    buf = torch.empty((chunk, env.num_envs, env.obs_dim), dtype=torch.float64, device=env.device)
+    t = 0
+    while t < T:
+        c = min(chunk, T - t)
+        og, rg, dg = env.rollout(c, out=buf[:c])
+        oc, rc, dc = orc.rollout(c, t0=t, nthreads=nt)
+        assert og.cpu().numpy().tobytes() == oc.tobytes(), ("obs", t)
+        assert rg.cpu().numpy().tobytes() == rc.tobytes(), ("reward", t)
+        assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc), ("done", t)
+        t += c
+    s = orc.stats()
+    e = env.episodic_stats()
+    assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
+    assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+    return e
+
+
+def test_config2_1d_static_4096_envs_full_episode():
+    """BASELINE configs[1]: 1D static plan 0 (sin), N = 4096, all 750 steps."""
+    env, orc = _pair(1, False, 4096, "p0")
+    e = _compare_chunks(env, orc, 750, 250)
+    assert e["episodes"] == 4096                                  # every env hits the time limit exactly once
+
+
+def test_config3_2d_dynamic_dense_65536_envs_full_pass():
+    """BASELINE configs[2] (headline): 2D dynamic dense, N = 65536, T = 600 -- every observation, reward and done
+    flag of all 39 321 600 env-steps equals the oracle's."""
+    env, orc = _pair(2, True, 65536, "dense_train")
+    e = _compare_chunks(env, orc, 600, 40)
+    assert e["episodes"] > 65536
+
+
+def test_config5_3d_dynamic_dense_16384_envs_full_pass():
+    """BASELINE configs[4]: 3D dynamic dense, N = 16384, T = 1000."""
+    env, orc = _pair(3, True, 16384, "dense_train")
+    e = _compare_chunks(env, orc, 1000, 100)
+    assert e["episodes"] > 16384 * 20                             # random agents box themselves in every ~22 steps
+
+
+def test_config4_shard_of_524288_envs():
+    """BASELINE configs[3]: rank 5 of 8 x 65536 envs -- the shard's global ids key the counter RNG."""
+    env, orc = _pair(2, True, 65536, "dense_train", base=5 * 65536)
+    _compare_chunks(env, orc, 120, 40)
+
+
+@pytest.mark.parametrize("kind", [(1, False), (1, True), (2, False), (2, True), (3, False), (3, True)], ids=str)
+@pytest.mark.parametrize("n", [1, 17, 65, 130])
+def test_ragged_tile_tails(kind, n):
+    dim, dyn = kind
+    tag = ("sin_val" if dim == 1 else "sparse_val") if dyn else "p1"
+    env, orc = _pair(dim, dyn, n, tag, seed=4)
+    _compare_chunks(env, orc, 90, 45)
+
+
+def test_masked_reset_and_explicit_plan_indices():
+    import torch
+
+    n = 100
+    env, orc = _pair(2, True, n, "dense_train", seed=2)
+    env.reset()
+    orc.reset()
+    env.rollout(50, obs=None)
+    orc.rollout(50, obs=None)
+    rng = np.random.default_rng(0)
+    mask = (rng.random(n) < 0.4).astype(np.uint8)
+    pidx = rng.integers(0, 400, size=n).astype(np.int32)
+    og = env.reset(torch.from_numpy(mask), torch.from_numpy(pidx))
+    oc = orc.reset(mask, pidx)
+    assert og.cpu().numpy().tobytes() == oc.tobytes()             # untouched envs report their current observation
+    assert np.array_equal(env.plan_idx.cpu().numpy()[mask == 1], pidx[mask == 1])
+    assert np.array_equal(env.count_step.cpu().numpy()[mask == 0], np.full(int((mask == 0).sum()), 50))
+    og, rg, dg = env.rollout(30, obs="last")
+    oc, rc, dc = orc.rollout(30, t0=50, obs="last")
+    assert og.cpu().numpy().tobytes() == oc.tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes()
+    with pytest.raises(ValueError):
+        env.reset(plan_idx=np.full(n, 400))
+
+
+def test_step_without_auto_reset_keeps_mutating_like_the_reference():
+    """no auto-reset; stepping after done keeps counting."""
+    import torch
+
+    env, orc = _pair(2, False, 8, "p1", seed=1)
+    env.reset()
+    orc.reset()
+    a = torch.full((8,), 4, dtype=torch.int8)
+    k = torch.ones(8, dtype=torch.int8)
+    for t in range(70):                                           # total_brick = 60: done at step 60, then keep dropping
+        og, rg, dg = env.step(a, k)
+        oc, rc, dc = orc.step(t, a.numpy(), k.numpy())
+        assert og.cpu().numpy().tobytes() == oc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+    assert int(env.count_brick[0]) == 70 and bool(env.need_reset[0])
+
+
+def test_api_argument_checks():
+    from snac_amd import BatchedDMPEnv, SnacError
+
+    env = BatchedDMPEnv(2, True, 4)
+    with pytest.raises(SnacError):
+        env.step()
+    env.reset()
+    with pytest.raises(ValueError):
+        env.step(actions=np.zeros(5, np.int8))
+    with pytest.raises(ValueError):
+        env.rollout(3, actions=np.zeros((2, 4), np.int8))
+    import torch
+
+    with pytest.raises(ValueError):
+        env.rollout(3, out=torch.empty((3, 4, 51), dtype=torch.float32, device=env.device))
+    assert env.input_plan().shape == (4, 20, 20) and env.plan().shape == (4, 26, 26)
+    assert env.environment_memory().shape == (4, 26, 26)
