@@ -43,8 +43,10 @@ def cpu_baseline(kind, dynamic, n, T, seed):
     L = snac_oracle.lib()
     chunk = 10
     best = None
-    # all host threads the process may use, and a single thread (the scalar port); report the faster
-    for cores, budget in ((avail, 12.0), (1, 6.0)):
+    # a few thread counts up to what the process may use (a shared host rarely scales to all of them), and a
+    # single thread (the scalar port); report the fastest
+    counts = sorted({c for c in (1, 8, 32, 64, avail) if c <= avail})
+    for cores, budget in [(c, 5.0) for c in counts]:
         orc = snac_oracle.OracleBatch(kind, dynamic, n, table, seed=seed)
         orc.reset()
         obs = np.zeros((chunk, n, orc.obs_dim), np.float64)
@@ -142,6 +144,13 @@ def main():
         alg = ALG_BYTES.get((args.kind, dkey), ALG_BYTES[(2, "f64")])
         achieved = alg * n * T / (kern_ms * 1e-3) / 1e9
         s = stats.tolist()
+        # measured HBM bytes per launch (rocprofv3 PMC passes of this same command, tools/profile.sh ->
+        # profiles/traffic.json), turned into GB/s with the live launch duration; null for other workloads
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile) and (args.kind, dynamic, n, T, dkey) == (2, True, 65536, 600, "f64"):
+            with open(tfile) as fh:
+                traffic = json.load(fh)["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec at N=65536 envs (2D dynamic dense); bit-exact vs CPU",
             "value": total_steps / dt,
@@ -161,7 +170,7 @@ def main():
                        "envs_per_gpu": n, "vector_steps_per_pass": T, "env_steps_per_pass": n * T * world,
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_rollout", "kernel_ms": kern_ms, "alg_bytes_per_env_step": alg},
             "episodic": {"episodes": s[0], "mean_return": (s[1] / s[0]) if s[0] else None,
                          "mean_iou": (s[2] / 2.0 ** 40 / s[0]) if s[0] else None},
