@@ -90,10 +90,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RCCL ("nccl" on ROCm) in production; SNAC_BENCH_BACKEND=gloo lets the N > 1 path be exercised with several
+    # ranks sharing one GPU (tests): the three int64 sums then take a CPU round trip.
+    backend = os.environ.get("SNAC_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+
+    def allreduce_(t, op=None):
+        op = op or dist.ReduceOp.SUM
+        if world == 1:
+            return t
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+        return t
 
     n = args.envs
     dynamic = not args.static
@@ -106,9 +125,7 @@ def main():
 
     def one_pass():
         env.rollout(T, obs="all", out=obs)
-        s = env.stats_tensor()
-        if world > 1:
-            dist.all_reduce(s)  # RCCL over xGMI: episodic [episodes, return sum, IoU fixed-point sum]
+        s = allreduce_(env.stats_tensor())  # RCCL over xGMI: episodic [episodes, return sum, IoU fixed-point sum]
         stats.copy_(s)
 
     for _ in range(args.warmup):
@@ -126,16 +143,11 @@ def main():
         ev[i][0].record()
         env.rollout(T, obs="all", out=obs)
         ev[i][1].record()
-        s = env.stats_tensor()
-        if world > 1:
-            dist.all_reduce(s)
+        s = allreduce_(env.stats_tensor())
         stats.copy_(s)
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = float(allreduce_(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
 
     if rank == 0:

@@ -1,0 +1,69 @@
+"""GPU: the bench.py contract (one JSON line, required keys) and its N > 1 path: two ranks under
+torch.distributed.run, sharing the one GPU of the test box (collectives via gloo for that reason; production uses RCCL),
+must report the same global episodic sums as one process holding all the envs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline"}
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, cwd=helpers.ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_line_and_two_rank_path():
+    one = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--envs", "8192", "--T", "120"])
+    assert KEYS <= set(one) and "cpu_baseline" in one
+    assert one["n_gpus"] == 1 and one["unit"] == "env-steps/s" and one["dtype"] == "f64" and one["scaling"] == "weak"
+    assert one["vs_baseline"] is None and one["higher_is_better"] is True and "workload" in one["config"]
+    r = one["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["unit"] == "GB/s"
+    assert one["cpu_baseline"]["kind"] == "port" and one["cpu_baseline"]["cores"] >= 1
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--envs", "4096",
+                "--T", "120", "--no-cpu"], env={"SNAC_BENCH_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and two["config"]["env_steps_per_pass"] == 2 * 4096 * 120
+    # 2 ranks x 4096 envs (ids 0..8191) == 1 rank x 8192 envs: same global episodic sums after the same 3 passes
+    assert two["episodic"] == one["episodic"]
+
+
+def test_rccl_int64_all_reduce_single_rank():
+    """The collective the N > 1 path uses (int64 SUM + barrier) on the RCCL backend, world size 1."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        t = torch.tensor([3, -7, 1 << 45], dtype=torch.int64, device="cuda:0")
+        dist.all_reduce(t)
+        dist.barrier()
+        m = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        assert t.tolist() == [3, -7, 1 << 45] and m.item() == 1.5
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,68 @@
+"""Secondary timings on the GPU box (not the driver's bench line): every BASELINE config's env type as a fused
+rollout, the float32-observation variant, and the per-tick step() API.  Prints one line per measurement."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from snac_amd import BatchedDMPEnv  # noqa: E402
+
+ALG = {1: 88, 2: 481, 3: 574}
+
+
+def rollout_time(kind, dynamic, n, T, obs_dtype=torch.float64, reps=5, obs="all"):
+    env = BatchedDMPEnv(kind, dynamic, n, seed=1, obs_dtype=obs_dtype)
+    env.reset()
+    buf = torch.empty((T, n, env.obs_dim), dtype=obs_dtype, device=env.device) if obs == "all" else None
+    env.rollout(T, obs=obs, out=buf)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(reps):
+        a.record()
+        env.rollout(T, obs=obs, out=buf)
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b))
+    return best
+
+
+def step_time(kind, dynamic, n, ticks=200, explicit=False):
+    env = BatchedDMPEnv(kind, dynamic, n, seed=1)
+    env.reset()
+    acts = torch.randint(0, env.num_actions, (n,), dtype=torch.int8, device=env.device) if explicit else None
+    ks = torch.randint(1, 4, (n,), dtype=torch.int8, device=env.device) if explicit else None
+    for _ in range(10):
+        env.step(acts, ks, auto_reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(ticks):
+        env.step(acts, ks, auto_reset=True)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / ticks * 1e3
+
+
+def main():
+    rows = [("1D static p0   N=4096   T=750 ", 1, False, 4096, 750), ("1D static p0   N=65536  T=750 ", 1, False, 65536, 750),
+            ("2D dynamic     N=65536  T=600 ", 2, True, 65536, 600), ("2D static      N=65536  T=600 ", 2, False, 65536, 600),
+            ("2D dynamic     N=524288 T=75  ", 2, True, 524288, 75), ("3D dynamic     N=16384  T=1000", 3, True, 16384, 1000),
+            ("3D dynamic     N=65536  T=250 ", 3, True, 65536, 250), ("3D static      N=16384  T=1300", 3, False, 16384, 1300)]
+    for name, kind, dyn, n, T in rows:
+        ms = rollout_time(kind, dyn, n, T)
+        print("rollout f64 %s  %8.3f ms  %.3e env-steps/s  alg %.0f GB/s" % (name, ms, n * T / ms * 1e3, ALG[kind] * n * T / ms / 1e6))
+    ms = rollout_time(2, True, 65536, 600, obs_dtype=torch.float32)
+    print("rollout f32 2D dynamic     N=65536  T=600   %8.3f ms  %.3e env-steps/s  alg(277 B) %.0f GB/s" % (ms, 65536 * 600 / ms * 1e3, 277 * 65536 * 600 / ms / 1e6))
+    ms = rollout_time(2, True, 65536, 600, obs="last")
+    print("rollout obs=last 2D dynamic N=65536 T=600   %8.3f ms  %.3e env-steps/s (reward/done only)" % (ms, 65536 * 600 / ms * 1e3))
+    for n in (1, 4096, 65536, 524288):
+        for explicit in (False, True):
+            ms = step_time(2, True, n, explicit=explicit)
+            print("step() 2D dynamic N=%-7d %s  %8.4f ms/tick  %.3e env-steps/s" % (n, "explicit a,k" if explicit else "counter RNG ", ms, n / ms * 1e3))
+
+
+if __name__ == "__main__":
+    main()
