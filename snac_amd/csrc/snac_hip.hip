@@ -101,58 +101,89 @@ struct Lane {
 };
 
 // ================================================================================================
+// LDS images.  Every kind keeps the env's grid WITH its frame in LDS, so that neither the transition nor the
+// observation window needs a bounds test: a window cell is one LDS read at (uniform base + lane constant).
+// The HBM records stay compact (interior only); the frame is re-created when a tile is loaded.
+
+// bit j of x (j < 16) -> bit 2j
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {
+    x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+// bit 2j of x -> bit j
+__device__ __forceinline__ uint32_t squeeze16(uint32_t x) {
+    x &= 0x55555555u; x = (x | (x >> 1)) & 0x33333333u; x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu; x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+}
+
+// ================================================================================================
 // 2D: Env/2D/DMP_Env_2D_static.py, Env/2D/DMP_Env_2D_dynamic_usedata_plan.py
-// LDS per wave: G[(row + 3) * RS + e], row in [-3, 22] (guard rows stay 0), RS = E + 1 (odd dword stride: the
-// 7 rows one env's window touches fall in 7 different banks); P[row * RS + e] the env's plan rows (so the step
-// loop issues no global load: vmcnt is in-order, a load would drain every observation store before it);
-// then SC[e][2] float64.
+// LDS per wave: C[(row * RS + e)] 64-bit words, row = bordered row 0..25, RS = E + 1 (odd stride: the 7 rows of a
+// window fall in different banks).  Cell k (bordered column 0..25) is the 2-bit field at bit 2k: 00 empty, 01 brick,
+// 11 frame -- a signed 2-bit extract yields the reference's cell value 0 / 1 / -1 directly.  Then P[row * RS + e]:
+// the env's plan rows as 1-bit boards (the step loop must not issue global loads: vmcnt is in-order, a load would
+// wait for every observation store before it).
 template <bool DYN_, int E_>
 struct K2D {
     static constexpr bool DYN = DYN_;
     static constexpr int E = E_, D = 51, W = 49, A = 5, TS = 600, GE = 20, RS = E + 1;
-    static constexpr int P_OFF = 26 * RS;
-    static constexpr int G_WORDS = 46 * RS + ((46 * RS) & 1);     // grid + plan rows; keeps SC 8-byte aligned
-    static constexpr int LDS_WORDS = G_WORDS + 4 * E;
+    static constexpr int P_OFF = 52 * RS;                            // dwords
+    static constexpr int SC_OFF = 72 * RS + ((72 * RS) & 1);
+    static constexpr int LDS_WORDS = SC_OFF + 4 * E;
+    __device__ static double* sc(uint32_t* lds) { return (double*)(lds + SC_OFF); }
+    static constexpr uint32_t ROW_LO = 0x3Fu, ROW_HI = 0xFC000u;     // frame cells 0-2 and 23-25 of an interior row
 
-    __device__ static double* sc(uint32_t* lds) { return (double*)(lds + G_WORDS); }
-
+    __device__ static uint64_t* cells(uint32_t* lds) { return (uint64_t*)lds; }
+    __device__ static uint64_t encode_row(uint32_t bits) {           // 20 interior bits -> 26 two-bit cells
+        const uint32_t lo = ROW_LO | (spread16(bits & 0x1FFFu) << 6), hi = ROW_HI | spread16(bits >> 13);
+        return ((uint64_t)hi << 32) | lo;
+    }
+    __device__ static uint32_t decode_row(uint64_t w) {
+        const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+        return squeeze16((lo >> 6) & 0x01555555u) | (squeeze16(hi & 0x1555u) << 13);
+    }
     __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
-        for (int i = lane; i < 3 * RS; i += 64) { lds[i] = 0u; lds[23 * RS + i] = 0u; }
+        uint64_t* c = cells(lds);
+        for (int i = lane; i < 3 * RS; i += 64) { c[i] = 0x000FFFFFFFFFFFFFull; c[23 * RS + i] = 0x000FFFFFFFFFFFFFull; }
         const uint32_t* src = (const uint32_t*)a.grid + (size_t)env0 * GE;
         for (int i = lane; i < nenv * GE; i += 64) {
             const int e = i / GE, row = i - e * GE;
-            lds[(row + 3) * RS + e] = src[i];
+            c[(row + 3) * RS + e] = encode_row(src[i]);
+        }
+    }
+    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+        const uint64_t* c = cells(lds);
+        uint32_t* dst = (uint32_t*)a.grid + (size_t)env0 * GE;
+        for (int i = lane; i < nenv * GE; i += 64) {
+            const int e = i / GE, row = i - e * GE;
+            dst[i] = decode_row(c[(row + 3) * RS + e]);
         }
     }
     __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
         if (lane < GE) lds[P_OFF + lane * RS + e] = ((const uint32_t*)a.plans)[pidx * GE + lane];
-    }
-    __device__ static void store_grid(const uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
-        uint32_t* dst = (uint32_t*)a.grid + (size_t)env0 * GE;
-        for (int i = lane; i < nenv * GE; i += 64) {
-            const int e = i / GE, row = i - e * GE;
-            dst[i] = lds[(row + 3) * RS + e];
-        }
     }
     // reset: DMP_Env_2D_dynamic_usedata_plan.py:34-66 (the total_brick floor of 30 is folded into plan_tb)
     __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
         s.pidx = pidx; s.tb = a.plan_tb[pidx];
         s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
     }
-    __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave zeroes env e's grid
-        if (lane < GE) lds[(lane + 3) * RS + e] = 0u;
+    __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave empties env e's interior
+        if (lane < GE) cells(lds)[(lane + 3) * RS + e] = ((uint64_t)ROW_HI << 32) | ROW_LO;
     }
     // step: DMP_Env_2D_dynamic_usedata_plan.py:85-147
     __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int lane, int& reward, bool& done) {
-        const int row = s.r - 3;
-        const uint32_t bit = 1u << (s.c - 3);
-        const uint32_t gbits = lds[(row + 3) * RS + lane];
-        const uint32_t pbits = lds[P_OFF + row * RS + lane];
+        uint64_t* cw = cells(lds) + s.r * RS + lane;
+        const uint64_t w = *cw;
+        const int off = 2 * s.c;
+        const bool was = ((w >> off) & 1ull) != 0ull;
+        const bool planned = ((lds[P_OFF + (s.r - 3) * RS + lane] >> (s.c - 3)) & 1u) != 0u;
         const bool drop = act == 4;
         s.cs += 1;
         if (drop) {
             s.cb += 1;
-            lds[(row + 3) * RS + lane] = gbits | bit;               // += 1 then clamp to 1 (:115, :134-135)
+            *cw = w | (1ull << off);                                 // += 1 then clamp to 1 (:115, :134-135)
         }
         if (act == 0) s.c = max(s.c - k, 3);                         // clip_position :74-83
         if (act == 1) s.c = min(s.c + k, 22);
@@ -161,88 +192,90 @@ struct K2D {
         const bool term = drop && s.cb >= s.tb;                      // :117-126, tested before the time limit
         done = term || s.cs >= TS;
         // un-clamped cell vs plan (:129-133): 5 iff the cell was empty and is planned
-        reward = (drop && !term && (gbits & bit) == 0u && (pbits & bit) != 0u) ? 5 : 0;
+        reward = (drop && !term && !was && planned) ? 5 : 0;
     }
     // boolean IoU: script/DQN/2d/DQN_2d_dynamic.py:63-71
-    __device__ static double iou(const uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
+    __device__ static double iou(uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
         int inter = 0, uni = 0;
         for (int row = 0; row < GE; ++row) {
-            const uint32_t g = lds[(row + 3) * RS + lane];
+            const uint32_t g = decode_row(cells(lds)[(row + 3) * RS + lane]);
             const uint32_t p = lds[P_OFF + row * RS + lane];
             inter += __popc(g & p); uni += __popc(g | p);
         }
         return (double)inter / (double)uni;
     }
-    // one window cell of env e: DMP_Env_2D_dynamic_usedata_plan.py:68-72
+    // phase-2 keys of the lane's env: byte offset of the window's first row, bit offset of its first column
+    __device__ static int key0(const Lane& s) { return (s.r - 3) * RS * 8; }
+    __device__ static int key1(const Lane& s) { return 2 * (s.c - 3); }
 };
 
 // ================================================================================================
 // 3D: Env/3D/DMP_simulator_3d_static_circle.py, Env/3D/DMP_simulator_3d_dynamic_triangle_usedata.py
-// LDS per wave: H[e * ES + cell] int16 heights of the 20x20 interior, ES = 402 (odd dword stride); PL the
-// env's plan in the same layout (no global load inside the step loop); then SC.
+// LDS per wave: H[e * ES + r * 26 + c] int16, the bordered 26x26 height map (frame = -1), ES = 678 (odd dword
+// stride); PL[e * PS + cell] the env's plan (20x20 interior), PS = 402.
 template <bool DYN_, int E_>
 struct K3D {
     static constexpr bool DYN = DYN_;
-    static constexpr int E = E_, D = 51, W = 49, A = 8, TS = DYN_ ? 1000 : 1300, GE = 400, ES = 402;
+    static constexpr int E = E_, D = 51, W = 49, A = 8, TS = DYN_ ? 1000 : 1300, GE = 400, ES = 678, PS = 402;
     static constexpr int P_OFF = E * ES / 2;                         // dwords
-    static constexpr int G_WORDS = E * ES + ((E * ES) & 1);
-    static constexpr int LDS_WORDS = G_WORDS + 4 * E;
+    static constexpr int SC_OFF = E * (ES + PS) / 2 + ((E * (ES + PS) / 2) & 1);
+    static constexpr int LDS_WORDS = SC_OFF + 4 * E;
+    __device__ static double* sc(uint32_t* lds) { return (double*)(lds + SC_OFF); }
 
-    __device__ static double* sc(uint32_t* lds) { return (double*)(lds + G_WORDS); }
-    __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
-        const uint32_t* src = (const uint32_t*)((const int16_t*)a.plans + (size_t)pidx * GE);
-        uint32_t* dst = lds + P_OFF + e * (ES / 2);
-#pragma unroll
-        for (int d = lane; d < GE / 2; d += 64) dst[d] = src[d];
-    }
+    __device__ static int16_t* hmap(uint32_t* lds) { return (int16_t*)lds; }
+    __device__ static int16_t* plan(uint32_t* lds) { return (int16_t*)(lds + P_OFF); }
 
     __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
-        const uint32_t* src = (const uint32_t*)((const int16_t*)a.grid + (size_t)env0 * GE);
-        for (int i = lane; i < nenv * (GE / 2); i += 64) {
-            const int e = i / (GE / 2), d = i - e * (GE / 2);
-            lds[e * (ES / 2) + d] = src[i];
+        for (int i = lane; i < E * ES / 2; i += 64) lds[i] = 0xFFFFFFFFu;            // everything frame (-1) ...
+        const int16_t* src = (const int16_t*)a.grid + (size_t)env0 * GE;
+        int16_t* h = hmap(lds);
+        for (int i = lane; i < nenv * GE; i += 64) {                                  // ... then the interiors
+            const int e = i / GE, cell = i - e * GE, r = cell / 20, c = cell - r * 20;
+            h[e * ES + (r + 3) * 26 + c + 3] = src[i];
         }
     }
-    __device__ static void store_grid(const uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
-        uint32_t* dst = (uint32_t*)((int16_t*)a.grid + (size_t)env0 * GE);
-        for (int i = lane; i < nenv * (GE / 2); i += 64) {
-            const int e = i / (GE / 2), d = i - e * (GE / 2);
-            dst[i] = lds[e * (ES / 2) + d];
+    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+        int16_t* dst = (int16_t*)a.grid + (size_t)env0 * GE;
+        const int16_t* h = hmap(lds);
+        for (int i = lane; i < nenv * GE; i += 64) {
+            const int e = i / GE, cell = i - e * GE, r = cell / 20, c = cell - r * 20;
+            dst[i] = h[e * ES + (r + 3) * 26 + c + 3];
         }
     }
-    __device__ static int cell(const int16_t* h, int rr, int cc) {   // interior coordinates; frame = -1
-        const bool inside = (unsigned)rr < 20u && (unsigned)cc < 20u;
-        const int v = h[inside ? rr * 20 + cc : 0];                  // unconditional read (address select only)
-        return v | (inside ? 0 : -1);
+    __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
+        const uint32_t* src = (const uint32_t*)((const int16_t*)a.plans + (size_t)pidx * GE);
+        uint32_t* dst = lds + P_OFF + e * (PS / 2);
+#pragma unroll
+        for (int d = lane; d < GE / 2; d += 64) dst[d] = src[d];
     }
     // reset: DMP_simulator_3d_dynamic_triangle_usedata.py:45-75
     __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
         s.pidx = pidx; s.tb = a.plan_tb[pidx];
         s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
     }
-    __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave zeroes env e's grid
-        uint32_t* h = lds + e * (ES / 2);
+    __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave zeroes env e's interior
+        int16_t* h = hmap(lds) + e * ES;
 #pragma unroll
-        for (int d = lane; d < GE / 2; d += 64) h[d] = 0u;
+        for (int i = lane; i < GE; i += 64) { const int r = i / 20, c = i - r * 20; h[(r + 3) * 26 + c + 3] = 0; }
     }
     // step: DMP_simulator_3d_static_circle.py:153-230, DMP_simulator_3d_dynamic_triangle_usedata.py:142-231
     __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int lane, int& reward, bool& done) {
-        int16_t* h = (int16_t*)lds + lane * ES;
-        const int rr = s.r - 3, cc = s.c - 3;
+        int16_t* h = hmap(lds) + lane * ES + s.r * 26 + s.c;         // the agent's cell
         s.cs += 1;
         reward = 0;
         // check_sur (:88-102 / :77-91): left, right, "up" (row + 1), "down" (row - 1)
-        const int n0 = cell(h, rr, cc - 1), n1 = cell(h, rr, cc + 1), n2 = cell(h, rr + 1, cc), n3 = cell(h, rr - 1, cc);
+        const int n0 = h[-1], n1 = h[1], n2 = h[26], n3 = h[-26];
         const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
         done = (s.cs >= TS) || (!DYN && boxed_pre);                  // bottom of step(): static :226, dynamic :226
         const int d = act & 3;
         const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
+        const int dl = dr * 26 + dc;
         const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
+        const int c2 = h[2 * dl], c3 = h[3 * dl];                    // within the frame: |offset| <= 3 cells
         const bool valid = (unsigned)act < 8u;
         if (valid && act < 4) {
             if (nd == 0) {                                           // check[act] == 0
                 // move_step (:104-134): consecutive free cells, at most k; clip_position is then a no-op
-                const int c2 = cell(h, rr + 2 * dr, cc + 2 * dc), c3 = cell(h, rr + 3 * dr, cc + 3 * dc);
                 int m = 1;
                 if (k >= 2 && c2 == 0) { m = 2; if (k >= 3 && c3 == 0) m = 3; }
                 s.r += dr * m; s.c += dc * m;
@@ -250,12 +283,11 @@ struct K3D {
         } else if (valid) {
             const bool built = nd != -1;                             // check[act] == 0 for act in 4..7
             const int newh = nd + 1;
-            const int tcell = (rr + dr) * 20 + (cc + dc);
             int pl = 0;
             if (built) {
                 s.cb += 1;
-                h[tcell] = (int16_t)newh;
-                pl = ((const int16_t*)(lds + P_OFF))[lane * ES + tcell];
+                h[dl] = (int16_t)newh;
+                pl = plan(lds)[lane * PS + (s.r + dr - 3) * 20 + (s.c + dc - 3)];
                 s.cross += newh <= pl ? 1 : 0;                       // running sum of min(height, plan) for iou()
             }
             bool fin = false;
@@ -275,67 +307,74 @@ struct K3D {
         }
     }
     // iou (:257-276) = sum(min(g, plan)) / (tb + cb - sum); the sum is tracked incrementally in s.cross
-    __device__ static double iou(const uint32_t*, const KArgs&, const Lane& s, bool, int) {
+    __device__ static double iou(uint32_t*, const KArgs&, const Lane& s, bool, int) {
         return (double)s.cross / (double)(s.tb + s.cb - s.cross);
     }
     // the same from the grid (snac_iou)
-    __device__ static double iou_full(const uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
-        const int16_t* h = (const int16_t*)lds + lane * ES;
-        const int16_t* pl = (const int16_t*)(lds + P_OFF) + lane * ES;
+    __device__ static double iou_full(uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
+        const int16_t* h = hmap(lds) + lane * ES;
+        const int16_t* pl = plan(lds) + lane * PS;
         int cross = 0;
-        for (int i = 0; i < GE; ++i) cross += min((int)h[i], (int)pl[i]);
+        for (int i = 0; i < GE; ++i) { const int r = i / 20, c = i - r * 20; cross += min((int)h[(r + 3) * 26 + c + 3], (int)pl[i]); }
         return (double)cross / (double)(s.tb + s.cb - cross);
     }
+    __device__ static int key0(const Lane& s) { return ((s.r - 3) * 26 + (s.c - 3)) * 2; }   // byte offset of the window corner
+    __device__ static int key1(const Lane&) { return 0; }
 };
 
 // ================================================================================================
 // 1D: Env/1D/DMP_Env_1D_static.py, Env/1D/DMP_Env_1D_dynamic_usedata_plan.py
-// LDS per wave: H[e * ES + cell] int16, ES = 34 (odd dword stride); PL plan, same layout; then SC; then POS[e].
+// LDS per wave: H[e * ES + cell] int16, the bordered 34-cell row (frame = -1), ES = 34 (odd dword stride); PL the
+// plan (30 cells), same stride; SC[e][2] float64 observation scalars; POS[e].
 template <bool DYN_, int E_>
 struct K1D {
     static constexpr bool DYN = DYN_;
     static constexpr int E = E_, D = 7, W = 5, A = 3, TS = 750, GE = 32, ES = 34;
     static constexpr int P_OFF = E * ES / 2;                         // dwords
-    static constexpr int G_WORDS = E * ES + ((E * ES) & 1);
-    static constexpr int LDS_WORDS = G_WORDS + 4 * E + E;
-    __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
-        if (lane < GE / 2) lds[P_OFF + e * (ES / 2) + lane] = ((const uint32_t*)((const int16_t*)a.plans + (size_t)pidx * GE))[lane];
-    }
+    static constexpr int SC_OFF = E * ES + ((E * ES) & 1);
+    static constexpr int LDS_WORDS = SC_OFF + 4 * E + E;
 
-    __device__ static double* sc(uint32_t* lds) { return (double*)(lds + G_WORDS); }
-    __device__ static int* pos(uint32_t* lds) { return (int*)(lds + G_WORDS + 4 * E); }
+    __device__ static int16_t* hmap(uint32_t* lds) { return (int16_t*)lds; }
+    __device__ static int16_t* plan(uint32_t* lds) { return (int16_t*)(lds + P_OFF); }
+    __device__ static double* sc(uint32_t* lds) { return (double*)(lds + SC_OFF); }
+    __device__ static int* pos(uint32_t* lds) { return (int*)(lds + SC_OFF + 4 * E); }
 
     __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
-        const uint32_t* src = (const uint32_t*)((const int16_t*)a.grid + (size_t)env0 * GE);
-        for (int i = lane; i < nenv * (GE / 2); i += 64) {
-            const int e = i / (GE / 2), d = i - e * (GE / 2);
-            lds[e * (ES / 2) + d] = src[i];
+        for (int i = lane; i < E * ES / 2; i += 64) lds[i] = 0xFFFFFFFFu;
+        const int16_t* src = (const int16_t*)a.grid + (size_t)env0 * GE;
+        int16_t* h = hmap(lds);
+        for (int i = lane; i < nenv * GE; i += 64) {
+            const int e = i / GE, cell = i - e * GE;
+            if (cell < 30) h[e * ES + cell + 2] = src[i];
         }
     }
-    __device__ static void store_grid(const uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
-        uint32_t* dst = (uint32_t*)((int16_t*)a.grid + (size_t)env0 * GE);
-        for (int i = lane; i < nenv * (GE / 2); i += 64) {
-            const int e = i / (GE / 2), d = i - e * (GE / 2);
-            dst[i] = lds[e * (ES / 2) + d];
+    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+        int16_t* dst = (int16_t*)a.grid + (size_t)env0 * GE;
+        const int16_t* h = hmap(lds);
+        for (int i = lane; i < nenv * GE; i += 64) {
+            const int e = i / GE, cell = i - e * GE;
+            dst[i] = cell < 30 ? h[e * ES + cell + 2] : (int16_t)0;
         }
+    }
+    __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
+        if (lane < GE / 2) lds[P_OFF + e * (ES / 2) + lane] = ((const uint32_t*)((const int16_t*)a.plans + (size_t)pidx * GE))[lane];
     }
     // reset: DMP_Env_1D_static.py:66-83, DMP_Env_1D_dynamic_usedata_plan.py:40-70
     __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
         s.pidx = pidx; s.tb = a.plan_tb[pidx];
         s.r = 2; s.c = 0; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
     }
-    __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave zeroes env e's grid
-        if (lane < GE / 2) lds[e * (ES / 2) + lane] = 0u;
+    __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave zeroes env e's interior
+        if (lane < 30) hmap(lds)[e * ES + lane + 2] = 0;
     }
     // step: DMP_Env_1D_static.py:85-136
     __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int lane, int& reward, bool& done) {
-        int16_t* h = (int16_t*)lds + lane * ES;
-        const int cellidx = s.r - 2;
-        const int hnew = (int)h[cellidx] + 1;
-        const int pl = ((const int16_t*)(lds + P_OFF))[lane * ES + cellidx];
+        int16_t* h = hmap(lds) + lane * ES + s.r;
+        const int hnew = (int)*h + 1;
+        const int pl = plan(lds)[lane * ES + s.r - 2];
         const bool drop = act == 2;
         s.cs += 1;
-        if (drop) { s.cb += 1; h[cellidx] = (int16_t)hnew; }
+        if (drop) { s.cb += 1; *h = (int16_t)hnew; }
         if (act == 0) s.r = max(s.r - k, 2);                         // clip_position :57-64
         if (act == 1) s.r = min(s.r + k, 31);
         const bool term = drop && s.cb >= s.tb;                      // :107-114, before the time limit
@@ -343,9 +382,9 @@ struct K1D {
         reward = (drop && !term) ? (hnew > pl ? -1 : (hnew == pl ? 10 : 1)) : 0;   // :117-123
     }
     // iou: DMP_Env_1D_static.py:138-151
-    __device__ static double iou(const uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
-        const int16_t* h = (const int16_t*)lds + lane * ES;
-        const int16_t* pl = (const int16_t*)(lds + P_OFF) + lane * ES;
+    __device__ static double iou(uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
+        const int16_t* h = hmap(lds) + lane * ES + 2;
+        const int16_t* pl = plan(lds) + lane * ES;
         int a1 = 0, a2 = 0, kk = 0;
         for (int i = 0; i < 30; ++i) {
             const int g = h[i], p = pl[i];
@@ -354,74 +393,79 @@ struct K1D {
         const int cross = a2 - kk;
         return (double)cross / (double)(a1 + a2 - cross);
     }
+    __device__ static int key0(const Lane& s) { return s.r; }
+    __device__ static int key1(const Lane&) { return 0; }
 };
 
 // ------------------------------------------------------------------------------------------------
 // phase 2: write the observation rows of the tile's envs.  orow points at [env0][0] of the target step.
-// r6 / c6: per-lane (position - 6) of the lane's env, i.e. the interior coordinate of its window's corner.
-// FULL: the tile holds K::E envs (no per-store bound test).
+// k0 / k1: the per-lane phase-2 keys of the lane's env (K::key0 / key1).  FULL: the tile holds K::E envs.
+// 2D / 3D: lanes 0..48 produce the 7x7 window of one env, lanes 49 / 50 its two scalar slots (staged in LDS by
+// write_scalars), and the 51 values leave as ONE contiguous store.  (Writing the scalar slots with a separate
+// per-lane store was measured: the partial-line writes cost 55 % -- 4.5 vs 2.9 ms per pass.)
+// 1D: 7 values per env, flat, one element per lane.
 template <class K, typename OT, bool FULL>
-__device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int r6, int c6, int lane) {
+__device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int k0, int k1, int lane) {
     if constexpr (K::D == 51) {
         constexpr int U = 8;                                         // envs per batch (K::E is a multiple of U)
         const int wl = lane < K::W ? lane : 0;
         const int wi = wl / 7, wj = wl - 7 * wi;
+        const char* base = (const char*)lds;
         const double* scp = K::sc(lds) + (lane >= K::W ? min(lane - K::W, 1) : 0);
         const bool is_win = lane < K::W;
         OT* p = orow + lane;
+        int lane_off;                                                // byte offset of this lane's cell / cell row
+        if constexpr (K::A == 8) lane_off = (wi * 26 + wj) * 2;
+        else lane_off = wi * K::RS * 8;
         for (int e0 = 0; e0 < (FULL ? K::E : nenv); e0 += U) {
-            bool inside[U];
-            int col[U];
+            int v[U];
             double sv[U];
-            int word[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int e = e0 + u;                                // < K::E: LDS reads stay in range past nenv
-                const int row = __builtin_amdgcn_readlane(r6, e) + wi;   // interior coordinates of this lane's cell
-                col[u] = __builtin_amdgcn_readlane(c6, e) + wj;
-                inside[u] = max((unsigned)row, (unsigned)col[u]) < 20u;
-                if constexpr (K::A == 8) word[u] = ((const int16_t*)lds)[e * K::ES + (inside[u] ? row * 20 + col[u] : 0)];
-                else word[u] = (int)lds[(row + 3) * K::RS + e];      // guard rows keep every address valid
                 sv[u] = scp[2 * e];
+                const int s0 = __builtin_amdgcn_readlane(k0, e);
+                if constexpr (K::A == 8) {
+                    v[u] = *(const int16_t*)(base + (e * K::ES * 2 + s0) + lane_off);
+                } else {
+                    const int off = __builtin_amdgcn_readlane(k1, e) + 2 * wj;
+                    const uint64_t w = *(const uint64_t*)(base + (e * 8 + s0) + lane_off);
+                    v[u] = ((int)((uint32_t)(w >> off) << 30)) >> 30;    // signed 2-bit field: 0 / 1 / -1
+                }
             }
-            // one fence for the whole batch: all 2U LDS reads are in flight before the first store is built
-            // (without it the compiler sinks each read into its store's exec-masked block and serialises them)
-            asm volatile("" ::"v"(word[0]), "v"(word[1]), "v"(word[2]), "v"(word[3]), "v"(word[4]), "v"(word[5]), "v"(word[6]),
-                         "v"(word[7]), "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]));
+            // one fence per batch: every LDS read is in flight before the first store is built (otherwise the
+            // compiler sinks each scalar read into its store's exec-masked block and serialises them)
+            asm volatile("" ::"v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]));
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                int v;
-                if constexpr (K::A == 8) v = inside[u] ? word[u] : -1;
-                else v = inside[u] ? (int)(((unsigned)word[u] >> (col[u] & 31)) & 1u) : -1;
-                const double val = is_win ? (double)v : sv[u];
-                // plain stores: nontemporal ones measured 22 % slower here (3.65 vs 2.99 ms per pass)
+                const double val = is_win ? (double)v[u] : sv[u];
                 if (lane < K::D && (FULL || e0 + u < nenv)) p[(e0 + u) * K::D] = (OT)val;
             }
         }
     } else {
-        // 1D: 7 values per env -- flat, one element per lane: q = e * 7 + el
-        const int16_t* h = (const int16_t*)lds;
+        // 1D: q = e * 7 + el
+        const int16_t* h = K::hmap(lds);
         const double* scp = K::sc(lds);
         const int* posp = K::pos(lds);
         const int total = nenv * K::D;
         for (int q = lane; q < total; q += 64) {
             const int e = q / K::D, el = q - e * K::D;
-            const int cellidx = posp[e] - 4 + el;                    // interior index of window cell el
-            const bool inside = (unsigned)cellidx < 30u && el < K::W;
-            const int v = inside ? (int)h[e * K::ES + cellidx] : -1;
+            const int v = h[e * K::ES + posp[e] - 2 + min(el, K::W - 1)];
             const double s = scp[2 * e + (el >= K::W ? el - K::W : 0)];
             orow[q] = (OT)(el < K::W ? (double)v : s);
         }
     }
 }
 
-template <class K>
-__device__ __forceinline__ void stage_scalars(uint32_t* lds, const Lane& s, int lane) {
+// the two scalar observation slots (count_brick, count_step or their normalised forms): one IEEE float64 division per
+// lane (no fast-math), staged in LDS for phase 2.
+template <class K, typename OT>
+__device__ __forceinline__ void write_scalars(uint32_t* lds, OT* orow, const Lane& s, bool active, int lane) {
     const double num0 = (double)s.cb, num1 = (double)s.cs;
-    double2 v;
-    v.x = K::DYN ? num0 / (double)s.tb : num0;
-    v.y = K::DYN ? num1 / (double)K::TS : num1;
+    const double v0 = K::DYN ? num0 / (double)s.tb : num0;
+    const double v1 = K::DYN ? num1 / (double)K::TS : num1;
     if (lane < K::E) {
+        double2 v; v.x = v0; v.y = v1;
         *(double2*)(K::sc(lds) + 2 * lane) = v;
         if constexpr (K::D == 7) K::pos(lds)[lane] = s.r;
     }
@@ -439,6 +483,13 @@ __device__ __forceinline__ uint32_t* wave_lds() {
     return lds + (threadIdx.x >> 6) * K::LDS_WORDS;
 }
 
+template <class K, typename OT>
+__device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, const Lane& s, bool active, int lane) {
+    write_scalars<K, OT>(lds, orow, s, active, lane);
+    if (nenv == K::E) write_obs<K, OT, true>(lds, orow, nenv, K::key0(s), K::key1(s), lane);
+    else write_obs<K, OT, false>(lds, orow, nenv, K::key0(s), K::key1(s), lane);
+}
+
 // T fused vector steps (T = 1: one step() call) for one tile of E envs per wave.
 template <class K, typename OT, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
@@ -453,6 +504,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
     uint32_t* lds = wave_lds<K, WPB>();
     Lane s;
     s.clear();
+    s.r = 3; s.c = 3;                                                // idle lanes keep an in-range position
     int episode = 0;
     if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
     K::load_grid(lds, a, env0, nenv, lane);
@@ -493,10 +545,8 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
             if (done) { d_eps += 1; d_ret += s.ep_ret; d_iou += __double2ll_rn(v * FX40); }
         }
         if (a.obs_mode == SNAC_OBS_ALL || (a.obs_mode == SNAC_OBS_LAST && t == a.T - 1)) {
-            stage_scalars<K>(lds, s, lane);
             const size_t orow = a.obs_mode == SNAC_OBS_ALL ? row : (size_t)env0;
-            if (nenv == E) write_obs<K, OT, true>(lds, obs + orow * K::D, nenv, s.r - 6, s.c - 6, lane);
-            else write_obs<K, OT, false>(lds, obs + orow * K::D, nenv, s.r - 6, s.c - 6, lane);
+            emit_obs<K, OT>(lds, obs + orow * K::D, nenv, s, active, lane);
         }
     }
     K::store_grid(lds, a, env0, nenv, lane);
@@ -525,6 +575,7 @@ __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
     uint32_t* lds = wave_lds<K, WPB>();
     Lane s;
     s.clear();
+    s.r = 3; s.c = 3;
     if (active) s.unpack(a.hdr[env]);
     K::load_grid(lds, a, env0, nenv, lane);
     if (a.aux_op == AUX_IOU)
@@ -551,10 +602,7 @@ __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
         if (active) a.out_f64[env] = v;
         return;
     }
-    if (a.obs) {
-        stage_scalars<K>(lds, s, lane);
-        write_obs<K, OT, false>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s.r - 6, s.c - 6, lane);
-    }
+    if (a.obs) emit_obs<K, OT>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s, active, lane);
 }
 
 // environment_memory with its -1 frame, float64 [N][H][W]; one thread per cell
