@@ -149,6 +149,33 @@ int snac_step(const snac_env_desc* desc, const snac_state* st, uint32_t t, const
 int snac_rollout(const snac_env_desc* desc, const snac_state* st, int32_t T, uint32_t t0, const int8_t* actions,
                  const int8_t* step_size, int obs_mode, void* obs, float* reward, uint8_t* done, void* stream);
 
+/* snac_rollout that also records, per env-step, what a replay memory needs besides obs / reward / done (SURVEY.md
+ * section 8 row f1): the action taken and the step size used (useful when they come from the counter RNG), the plan
+ * row in effect, and whether the step was the first of its episode.  Every member is [T][N] or NULL. */
+typedef struct snac_rollout_record {
+    int8_t* actions;
+    int8_t* step_size;
+    int16_t* plan_idx;
+    uint8_t* first;
+} snac_rollout_record;
+int snac_rollout_rec(const snac_env_desc* desc, const snac_state* st, int32_t T, uint32_t t0, const int8_t* actions,
+                     const int8_t* step_size, int obs_mode, void* obs, float* reward, uint8_t* done,
+                     const snac_rollout_record* rec, void* stream);
+
+/* Minibatch assembly for the replay memory of the DQN / DRQN scripts (store_memory / learning_process,
+ * script/DQN/2d/DQN_2d_dynamic.py:122-124,145-166): the tuples (s, a, r, s', plan) are not stored, they are gathered from
+ * the rollout output ring  obs_ring[cap][N][obs_dim] (obs_dtype)  filled by snac_rollout(_rec) with SNAC_OBS_ALL:
+ *   s'   = obs_ring[tick][env]
+ *   s    = obs_ring[tick-1 mod cap][env], or the reset observation when first_ring[tick][env] != 0
+ *   plan = the env's input_plan (2D / 3D: 20x20, 1D: 30 heights) expanded from the plan table
+ * for `batch` samples (tick_idx[b], env_idx[b]); outputs are float32 as the scripts feed them to the networks:
+ * s_out / s_next_out [batch][obs_dim], plan_out [batch][400 | 30] or NULL.  a, r, done are plain gathers of the [cap][N]
+ * arrays and stay with the caller. */
+int snac_replay_gather(const snac_env_desc* desc, const snac_state* st, int32_t cap, const void* obs_ring,
+                       const uint8_t* first_ring, const int16_t* plan_idx_ring, const int32_t* tick_idx,
+                       const int32_t* env_idx, int32_t batch, float* s_out, float* s_next_out, float* plan_out,
+                       void* stream);
+
 /* current observation of every env without stepping: observation_() + the hstack of
  * Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:64-72 */
 int snac_observe(const snac_env_desc* desc, const snac_state* st, void* obs, void* stream);

@@ -6,7 +6,7 @@ implementation.  See DESIGN.md / INTEGRATION.md.
 from ._lib import SnacError, build  # noqa: F401
 from . import plans  # noqa: F401
 
-__all__ = ["BatchedDMPEnv", "VectorizedEnvWrapper", "SnacError", "build", "plans"]
+__all__ = ["BatchedDMPEnv", "VectorizedEnvWrapper", "ReplayRing", "SnacError", "build", "plans"]
 
 
 def __getattr__(name):  # torch is imported lazily so that `import snac_amd` stays cheap
@@ -14,6 +14,10 @@ def __getattr__(name):  # torch is imported lazily so that `import snac_amd` sta
         from .batched import BatchedDMPEnv
 
         return BatchedDMPEnv
+    if name == "ReplayRing":
+        from .replay import ReplayRing
+
+        return ReplayRing
     if name == "VectorizedEnvWrapper":
         from .vector import VectorizedEnvWrapper
 

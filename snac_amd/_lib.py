@@ -16,7 +16,7 @@ OBS_NONE, OBS_ALL, OBS_LAST = 0, 1, 2
 FLAG_NEED_RESET = 1
 
 EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_reset", "snac_step", "snac_rollout",
-           "snac_observe", "snac_iou", "snac_export_grid")
+           "snac_rollout_rec", "snac_replay_gather", "snac_observe", "snac_iou", "snac_export_grid")
 
 
 class Sizes(C.Structure):
@@ -28,6 +28,10 @@ class Sizes(C.Structure):
 class EnvDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dynamic", C.c_int32), ("num_envs", C.c_int32), ("num_plans", C.c_int32),
                 ("obs_dtype", C.c_int32), ("static_plan", C.c_int32), ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
+
+
+class RolloutRecord(C.Structure):
+    _fields_ = [("actions", C.c_void_p), ("step_size", C.c_void_p), ("plan_idx", C.c_void_p), ("first", C.c_void_p)]
 
 
 class State(C.Structure):
@@ -69,6 +73,9 @@ def lib():
         L.snac_reset.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp, vp, vp]
         L.snac_step.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_uint32, vp, vp, C.c_int, vp, vp, vp, vp]
         L.snac_rollout.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, C.c_uint32, vp, vp, C.c_int, vp, vp, vp, vp]
+        L.snac_rollout_rec.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, C.c_uint32, vp, vp, C.c_int, vp, vp, vp,
+                                       C.POINTER(RolloutRecord), vp]
+        L.snac_replay_gather.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp]
         L.snac_observe.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
         L.snac_iou.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
         L.snac_export_grid.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]

@@ -137,10 +137,19 @@ class BatchedDMPEnv:
         self.t += 1
         return obs, reward, done.view(torch.bool)
 
-    def rollout(self, T, actions=None, step_size=None, obs="all", out=None, want_reward=True, want_done=True):
+    def _buf(self, t, shape, dtype, what):
+        if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != self.device or not t.is_contiguous():
+            raise ValueError("%s must be a contiguous %s tensor of shape %s on %s" % (what, dtype, tuple(shape), self.device))
+        return t
+
+    def rollout(self, T, actions=None, step_size=None, obs="all", out=None, want_reward=True, want_done=True,
+                reward_out=None, done_out=None, record=None):
         """T vector steps with auto-reset in ONE launch (the loop of multiprocess.py:82-84).
         actions / step_size: int[T, N] or None (counter RNG).  obs: "all" -> [T, N, D], "last" -> [N, D], None.
-        out: optional preallocated obs tensor.  Returns (obs, reward [T, N] float32, done [T, N] bool)."""
+        out / reward_out / done_out: optional preallocated outputs (done_out uint8).  record: optional dict of
+        preallocated [T, N] tensors {"actions": int8, "step_size": int8, "plan_idx": int16, "first": uint8} that receive
+        the action taken, the step size used, the plan row in effect and the first-step-of-episode flag of every env-step.
+        Returns (obs, reward [T, N] float32, done [T, N] bool)."""
         if not self._was_reset:
             raise _lib.SnacError("rollout() before reset()")
         N, T = self.num_envs, int(T)
@@ -156,15 +165,58 @@ class BatchedDMPEnv:
                 o = out
             else:
                 o = torch.empty(shape, dtype=self.obs_dtype, device=self.device)
-        reward = torch.empty((T, N), dtype=torch.float32, device=self.device) if want_reward else None
-        done = torch.empty((T, N), dtype=torch.uint8, device=self.device) if want_done else None
+        if reward_out is not None:
+            reward = self._buf(reward_out, (T, N), torch.float32, "reward_out")
+        else:
+            reward = torch.empty((T, N), dtype=torch.float32, device=self.device) if want_reward else None
+        if done_out is not None:
+            done = self._buf(done_out, (T, N), torch.uint8, "done_out")
+        else:
+            done = torch.empty((T, N), dtype=torch.uint8, device=self.device) if want_done else None
+        rec = None
+        if record is not None:
+            kinds = {"actions": torch.int8, "step_size": torch.int8, "plan_idx": torch.int16, "first": torch.uint8}
+            ptrs = {}
+            for name, dt in kinds.items():
+                t = record.get(name)
+                ptrs[name] = None if t is None else self._buf(t, (T, N), dt, "record[%r]" % name).data_ptr()
+            rec = _lib.RolloutRecord(ptrs["actions"], ptrs["step_size"], ptrs["plan_idx"], ptrs["first"])
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.snac_rollout(C.byref(self._desc), C.byref(self._state), T, self.t & 0xFFFFFFFF, _ptr(a), _ptr(k),
-                                              mode, _ptr(o), _ptr(reward), _ptr(done), self._stream()))
+            _lib.check(self._lib.snac_rollout_rec(C.byref(self._desc), C.byref(self._state), T, self.t & 0xFFFFFFFF, _ptr(a),
+                                                  _ptr(k), mode, _ptr(o), _ptr(reward), _ptr(done),
+                                                  C.byref(rec) if rec is not None else None, self._stream()))
         self.t += T
         return o, reward, (done.view(torch.bool) if done is not None else None)
 
+    # ---- snapshots (MCTS-style branching, checkpoints) ---------------------------------------------
+    def state_dict(self):
+        """Everything that defines the envs' future (tensors are cloned): the MCTS variants of the reference snapshot
+        (position, grid, count_brick, count_step) per env (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175)."""
+        return dict(hdr=self._hdr.clone(), episode=self._episode.clone(), grid=self._grid.clone(), stats=self._stats.clone(),
+                    t=self.t, kind=self.kind, dynamic=self.dynamic, num_envs=self.num_envs)
+
+    def load_state_dict(self, sd):
+        if (sd["kind"], sd["dynamic"], sd["num_envs"]) != (self.kind, self.dynamic, self.num_envs):
+            raise ValueError("snapshot belongs to a different env batch")
+        self._hdr.copy_(sd["hdr"]); self._episode.copy_(sd["episode"]); self._grid.copy_(sd["grid"]); self._stats.copy_(sd["stats"])
+        self.t = int(sd["t"])
+        self._was_reset = True
+
+    def fork(self, index):
+        """New batch whose env j is a copy of this batch's env index[j] (same plans, seed, tick): expand tree leaves into
+        children and step each child with its own action -- the batched form of the MCTS variants' functional
+        transition(state, action).  Episodic sums start at zero; counter-RNG streams are keyed by the NEW local index."""
+        index = torch.as_tensor(index, device=self.device, dtype=torch.long)
+        child = BatchedDMPEnv(self.kind, self.dynamic, int(index.numel()), plans=self.plans_full, device=self.device, seed=self.seed,
+                              obs_dtype=self.obs_dtype, env_id_base=self.env_id_base)
+        child._hdr.copy_(self._hdr[index]); child._episode.copy_(self._episode[index]); child._grid.copy_(self._grid[index])
+        child.t = self.t
+        child._was_reset = self._was_reset
+        return child
+
     def observe(self):
+        if not self._was_reset:
+            raise _lib.SnacError("observe() before reset()")
         obs = self._new_obs()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.snac_observe(C.byref(self._desc), C.byref(self._state), _ptr(obs), self._stream()))

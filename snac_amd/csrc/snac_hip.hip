@@ -70,6 +70,11 @@ struct KArgs {
     void* obs;
     float* reward;
     uint8_t* done;
+    // optional per-step record (snac_rollout_rec): what a replay memory needs besides obs / reward / done
+    int8_t* actions_out;
+    int8_t* step_size_out;
+    int16_t* plan_idx_out;
+    uint8_t* first_out;
     // aux kernel only
     int32_t aux_op;            // AUX_*
     const uint8_t* mask;
@@ -173,7 +178,7 @@ struct K2D {
         if (lane < GE) cells(lds)[(lane + 3) * RS + e] = ((uint64_t)ROW_HI << 32) | ROW_LO;
     }
     // step: DMP_Env_2D_dynamic_usedata_plan.py:85-147
-    __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int lane, int& reward, bool& done) {
         uint64_t* cw = cells(lds) + s.r * RS + lane;
         const uint64_t w = *cw;
         const int off = 2 * s.c;
@@ -195,7 +200,7 @@ struct K2D {
         reward = (drop && !term && !was && planned) ? 5 : 0;
     }
     // boolean IoU: script/DQN/2d/DQN_2d_dynamic.py:63-71
-    __device__ static double iou(uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
+    __device__ static double iou(uint32_t* lds, const Lane& s, int lane) {
         int inter = 0, uni = 0;
         for (int row = 0; row < GE; ++row) {
             const uint32_t g = decode_row(cells(lds)[(row + 3) * RS + lane]);
@@ -259,7 +264,7 @@ struct K3D {
         for (int i = lane; i < GE; i += 64) { const int r = i / 20, c = i - r * 20; h[(r + 3) * 26 + c + 3] = 0; }
     }
     // step: DMP_simulator_3d_static_circle.py:153-230, DMP_simulator_3d_dynamic_triangle_usedata.py:142-231
-    __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r * 26 + s.c;         // the agent's cell
         s.cs += 1;
         reward = 0;
@@ -307,11 +312,11 @@ struct K3D {
         }
     }
     // iou (:257-276) = sum(min(g, plan)) / (tb + cb - sum); the sum is tracked incrementally in s.cross
-    __device__ static double iou(uint32_t*, const KArgs&, const Lane& s, bool, int) {
+    __device__ static double iou(uint32_t*, const Lane& s, int) {
         return (double)s.cross / (double)(s.tb + s.cb - s.cross);
     }
     // the same from the grid (snac_iou)
-    __device__ static double iou_full(uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
+    __device__ static double iou_full(uint32_t* lds, const Lane& s, int lane) {
         const int16_t* h = hmap(lds) + lane * ES;
         const int16_t* pl = plan(lds) + lane * PS;
         int cross = 0;
@@ -368,7 +373,7 @@ struct K1D {
         if (lane < 30) hmap(lds)[e * ES + lane + 2] = 0;
     }
     // step: DMP_Env_1D_static.py:85-136
-    __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r;
         const int hnew = (int)*h + 1;
         const int pl = plan(lds)[lane * ES + s.r - 2];
@@ -382,7 +387,7 @@ struct K1D {
         reward = (drop && !term) ? (hnew > pl ? -1 : (hnew == pl ? 10 : 1)) : 0;   // :117-123
     }
     // iou: DMP_Env_1D_static.py:138-151
-    __device__ static double iou(uint32_t* lds, const KArgs& a, const Lane& s, bool want, int lane) {
+    __device__ static double iou(uint32_t* lds, const Lane& s, int lane) {
         const int16_t* h = hmap(lds) + lane * ES + 2;
         const int16_t* pl = plan(lds) + lane * ES;
         int a1 = 0, a2 = 0, kk = 0;
@@ -534,14 +539,18 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
             const uint32_t w = rng_word(sk, a.t0 + (uint32_t)t);
             const int act = a.actions ? (int)a.actions[row + lane] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
             const int k = a.step_size ? (int)a.step_size[row + lane] : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
-            K::step(lds, a, s, act, k, lane, reward, done);
+            K::step(lds, s, act, k, lane, reward, done);
             s.ep_ret += reward;
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
             if (a.reward) a.reward[row + lane] = (float)reward;
             if (a.done) a.done[row + lane] = done ? 1 : 0;
+            if (a.actions_out) a.actions_out[row + lane] = (int8_t)act;
+            if (a.step_size_out) a.step_size_out[row + lane] = (int8_t)k;
+            if (a.plan_idx_out) a.plan_idx_out[row + lane] = (int16_t)s.pidx;
+            if (a.first_out) a.first_out[row + lane] = s.cs == 1 ? 1 : 0;   // first step of its episode
         }
         if (__any(done)) {
-            const double v = K::iou(lds, a, s, done, lane);
+            const double v = K::iou(lds, s, lane);
             if (done) { d_eps += 1; d_ret += s.ep_ret; d_iou += __double2ll_rn(v * FX40); }
         }
         if (a.obs_mode == SNAC_OBS_ALL || (a.obs_mode == SNAC_OBS_LAST && t == a.T - 1)) {
@@ -597,8 +606,8 @@ __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
     }
     if (a.aux_op == AUX_IOU) {
         double v;
-        if constexpr (K::A == 8) v = K::iou_full(lds, a, s, active, lane);
-        else v = K::iou(lds, a, s, active, lane);
+        if constexpr (K::A == 8) v = K::iou_full(lds, s, lane);
+        else v = K::iou(lds, s, lane);
         if (active) a.out_f64[env] = v;
         return;
     }
@@ -621,6 +630,58 @@ __global__ void k_export(const KArgs a, long long total) {
             else v = ((const int16_t*)a.grid)[env * 400 + (r - HW) * 20 + (c - HW)];
         }
         a.out_f64[i] = (double)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// replay sampling (the step after the env path: script/DQN/2d/DQN_2d_dynamic.py:122-124,145-166 keeps
+// (s, a, r, s', plan) tuples in a python deque and re-assembles float32 minibatches on the host).  The rollout output
+// ring obs[cap][N][D] already holds every s' -- and s is the previous tick's row, or the constant reset observation when
+// the step opened an episode -- so sampling is a gather: one wave per sample, float32 out, plan expanded from the table.
+struct GArgs {
+    int32_t n, cap, batch, num_plans;
+    const void* obs;
+    const uint8_t* first;
+    const int16_t* plan_idx;
+    const int32_t* tick;
+    const int32_t* env;
+    const void* plans;
+    float* s;
+    float* s_next;
+    float* plan_out;
+};
+
+template <int KIND, typename OT>
+__global__ __launch_bounds__(256) void k_gather(const GArgs g) {
+    constexpr int D = KIND == 1 ? 7 : 51, W = KIND == 1 ? 5 : 49, PC = KIND == 1 ? 30 : 400;
+    const int lane = threadIdx.x & 63;
+    const int b = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (b >= g.batch) return;
+    const int t = min(max(g.tick[b], 0), g.cap - 1), i = min(max(g.env[b], 0), g.n - 1);
+    const size_t cur = (size_t)t * g.n + i, prev = (size_t)(t == 0 ? g.cap - 1 : t - 1) * g.n + i;
+    const bool first = g.first[cur] != 0;
+    const OT* o = (const OT*)g.obs;
+    if (lane < D) {
+        g.s_next[(size_t)b * D + lane] = (float)o[cur * D + lane];
+        float sv;
+        if (first) {   // reset observation: window at the start position over an empty grid, both scalar slots 0
+            const int wi = lane / 7, wj = lane - 7 * wi;
+            const bool frame = KIND == 1 ? lane < 2 : (wi < 3 || wj < 3);
+            sv = (lane < W && frame) ? -1.0f : 0.0f;
+        } else {
+            sv = (float)o[prev * D + lane];
+        }
+        g.s[(size_t)b * D + lane] = sv;
+    }
+    if (g.plan_out) {
+        const int p = min(max((int)g.plan_idx[cur], 0), g.num_plans - 1);
+        for (int c = lane; c < PC; c += 64) {
+            int v;
+            if (KIND == 2) { const int row = c / 20, col = c - row * 20; v = (((const uint32_t*)g.plans)[p * 20 + row] >> col) & 1u; }
+            else if (KIND == 3) v = ((const int16_t*)g.plans)[p * 400 + c];
+            else v = ((const int16_t*)g.plans)[p * 32 + c];
+            g.plan_out[(size_t)b * PC + c] = (float)v;
+        }
     }
 }
 
@@ -731,8 +792,9 @@ int snac_reset(const snac_env_desc* d, const snac_state* st, const uint8_t* mask
     return launch(OP_AUX, d, a, stream);
 }
 
-int snac_rollout(const snac_env_desc* d, const snac_state* st, int32_t T, uint32_t t0, const int8_t* actions,
-                 const int8_t* step_size, int obs_mode, void* obs, float* reward, uint8_t* done, void* stream) {
+int snac_rollout_rec(const snac_env_desc* d, const snac_state* st, int32_t T, uint32_t t0, const int8_t* actions,
+                     const int8_t* step_size, int obs_mode, void* obs, float* reward, uint8_t* done,
+                     const snac_rollout_record* rec, void* stream) {
     if (int rc = check_common(d, st)) return rc;
     if (T < 0) return fail(SNAC_ERR_ARG, "T must be >= 0");
     if (obs_mode < SNAC_OBS_NONE || obs_mode > SNAC_OBS_LAST) return fail(SNAC_ERR_ARG, "unknown obs_mode");
@@ -741,7 +803,41 @@ int snac_rollout(const snac_env_desc* d, const snac_state* st, int32_t T, uint32
     KArgs a = make_args(d, st);
     a.T = T; a.t0 = t0; a.auto_reset = 1; a.obs_mode = obs_mode;
     a.actions = actions; a.step_size = step_size; a.obs = obs; a.reward = reward; a.done = done;
+    if (rec) {
+        a.actions_out = rec->actions; a.step_size_out = rec->step_size; a.plan_idx_out = rec->plan_idx; a.first_out = rec->first;
+    }
     return launch(OP_ROLLOUT, d, a, stream);
+}
+
+int snac_rollout(const snac_env_desc* d, const snac_state* st, int32_t T, uint32_t t0, const int8_t* actions,
+                 const int8_t* step_size, int obs_mode, void* obs, float* reward, uint8_t* done, void* stream) {
+    return snac_rollout_rec(d, st, T, t0, actions, step_size, obs_mode, obs, reward, done, nullptr, stream);
+}
+
+int snac_replay_gather(const snac_env_desc* d, const snac_state* st, int32_t cap, const void* obs_ring,
+                       const uint8_t* first_ring, const int16_t* plan_idx_ring, const int32_t* tick_idx,
+                       const int32_t* env_idx, int32_t batch, float* s_out, float* s_next_out, float* plan_out,
+                       void* stream) {
+    if (int rc = check_common(d, st)) return rc;
+    if (cap < 2 || batch < 0) return fail(SNAC_ERR_ARG, "cap must be >= 2 and batch >= 0");
+    if (!obs_ring || !first_ring || !tick_idx || !env_idx || !s_out || !s_next_out) return fail(SNAC_ERR_ARG, "null pointer");
+    if (plan_out && !plan_idx_ring) return fail(SNAC_ERR_ARG, "plan_out needs plan_idx_ring");
+    if (batch == 0) return SNAC_OK;
+    GArgs g;
+    g.n = d->num_envs; g.cap = cap; g.batch = batch; g.num_plans = d->num_plans;
+    g.obs = obs_ring; g.first = first_ring; g.plan_idx = plan_idx_ring; g.tick = tick_idx; g.env = env_idx;
+    g.plans = st->plans; g.s = s_out; g.s_next = s_next_out; g.plan_out = plan_out;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((batch + 3) / 4)), block(256);
+    const bool f32 = d->obs_dtype == SNAC_OBS_F32;
+    void (*kern)(const GArgs);
+    if (d->kind == SNAC_ENV_1D) kern = f32 ? k_gather<1, float> : k_gather<1, double>;
+    else if (d->kind == SNAC_ENV_2D) kern = f32 ? k_gather<2, float> : k_gather<2, double>;
+    else kern = f32 ? k_gather<3, float> : k_gather<3, double>;
+    hipLaunchKernelGGL(kern, grid, block, 0, s, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "gather launch");
+    return SNAC_OK;
 }
 
 int snac_step(const snac_env_desc* d, const snac_state* st, uint32_t t, const int8_t* actions, const int8_t* step_size,

@@ -69,10 +69,13 @@ class _Facade(_Base):
         self._set_cb(0)
         return obs, (r, c)
 
-    def _do_step(self, action):
+    def _do_step(self, action, step_size=None):
         import torch
 
-        self.step_size = int(np.random.randint(1, 4))          # drawn on EVERY step, like the reference
+        if step_size is None:
+            self.step_size = int(np.random.randint(1, 4))      # drawn on EVERY step, like the reference
+        else:
+            self.step_size = int(step_size)                    # hindsight variants: injected by the caller
         a = int(action)
         bad = not (0 <= a < self.action_dim) and self._dim != 3
         send = a if -128 <= a <= 127 else 127
@@ -195,10 +198,17 @@ class deep_mobile_printing_1d1r_static(_Env1D):
         self.position_memory = [r]
         return obs.reshape(1, 7)
 
-    def step(self, action):
-        obs, reward, done, (r, _) = self._do_step(action)
+    def step(self, action, _step_size=None):
+        obs, reward, done, (r, _) = self._do_step(action, _step_size)
         self._after_step(action, r)
         return obs.reshape(1, 7), reward, done
+
+
+class deep_mobile_printing_1d1r_hindsight(deep_mobile_printing_1d1r_static):
+    """Env/1D/DMP_Env_1D_static_hindsight_replay.py :: step(action, step_size) -- the caller injects the step size"""
+
+    def step(self, action, step_size):
+        return deep_mobile_printing_1d1r_static.step(self, action, step_size)
 
 
 class deep_mobile_printing_1d1r_dynamic(_Env1D):
@@ -278,8 +288,8 @@ class _EnvGrid(_Facade):
         self.position_memory = [[r, c]]
         return obs.reshape(1, 51), [r, c]
 
-    def _grid_step(self, action):
-        obs, reward, done, (r, c) = self._do_step(action)
+    def _grid_step(self, action, step_size=None):
+        obs, reward, done, (r, c) = self._do_step(action, step_size)
         self.position_memory.append([r, c])
         return obs.reshape(1, 51), reward, done, self.position_memory[-1]
 
@@ -327,9 +337,16 @@ class deep_mobile_printing_2d1r_static(_EnvGrid):
         self.total_brick = float(self.total_brick)
         return obs
 
-    def step(self, action):
-        obs, reward, done, _ = self._grid_step(action)
+    def step(self, action, _step_size=None):
+        obs, reward, done, _ = self._grid_step(action, _step_size)
         return obs, reward, done
+
+
+class deep_mobile_printing_2d1r_hindsight(deep_mobile_printing_2d1r_static):
+    """Env/2D/DMP_Env_2D_static_hindsight_replay.py :: step(action, step_size)"""
+
+    def step(self, action, step_size):
+        return deep_mobile_printing_2d1r_static.step(self, action, step_size)
 
 
 class deep_mobile_printing_2d1r_dynamic(_EnvGrid):
@@ -419,9 +436,16 @@ class deep_mobile_printing_3d1r_static(_Env3D):
         obs, _ = self._grid_reset(0)
         return obs
 
-    def step(self, action):
-        obs, reward, done, _ = self._grid_step(action)
+    def step(self, action, _step_size=None):
+        obs, reward, done, _ = self._grid_step(action, _step_size)
         return obs, reward, done
+
+
+class deep_mobile_printing_3d1r_hindsight(deep_mobile_printing_3d1r_static):
+    """Env/3D/DMP_simulator_3d_static_circle_hindsight_replay.py :: step(action, step_size)"""
+
+    def step(self, action, step_size):
+        return deep_mobile_printing_3d1r_static.step(self, action, step_size)
 
 
 class deep_mobile_printing_3d1r_dynamic(_Env3D):

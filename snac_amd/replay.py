@@ -1,0 +1,105 @@
+"""ReplayRing: the replay memory of the reference's DQN / DRQN scripts, kept on the GPU.
+
+The reference appends one python tuple (s, a, r, s', env_plan) per env-step to a deque and rebuilds float32 minibatches
+on the host (script/DQN/2d/DQN_2d_dynamic.py:122-124 store_memory, :184-199 prefill loop, :145-166 minibatch assembly).
+Here the fused rollout writes its outputs straight into a ring over ticks,
+
+    obs[cap, N, D]   reward[cap, N]   done[cap, N]   action[cap, N]   step_size[cap, N]   plan_idx[cap, N]   first[cap, N]
+
+and a transition is addressed by (slot, env): s' = obs[slot, env]; s = obs[slot - 1, env], or the reset observation
+when first[slot, env] (the reference takes prev_state from env.reset() there); plan = the plan row in effect.  Nothing
+is stored twice and nothing crosses PCIe; sample() gathers float32 minibatches with snac_replay_gather.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class ReplayRing:
+    def __init__(self, env, capacity_ticks):
+        """env: BatchedDMPEnv (already reset); capacity_ticks: ring length in vector steps (>= 2)."""
+        if capacity_ticks < 2:
+            raise ValueError("capacity_ticks must be >= 2")
+        self.env = env
+        self.cap = int(capacity_ticks)
+        N, D, dev = env.num_envs, env.obs_dim, env.device
+        self.obs = torch.empty((self.cap, N, D), dtype=env.obs_dtype, device=dev)
+        self.reward = torch.zeros((self.cap, N), dtype=torch.float32, device=dev)
+        self.done = torch.zeros((self.cap, N), dtype=torch.uint8, device=dev)
+        self.action = torch.zeros((self.cap, N), dtype=torch.int8, device=dev)
+        self.step_size = torch.zeros((self.cap, N), dtype=torch.int8, device=dev)
+        self.plan_idx = torch.zeros((self.cap, N), dtype=torch.int16, device=dev)
+        self.first = torch.zeros((self.cap, N), dtype=torch.uint8, device=dev)
+        self.head = 0          # next slot to write
+        self.ticks = 0         # ticks collected so far
+        self.plan_cells = 30 if env.kind == 1 else 400
+
+    def __len__(self):
+        """Number of addressable transitions."""
+        return self.valid_ticks() * self.env.num_envs
+
+    def valid_ticks(self):
+        """Slots whose predecessor is still in the ring (the oldest slot is kept only as a predecessor once wrapped)."""
+        return self.ticks if self.ticks < self.cap else self.cap - 1
+
+    def collect(self, T, actions=None, step_size=None):
+        """Run T vector steps (auto-reset) and append them: at most two launches (ring wrap).  actions / step_size as in
+        BatchedDMPEnv.rollout ([T, N] or None for the counter RNG)."""
+        T = int(T)
+        if T > self.cap:
+            raise ValueError("T exceeds the ring capacity")
+        done_ticks = 0
+        while done_ticks < T:
+            n = min(T - done_ticks, self.cap - self.head)
+            sl = slice(self.head, self.head + n)
+            a = None if actions is None else actions[done_ticks:done_ticks + n]
+            k = None if step_size is None else step_size[done_ticks:done_ticks + n]
+            self.env.rollout(n, actions=a, step_size=k, obs="all", out=self.obs[sl], reward_out=self.reward[sl], done_out=self.done[sl],
+                             record=dict(actions=self.action[sl], step_size=self.step_size[sl], plan_idx=self.plan_idx[sl],
+                                         first=self.first[sl]))
+            self.head = (self.head + n) % self.cap
+            self.ticks += n
+            done_ticks += n
+
+    def slots(self):
+        """Ring slots that hold addressable transitions, oldest first (int64 tensor on the device)."""
+        v = self.valid_ticks()
+        start = (self.head - v) % self.cap
+        return (torch.arange(v, device=self.env.device) + start) % self.cap
+
+    def gather(self, slot, env_index, with_plan=True):
+        """Minibatch for explicit (slot, env) pairs -> dict of float32 / int tensors on the device:
+        s [B, D], s_next [B, D], action [B], reward [B], done [B] (bool), plan [B, 20, 20] (1D: [B, 30])."""
+        e = self.env
+        slot = torch.as_tensor(slot, device=e.device).to(torch.int32).contiguous()
+        env_index = torch.as_tensor(env_index, device=e.device).to(torch.int32).contiguous()
+        B = int(slot.numel())
+        s = torch.empty((B, e.obs_dim), dtype=torch.float32, device=e.device)
+        s_next = torch.empty_like(s)
+        plan = torch.empty((B, self.plan_cells), dtype=torch.float32, device=e.device) if with_plan else None
+        with torch.cuda.device(e.device):
+            _lib.check(e._lib.snac_replay_gather(C.byref(e._desc), C.byref(e._state), self.cap, _ptr(self.obs), _ptr(self.first),
+                                                 _ptr(self.plan_idx), _ptr(slot), _ptr(env_index), B, _ptr(s), _ptr(s_next),
+                                                 _ptr(plan), e._stream()))
+        sl, ei = slot.long(), env_index.long()
+        out = dict(s=s, s_next=s_next, action=self.action[sl, ei].long(), reward=self.reward[sl, ei], done=self.done[sl, ei].bool())
+        if with_plan:
+            out["plan"] = plan if e.kind == 1 else plan.view(B, 20, 20)
+        return out
+
+    def sample(self, batch, generator=None, with_plan=True):
+        """Uniform minibatch over the addressable transitions (random.sample in the reference, :144)."""
+        v = self.valid_ticks()
+        if v == 0:
+            raise ValueError("the ring is empty")
+        dev = self.env.device
+        age = torch.randint(0, v, (batch,), device=dev, generator=generator)
+        slot = (self.head - 1 - age) % self.cap
+        env_index = torch.randint(0, self.env.num_envs, (batch,), device=dev, generator=generator)
+        return self.gather(slot, env_index, with_plan=with_plan)

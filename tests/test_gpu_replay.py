@@ -1,0 +1,124 @@
+"""GPU: SURVEY.md section 8 rows f1 / f2 -- the device-resident replay ring (what the reference's DQN scripts keep in
+a python deque) and the snapshot / fork primitives (the MCTS variants' functional transition, batched)."""
+import numpy as np
+import pytest
+
+import helpers
+import rng_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_style_memory(dim, dyn, n, T, seed, table):
+    """Restatement of the prefill loop of script/DQN/2d/DQN_2d_dynamic.py:184-199 on the CPU oracle, for n independent
+    envs: state = env.reset(); prev = state[0]; each step store (prev, action, reward, next_state[0], plan); prev = next;
+    on done start over from reset().  Actions / step sizes / plan indices follow the counter RNG (one tick at a time)."""
+    orc = helpers.oracle().OracleBatch(dim, dyn, n, table, seed=seed)
+    prev = orc.reset()
+    reset_obs = prev.copy()
+    A = helpers.DIMS[dim]["A"]
+    mem = []
+    for t in range(T):
+        w = rng_spec.words(seed, rng_spec.STREAM_STEP, np.arange(n, dtype=np.uint64), np.uint64(t))
+        acts = rng_spec.action_of(w, A)
+        nxt, rew, done = orc.step(t, auto_reset=True)
+        pidx = orc.state()["plan_idx"]
+        mem.append(dict(s=prev.copy(), a=acts.astype(np.int64), r=rew.copy(), s_next=nxt.copy(), done=done.copy(), plan_idx=pidx.copy()))
+        prev = np.where(done[:, None] != 0, reset_obs, nxt)       # after done the reference calls reset() again
+    return mem
+
+
+@pytest.mark.parametrize("kind", [(1, True), (2, False), (2, True), (3, True)], ids=str)
+@pytest.mark.parametrize("f32", [False, True], ids=["f64ring", "f32ring"])
+def test_ring_holds_the_reference_replay_tuples(kind, f32):
+    import torch
+    from snac_amd import BatchedDMPEnv, ReplayRing
+
+    dim, dyn = kind
+    n, T, seed = 24, 90, 6
+    tag = ("sin_train" if dim == 1 else "dense_train") if dyn else "p0"
+    table = helpers.plan_table(dim, dyn, tag)
+    full = table.reshape(len(table), 30) if dim == 1 else table.reshape(len(table), 26, 26)
+    env = BatchedDMPEnv(dim, dyn, n, plans=full, seed=seed, obs_dtype=torch.float32 if f32 else torch.float64)
+    env.reset()
+    ring = ReplayRing(env, capacity_ticks=128)
+    ring.collect(40)
+    ring.collect(T - 40)
+    assert ring.valid_ticks() == T and len(ring) == T * n
+    mem = _reference_style_memory(dim, dyn, n, T, seed, table)
+    slots = np.repeat(np.arange(T), n)
+    envs = np.tile(np.arange(n), T)
+    got = ring.gather(slots, envs)
+    s = got["s"].cpu().numpy().reshape(T, n, -1)
+    s_next = got["s_next"].cpu().numpy().reshape(T, n, -1)
+    plan = got["plan"].cpu().numpy().reshape(T, n, -1)
+    for t in range(T):
+        m = mem[t]
+        assert np.array_equal(s[t], m["s"].astype(np.float32)), t           # float32 as torch.FloatTensor(s) makes it
+        assert np.array_equal(s_next[t], m["s_next"].astype(np.float32)), t
+        want_plan = (full[m["plan_idx"]] if dim == 1 else full[m["plan_idx"]][:, 3:23, 3:23].reshape(n, -1)).astype(np.float32)
+        assert np.array_equal(plan[t], want_plan), t
+    assert np.array_equal(got["action"].cpu().numpy().reshape(T, n), np.stack([m["a"] for m in mem]))
+    assert np.array_equal(got["reward"].cpu().numpy().reshape(T, n), np.stack([m["r"] for m in mem]))
+    assert np.array_equal(got["done"].cpu().numpy().reshape(T, n).astype(np.uint8), np.stack([m["done"] for m in mem]))
+
+
+def test_ring_wraps_and_samples():
+    import torch
+    from snac_amd import BatchedDMPEnv, ReplayRing
+
+    n, cap, seed = 16, 32, 2
+    table = helpers.plan_table(2, True, "dense_train")
+    env = BatchedDMPEnv(2, True, n, plans=table.reshape(-1, 26, 26), seed=seed)
+    env.reset()
+    ring = ReplayRing(env, cap)
+    for _ in range(5):
+        ring.collect(20)                                              # 100 ticks through a 32-slot ring
+    T = 100
+    assert ring.valid_ticks() == cap - 1
+    mem = _reference_style_memory(2, True, n, T, seed, table)
+    slots = ring.slots().cpu().numpy()                                # oldest first: ticks T-31 .. T-1
+    assert len(slots) == cap - 1 and slots[-1] == (T - 1) % cap
+    for j, slot in enumerate(slots):
+        t = T - (cap - 1) + j
+        got = ring.gather(np.full(n, slot), np.arange(n), with_plan=False)
+        assert np.array_equal(got["s"].cpu().numpy(), mem[t]["s"].astype(np.float32)), t
+        assert np.array_equal(got["s_next"].cpu().numpy(), mem[t]["s_next"].astype(np.float32)), t
+    g = torch.Generator(device=env.device)
+    g.manual_seed(0)
+    b = ring.sample(256, generator=g)
+    assert b["s"].shape == (256, 51) and b["plan"].shape == (256, 20, 20) and b["s"].dtype == torch.float32
+    assert set(np.unique(b["plan"].cpu().numpy()).tolist()) <= {0.0, 1.0}
+    with pytest.raises(ValueError):
+        ring.collect(cap + 1)
+
+
+def test_snapshot_restore_and_fork():
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    env = BatchedDMPEnv(3, True, 32, seed=8)
+    env.reset()
+    env.rollout(40, obs=None)
+    sd = env.state_dict()
+    o1, r1, d1 = env.rollout(25)
+    mem1 = env.environment_memory().clone()
+    env.load_state_dict(sd)
+    o2, r2, d2 = env.rollout(25)
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(mem1, env.environment_memory())
+    # fork: children = copies of chosen parents, each stepped with its own action (functional transition, batched)
+    env.load_state_dict(sd)
+    parents = [3, 3, 3, 3, 3, 3, 3, 3, 9, 9]
+    acts = torch.tensor([0, 1, 2, 3, 4, 5, 6, 7, 4, 0], dtype=torch.int8)
+    ks = torch.tensor([3, 3, 3, 3, 1, 1, 1, 1, 2, 2], dtype=torch.int8)
+    child = env.fork(parents)
+    before = env.environment_memory().clone()
+    oc, rc, dc = child.step(acts, ks)
+    assert torch.equal(env.environment_memory(), before)              # the parents are untouched
+    for j, (p, a, k) in enumerate(zip(parents, acts.tolist(), ks.tolist())):
+        env.load_state_dict(sd)
+        o, r, d = env.step(torch.full((32,), a, dtype=torch.int8), torch.full((32,), k, dtype=torch.int8))
+        assert torch.equal(o[p], oc[j]) and r[p] == rc[j] and d[p] == dc[j]
+        assert torch.equal(env.environment_memory()[p], child.environment_memory()[j])
+    with pytest.raises(ValueError):
+        BatchedDMPEnv(3, True, 8).load_state_dict(sd)
