@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define SNAC_ABI_VERSION 1
+#define SNAC_ABI_VERSION 2
 
 typedef enum snac_status {
     SNAC_OK = 0,
@@ -101,6 +101,10 @@ typedef struct snac_env_desc {
     int32_t static_plan;        /* plan row used by resets when dynamic == 0 or no plan index is supplied */
     uint64_t seed;              /* counter-RNG seed */
     int64_t env_id_base;        /* global id of local env 0 */
+    int32_t total_step;         /* time limit; 0 = the class constant (750 / 600 / 1300 static 3D / 1000 dynamic 3D).
+                                   The 3D L-Net variant runs the dynamic rules with 1300
+                                   (Env/3D/DMP_simulator_3d_static_circle_Lnet.py:28) */
+    int32_t reserved;           /* must be 0 */
 } snac_env_desc;
 
 typedef struct snac_state {

@@ -25,6 +25,7 @@ int orc_init(orc_env* e, int dim, int dynamic) {
     memset(e, 0, sizeof(*e));
     e->dim = dim;
     e->dynamic = dynamic ? 1 : 0;
+    e->obs_norm = e->dynamic; e->rules_dyn = e->dynamic; e->frame = -1;
     if (dim == 1) {
         e->hw = 2; e->H = 1; e->W = 30 + 2 * 2; e->total_step = 750; e->num_actions = 3; e->obs_dim = 2 * 2 + 1 + 2;
     } else if (dim == 2) {
@@ -34,6 +35,18 @@ int orc_init(orc_env* e, int dim, int dynamic) {
     } else {
         return -1;
     }
+    return 0;
+}
+
+/* L-Net env variants (Env/1D/DMP_Env_1D_static_Lnet.py, Env/2D/DMP_Env_2D_static_Lnet.py:61-76,
+ * Env/3D/DMP_simulator_3d_static_circle_Lnet.py): a static plan with, per dimension, normalised observation scalars,
+ * frame value 2 instead of -1 (2D), the dynamic class's termination rules with total_step 1300 (3D).
+ * total_step <= 0 keeps the current value. */
+int orc_configure(orc_env* e, int obs_norm, int rules_dyn, int total_step, int frame) {
+    e->obs_norm = obs_norm ? 1 : 0;
+    e->rules_dyn = rules_dyn ? 1 : 0;
+    if (total_step > 0) e->total_step = total_step;
+    e->frame = frame;
     return 0;
 }
 
@@ -50,7 +63,7 @@ void orc_observe(const orc_env* e, double* obs) {
         for (int i = -e->hw; i <= e->hw; ++i)
             for (int j = -e->hw; j <= e->hw; ++j) obs[n++] = (double)G(e, e->pos[0] + i, e->pos[1] + j);
     }
-    if (e->dynamic) {
+    if (e->obs_norm) {
         obs[n++] = (double)e->cb / (double)e->tb;
         obs[n++] = (double)e->cs / (double)e->total_step;
     } else {
@@ -72,7 +85,7 @@ int orc_reset(orc_env* e, const int32_t* plan, int plan_idx, double* obs) {
         for (int c = 0; c < e->W; ++c) {
             int frame = (c < e->hw) || (c >= e->W - e->hw);
             if (e->dim != 1) frame = frame || (r < e->hw) || (r >= e->H - e->hw);
-            G(e, r, c) = frame ? -1 : 0;             /* S1:69-71, D2:49-53 */
+            G(e, r, c) = frame ? e->frame : 0;       /* S1:69-71, D2:49-53; 2 in the 2D L-Net variant */
         }
     e->cb = 0;
     e->cs = 0;
@@ -210,7 +223,7 @@ static int step3(orc_env* e, int action, int k, double* reward, int* done) {
             tr = e->pos[0] + DR[action - 4]; tc = e->pos[1] + DC[action - 4];
             G(e, tr, tc) += 1;
         }
-        if (e->dynamic) {
+        if (e->rules_dyn) {
             int after[8];
             check_sur(e, after);                     /* D3:199: re-evaluated AFTER the build */
             if (after[0] && after[1] && after[2] && after[3]) { *done = 1; *reward = -100.0; return 0; }
@@ -224,7 +237,7 @@ static int step3(orc_env* e, int action, int k, double* reward, int* done) {
     }
     /* moves, blocked moves, blocked builds: S3:226-230, D3:226-231 */
     *done = (e->cs >= e->total_step);
-    if (!e->dynamic) *done = *done || (check[0] && check[1] && check[2] && check[3]);
+    if (!e->rules_dyn) *done = *done || (check[0] && check[1] && check[2] && check[3]);
     *reward = 0.0;
     return 0;
 }

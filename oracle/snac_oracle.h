@@ -41,10 +41,14 @@ typedef struct orc_env {
     int32_t cb, cs, tb;  /* count_brick, count_step, total_brick */
     int32_t step_size;   /* last step size used */
     int32_t plan_idx;
+    int32_t obs_norm;    /* observation scalars cb/tb, cs/T (default: = dynamic) */
+    int32_t rules_dyn;   /* 3D: termination rules of the dynamic class (default: = dynamic) */
+    int32_t frame;       /* value of the frame cells: -1, or 2 in the 2D L-Net variant */
 } orc_env;
 
 /* ---- single env ---- */
 int  orc_init(orc_env* e, int dim, int dynamic);
+int  orc_configure(orc_env* e, int obs_norm, int rules_dyn, int total_step, int frame);
 /* plan: 30 (1D) or 676 (2D/3D) ints; obs: obs_dim doubles (may be NULL) */
 int  orc_reset(orc_env* e, const int32_t* plan, int plan_idx, double* obs);
 /* returns 0, or -1 for an action outside [0, num_actions) (the reference raises after cs += 1) */

@@ -24,7 +24,8 @@ def build(force=False):
 class _Env(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "dynamic", "hw", "H", "W", "total_step", "num_actions", "obs_dim")] + [
         ("grid", C.c_int32 * MAX_CELLS), ("plan", C.c_int32 * MAX_CELLS), ("pos", C.c_int32 * 2),
-        ("cb", C.c_int32), ("cs", C.c_int32), ("tb", C.c_int32), ("step_size", C.c_int32), ("plan_idx", C.c_int32)]
+        ("cb", C.c_int32), ("cs", C.c_int32), ("tb", C.c_int32), ("step_size", C.c_int32), ("plan_idx", C.c_int32),
+        ("obs_norm", C.c_int32), ("rules_dyn", C.c_int32), ("frame", C.c_int32)]
 
 
 class _Batch(C.Structure):
@@ -48,6 +49,7 @@ def lib():
         build()
         L = C.CDLL(LIB)
         L.orc_init.argtypes = [C.POINTER(_Env), C.c_int, C.c_int]
+        L.orc_configure.argtypes = [C.POINTER(_Env), C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_reset.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_int, C.c_void_p]
         L.orc_step.argtypes = [C.POINTER(_Env), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.orc_observe.argtypes = [C.POINTER(_Env), C.c_void_p]
@@ -105,6 +107,10 @@ class OracleEnv:
         if lib().orc_init(C.byref(self.e), dim, int(dynamic)):
             raise ValueError("bad dim")
         self.obs_dim = self.e.obs_dim
+
+    def configure(self, obs_norm, rules_dyn, total_step=0, frame=-1):
+        lib().orc_configure(C.byref(self.e), int(obs_norm), int(rules_dyn), int(total_step), int(frame))
+        return self
 
     def reset(self, plan, plan_idx=0):
         plan = np.ascontiguousarray(np.asarray(plan).reshape(-1), np.int32)

@@ -10,6 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SNAC_OK = 0
+ABI_VERSION = 2
 ENV_1D, ENV_2D, ENV_3D = 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 OBS_NONE, OBS_ALL, OBS_LAST = 0, 1, 2
@@ -27,7 +28,8 @@ class Sizes(C.Structure):
 
 class EnvDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dynamic", C.c_int32), ("num_envs", C.c_int32), ("num_plans", C.c_int32),
-                ("obs_dtype", C.c_int32), ("static_plan", C.c_int32), ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
+                ("obs_dtype", C.c_int32), ("static_plan", C.c_int32), ("seed", C.c_uint64), ("env_id_base", C.c_int64),
+                ("total_step", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RolloutRecord(C.Structure):
@@ -81,7 +83,7 @@ def lib():
         L.snac_export_grid.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
         for n in EXPORTS:
             getattr(L, n)
-        if L.snac_version() != 1:
+        if L.snac_version() != ABI_VERSION:
             raise SnacError("libsnac_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -33,7 +33,7 @@ class BatchedDMPEnv:
     """
 
     def __init__(self, kind, dynamic, num_envs, plans=None, plan_choose=0, density="dense", split="train",
-                 device="cuda", seed=1, obs_dtype=torch.float64, env_id_base=0):
+                 device="cuda", seed=1, obs_dtype=torch.float64, env_id_base=0, total_step=None):
         if not torch.cuda.is_available():
             raise _lib.SnacError("BatchedDMPEnv needs a ROCm GPU: there is no CPU fallback")
         self.kind = _KINDS[kind]
@@ -52,7 +52,8 @@ class BatchedDMPEnv:
         self._lib = _lib.lib()
         sz = _lib.env_sizes(self.kind, self.dynamic)
         self.sizes = sz
-        self.obs_dim, self.num_actions, self.total_step = sz.obs_dim, sz.num_actions, sz.total_step
+        self.obs_dim, self.num_actions = sz.obs_dim, sz.num_actions
+        self.total_step = int(total_step) if total_step else sz.total_step   # override: the 3D L-Net variant (1300)
         if plans is None:
             if self.dynamic:
                 plans = _plans.dataset(self.kind, density, split)
@@ -70,7 +71,7 @@ class BatchedDMPEnv:
         self._stats = torch.zeros((3, N), dtype=torch.int64, device=dev)
         self._desc = _lib.EnvDesc(self.kind, int(self.dynamic), N, self.num_plans,
                                   _lib.OBS_F64 if obs_dtype == torch.float64 else _lib.OBS_F32, 0,
-                                  self.seed & 0xFFFFFFFFFFFFFFFF, self.env_id_base)
+                                  self.seed & 0xFFFFFFFFFFFFFFFF, self.env_id_base, self.total_step, 0)
         self._state = _lib.State(self._hdr.data_ptr(), self._episode.data_ptr(), self._grid.data_ptr(),
                                  self._plans.data_ptr(), self._plan_tb.data_ptr(), self._stats[0].data_ptr(),
                                  self._stats[1].data_ptr(), self._stats[2].data_ptr())
@@ -208,7 +209,7 @@ class BatchedDMPEnv:
         transition(state, action).  Episodic sums start at zero; counter-RNG streams are keyed by the NEW local index."""
         index = torch.as_tensor(index, device=self.device, dtype=torch.long)
         child = BatchedDMPEnv(self.kind, self.dynamic, int(index.numel()), plans=self.plans_full, device=self.device, seed=self.seed,
-                              obs_dtype=self.obs_dtype, env_id_base=self.env_id_base)
+                              obs_dtype=self.obs_dtype, env_id_base=self.env_id_base, total_step=self.total_step)
         child._hdr.copy_(self._hdr[index]); child._episode.copy_(self._episode[index]); child._grid.copy_(self._grid[index])
         child.t = self.t
         child._was_reset = self._was_reset

@@ -55,6 +55,7 @@ __device__ inline uint32_t rng_word(EnvKeys k, uint32_t t) { return mix32(mix32(
 // ------------------------------------------------------------------------------------------------
 struct KArgs {
     int32_t n, num_plans, static_plan, T, auto_reset, obs_mode;
+    int32_t total_step;        // the env's time limit (snac_env_desc.total_step or the kind's default)
     uint32_t t0, key_step, key_plan;
     int64_t env_id_base;
     int4* hdr;                 // snac_env_hdr[N] as 16-byte words
@@ -178,7 +179,7 @@ struct K2D {
         if (lane < GE) cells(lds)[(lane + 3) * RS + e] = ((uint64_t)ROW_HI << 32) | ROW_LO;
     }
     // step: DMP_Env_2D_dynamic_usedata_plan.py:85-147
-    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int lane, int& reward, bool& done) {
         uint64_t* cw = cells(lds) + s.r * RS + lane;
         const uint64_t w = *cw;
         const int off = 2 * s.c;
@@ -195,7 +196,7 @@ struct K2D {
         if (act == 2) s.r = min(s.r + k, 22);                        // "up" is row + k (:100-103)
         if (act == 3) s.r = max(s.r - k, 3);
         const bool term = drop && s.cb >= s.tb;                      // :117-126, tested before the time limit
-        done = term || s.cs >= TS;
+        done = term || s.cs >= ts;
         // un-clamped cell vs plan (:129-133): 5 iff the cell was empty and is planned
         reward = (drop && !term && !was && planned) ? 5 : 0;
     }
@@ -264,14 +265,14 @@ struct K3D {
         for (int i = lane; i < GE; i += 64) { const int r = i / 20, c = i - r * 20; h[(r + 3) * 26 + c + 3] = 0; }
     }
     // step: DMP_simulator_3d_static_circle.py:153-230, DMP_simulator_3d_dynamic_triangle_usedata.py:142-231
-    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r * 26 + s.c;         // the agent's cell
         s.cs += 1;
         reward = 0;
         // check_sur (:88-102 / :77-91): left, right, "up" (row + 1), "down" (row - 1)
         const int n0 = h[-1], n1 = h[1], n2 = h[26], n3 = h[-26];
         const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
-        done = (s.cs >= TS) || (!DYN && boxed_pre);                  // bottom of step(): static :226, dynamic :226
+        done = (s.cs >= ts) || (!DYN && boxed_pre);                  // bottom of step(): static :226, dynamic :226
         const int d = act & 3;
         const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
         const int dl = dr * 26 + dc;
@@ -373,7 +374,7 @@ struct K1D {
         if (lane < 30) hmap(lds)[e * ES + lane + 2] = 0;
     }
     // step: DMP_Env_1D_static.py:85-136
-    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r;
         const int hnew = (int)*h + 1;
         const int pl = plan(lds)[lane * ES + s.r - 2];
@@ -383,7 +384,7 @@ struct K1D {
         if (act == 0) s.r = max(s.r - k, 2);                         // clip_position :57-64
         if (act == 1) s.r = min(s.r + k, 31);
         const bool term = drop && s.cb >= s.tb;                      // :107-114, before the time limit
-        done = term || s.cs >= TS;
+        done = term || s.cs >= ts;
         reward = (drop && !term) ? (hnew > pl ? -1 : (hnew == pl ? 10 : 1)) : 0;   // :117-123
     }
     // iou: DMP_Env_1D_static.py:138-151
@@ -465,10 +466,10 @@ __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int
 // the two scalar observation slots (count_brick, count_step or their normalised forms): one IEEE float64 division per
 // lane (no fast-math), staged in LDS for phase 2.
 template <class K, typename OT>
-__device__ __forceinline__ void write_scalars(uint32_t* lds, OT* orow, const Lane& s, bool active, int lane) {
+__device__ __forceinline__ void write_scalars(uint32_t* lds, const Lane& s, int ts, int lane) {
     const double num0 = (double)s.cb, num1 = (double)s.cs;
     const double v0 = K::DYN ? num0 / (double)s.tb : num0;
-    const double v1 = K::DYN ? num1 / (double)K::TS : num1;
+    const double v1 = K::DYN ? num1 / (double)ts : num1;
     if (lane < K::E) {
         double2 v; v.x = v0; v.y = v1;
         *(double2*)(K::sc(lds) + 2 * lane) = v;
@@ -489,8 +490,8 @@ __device__ __forceinline__ uint32_t* wave_lds() {
 }
 
 template <class K, typename OT>
-__device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, const Lane& s, bool active, int lane) {
-    write_scalars<K, OT>(lds, orow, s, active, lane);
+__device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, const Lane& s, int ts, int lane) {
+    write_scalars<K, OT>(lds, s, ts, lane);
     if (nenv == K::E) write_obs<K, OT, true>(lds, orow, nenv, K::key0(s), K::key1(s), lane);
     else write_obs<K, OT, false>(lds, orow, nenv, K::key0(s), K::key1(s), lane);
 }
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
             const uint32_t w = rng_word(sk, a.t0 + (uint32_t)t);
             const int act = a.actions ? (int)a.actions[row + lane] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
             const int k = a.step_size ? (int)a.step_size[row + lane] : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
-            K::step(lds, s, act, k, lane, reward, done);
+            K::step(lds, s, act, k, a.total_step, lane, reward, done);
             s.ep_ret += reward;
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
             if (a.reward) a.reward[row + lane] = (float)reward;
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
         }
         if (a.obs_mode == SNAC_OBS_ALL || (a.obs_mode == SNAC_OBS_LAST && t == a.T - 1)) {
             const size_t orow = a.obs_mode == SNAC_OBS_ALL ? row : (size_t)env0;
-            emit_obs<K, OT>(lds, obs + orow * K::D, nenv, s, active, lane);
+            emit_obs<K, OT>(lds, obs + orow * K::D, nenv, s, a.total_step, lane);
         }
     }
     K::store_grid(lds, a, env0, nenv, lane);
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
         if (active) a.out_f64[env] = v;
         return;
     }
-    if (a.obs) emit_obs<K, OT>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s, active, lane);
+    if (a.obs) emit_obs<K, OT>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s, a.total_step, lane);
 }
 
 // environment_memory with its -1 frame, float64 [N][H][W]; one thread per cell
@@ -694,6 +695,7 @@ int check_common(const snac_env_desc* d, const snac_state* st) {
     if (d->num_plans <= 0 || d->num_plans > 32767) return fail(SNAC_ERR_ARG, "num_plans out of range");
     if (d->static_plan < 0 || d->static_plan >= d->num_plans) return fail(SNAC_ERR_ARG, "static_plan out of range");
     if (d->obs_dtype != SNAC_OBS_F64 && d->obs_dtype != SNAC_OBS_F32) return fail(SNAC_ERR_ARG, "unknown obs_dtype");
+    if (d->total_step < 0 || d->total_step > 32000) return fail(SNAC_ERR_ARG, "total_step out of range");
     if (!st->hdr || !st->episode || !st->grid || !st->plans || !st->plan_tb || !st->stat_episodes || !st->stat_return ||
         !st->stat_iou_fx)
         return fail(SNAC_ERR_ARG, "null pointer in snac_state");
@@ -704,6 +706,8 @@ KArgs make_args(const snac_env_desc* d, const snac_state* st) {
     KArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n = d->num_envs; a.num_plans = d->num_plans; a.static_plan = d->static_plan;
+    a.total_step = d->total_step > 0 ? d->total_step
+                                     : (d->kind == SNAC_ENV_1D ? 750 : (d->kind == SNAC_ENV_2D ? 600 : (d->dynamic ? 1000 : 1300)));
     a.key_step = stream_key(d->seed, 0); a.key_plan = stream_key(d->seed, 1);
     a.env_id_base = d->env_id_base;
     a.hdr = (int4*)st->hdr; a.episode = st->episode; a.grid = st->grid; a.plans = st->plans; a.plan_tb = st->plan_tb;

@@ -47,10 +47,10 @@ class _Facade(_Base):
     _dim = 0
     _dynamic = False
 
-    def _setup(self, plans_full):
+    def _setup(self, plans_full, total_step=None):
         from .batched import BatchedDMPEnv  # imports torch; raises without a ROCm GPU
 
-        self._env = BatchedDMPEnv(self._dim, self._dynamic, 1, plans=plans_full)
+        self._env = BatchedDMPEnv(self._dim, self._dynamic, 1, plans=plans_full, total_step=total_step)
         self._table = np.asarray(plans_full, np.float64)
 
     # ---- shared plumbing ---------------------------------------------------------------------------

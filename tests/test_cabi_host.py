@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.EXPORTS), names
     for n in names:
         assert hasattr(L, n), n
-    assert L.snac_version() == 1
+    assert L.snac_version() == _lib.ABI_VERSION
 
 
 def test_env_sizes_match_reference_constants():
@@ -45,14 +45,14 @@ def test_argument_validation_happens_before_any_launch():
     from snac_amd import _lib
 
     L = _lib.lib()
-    d = _lib.EnvDesc(2, 1, 16, 4, 0, 0, 1, 0)
+    d = _lib.EnvDesc(2, 1, 16, 4, 0, 0, 1, 0, 0, 0)
     st = _lib.State(0, 0, 0, 0, 0, 0, 0, 0)   # null pointers
     assert L.snac_step(C.byref(d), C.byref(st), 0, None, None, 0, None, None, None, None) == -1
     assert b"null pointer" in L.snac_last_error()
-    bad = _lib.EnvDesc(9, 1, 16, 4, 0, 0, 1, 0)
+    bad = _lib.EnvDesc(9, 1, 16, 4, 0, 0, 1, 0, 0, 0)
     assert L.snac_reset(C.byref(bad), C.byref(st), None, None, None, None) == -1
     assert b"kind" in L.snac_last_error()
-    bad = _lib.EnvDesc(2, 1, 0, 4, 0, 0, 1, 0)
+    bad = _lib.EnvDesc(2, 1, 0, 4, 0, 0, 1, 0, 0, 0)
     assert L.snac_iou(C.byref(bad), C.byref(st), None, None) == -1
     assert L.snac_rollout(None, None, 1, 0, None, None, 0, None, None, None, None) == -1
 
