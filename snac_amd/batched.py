@@ -33,7 +33,7 @@ class BatchedDMPEnv:
     """
 
     def __init__(self, kind, dynamic, num_envs, plans=None, plan_choose=0, density="dense", split="train",
-                 device="cuda", seed=1, obs_dtype=torch.float64, env_id_base=0, total_step=None):
+                 device="cuda", seed=1, obs_dtype=torch.float64, env_id_base=0, total_step=None, plan_tb=None):
         if not torch.cuda.is_available():
             raise _lib.SnacError("BatchedDMPEnv needs a ROCm GPU: there is no CPU fallback")
         self.kind = _KINDS[kind]
@@ -59,8 +59,12 @@ class BatchedDMPEnv:
                 plans = _plans.dataset(self.kind, density, split)
             else:
                 plans = _plans.static_plan(self.kind, plan_choose)[None]
-        self.plans_full = np.asarray(plans, np.float64)
+        self.plans_full = np.array(plans, np.float64)          # own copy: set_plan_row() edits it
         packed, tb = _plans.pack_plans(self.kind, self.plans_full)
+        if plan_tb is not None:                                # caller-supplied total_brick per plan row (hindsight relabel)
+            tb = np.asarray(plan_tb).astype(np.int16)
+            if tb.shape != (len(packed),) or tb.min() < 1:
+                raise ValueError("plan_tb must hold one positive total_brick per plan")
         self.num_plans = len(packed)
         dev, N = self.device, self.num_envs
         self._plans = torch.from_numpy(packed.view(np.int32) if self.kind == 2 else packed).to(dev)
@@ -188,6 +192,21 @@ class BatchedDMPEnv:
                                                   C.byref(rec) if rec is not None else None, self._stream()))
         self.t += T
         return o, reward, (done.view(torch.bool) if done is not None else None)
+
+    def set_plan_row(self, index, full_plan, update_tb=False):
+        """Replace row `index` of the device plan table by `full_plan` ([30] / [26, 26] as the reference stores it).
+        update_tb=False keeps the row's total_brick: the hindsight scripts overwrite env.plan AFTER reset() has
+        computed total_brick from the original plan (script/DRQN_hindsight/2d/DRQN_hindsight_2D_static.py:245-250)."""
+        index = int(index)
+        if not 0 <= index < self.num_plans:
+            raise ValueError("plan index out of range")
+        full = np.asarray(full_plan, np.float64)
+        packed, tb = _plans.pack_plans(self.kind, full[None])
+        row = torch.from_numpy(packed.view(np.int32) if self.kind == 2 else packed)[0]
+        self._plans[index].copy_(row.to(self.device))
+        self.plans_full[index] = full
+        if update_tb:
+            self._plan_tb[index] = int(tb[0])
 
     # ---- snapshots (MCTS-style branching, checkpoints) ---------------------------------------------
     def state_dict(self):

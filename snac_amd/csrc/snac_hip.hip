@@ -734,7 +734,7 @@ void launch_dt(Op op, int obs_dtype, const KArgs& a, hipStream_t s) {
 // tile size: enough tiles to give every SIMD of the 256 CUs a few waves; SNAC_TILE overrides (tuning)
 int pick_tile(int kind, int n) {
     static const int forced = [] { const char* e = std::getenv("SNAC_TILE"); return e ? std::atoi(e) : 0; }();
-    if (kind == SNAC_ENV_3D) return 16;
+    if (kind == SNAC_ENV_3D) return forced == 16 ? 16 : 8;   // 8: 17 KB of LDS per wave, 9 waves per CU; measured +10-15 % over 16
     if (forced == 16 || forced == 32 || forced == 64) return forced;
     if (n >= 64 * 1024) return 64;   // >= one wave per SIMD on 256 CUs; measured best at N = 65536 (profiles/)
     if (n >= 32 * 1024) return 32;
@@ -755,8 +755,9 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     switch (d->kind) {
         case SNAC_ENV_1D: launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D: launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
-        default:
-            dyn ? launch_dt<K3D, true, 16, 2>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 16, 2>(op, d->obs_dtype, a, s);
+        default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
+            if (E == 8) dyn ? launch_dt<K3D, true, 8, 4>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 4>(op, d->obs_dtype, a, s);
+            else dyn ? launch_dt<K3D, true, 16, 2>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 16, 2>(op, d->obs_dtype, a, s);
             break;
     }
     hipError_t e = hipGetLastError();

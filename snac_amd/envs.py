@@ -60,8 +60,12 @@ class _Facade(_Base):
         return int(h8[0]), int(h8[1]), int(h16[2]), int(h16[3]), int(h16[4])
 
     def _do_reset(self, plan_idx):
+        if getattr(self, "_plan_dirty", False):                # a hindsight relabel changed the device row: restore it
+            self._env.set_plan_row(self._dirty_row, self._table[self._dirty_row])
+            self._plan_dirty = False
         obs = self._env.reset(plan_idx=np.asarray([plan_idx], np.int16)).cpu().numpy()
-        self.plan = self._table[plan_idx]
+        self.plan = self._table[plan_idx].copy()               # a fresh array per reset, like create_plan()
+        self._sent_plan = self.plan.copy()
         r, c, cb, cs, tb = self._hdr()
         self.total_brick = float(tb)
         self.count_step = 0
@@ -90,6 +94,17 @@ class _Facade(_Base):
 
     def _set_cb(self, cb):
         self.count_brick = cb
+
+    def _sync_plan(self):
+        """Hindsight relabelling (script/DRQN_hindsight/2d/DRQN_hindsight_2D_static.py:245-252): after reset() the
+        caller overwrites `plan` (in place, or by rebinding it in 1D) with the final grid of the episode it replays.
+        Push such a change to the device plan row; total_brick keeps the value computed by reset(), as in the reference."""
+        cur = np.asarray(self.plan, np.float64)
+        if not np.array_equal(cur, self._sent_plan):
+            self._dirty_row = int(self._env.plan_idx[0])
+            self._env.set_plan_row(self._dirty_row, cur)
+            self._sent_plan = cur.copy()
+            self._plan_dirty = True
 
     @property
     def environment_memory(self):
@@ -208,6 +223,7 @@ class deep_mobile_printing_1d1r_hindsight(deep_mobile_printing_1d1r_static):
     """Env/1D/DMP_Env_1D_static_hindsight_replay.py :: step(action, step_size) -- the caller injects the step size"""
 
     def step(self, action, step_size):
+        self._sync_plan()
         return deep_mobile_printing_1d1r_static.step(self, action, step_size)
 
 
@@ -346,6 +362,7 @@ class deep_mobile_printing_2d1r_hindsight(deep_mobile_printing_2d1r_static):
     """Env/2D/DMP_Env_2D_static_hindsight_replay.py :: step(action, step_size)"""
 
     def step(self, action, step_size):
+        self._sync_plan()
         return deep_mobile_printing_2d1r_static.step(self, action, step_size)
 
 
@@ -445,6 +462,7 @@ class deep_mobile_printing_3d1r_hindsight(deep_mobile_printing_3d1r_static):
     """Env/3D/DMP_simulator_3d_static_circle_hindsight_replay.py :: step(action, step_size)"""
 
     def step(self, action, step_size):
+        self._sync_plan()
         return deep_mobile_printing_3d1r_static.step(self, action, step_size)
 
 
