@@ -64,5 +64,59 @@ def main():
             print("step() 2D dynamic N=%-7d %s  %8.4f ms/tick  %.3e env-steps/s" % (n, "explicit a,k" if explicit else "counter RNG ", ms, n / ms * 1e3))
 
 
+def graph_step_time(n, ticks=300):
+    """step() with explicit inputs replayed as a hipGraph (torch.cuda.CUDAGraph) vs the eager call."""
+    env = BatchedDMPEnv(2, True, n, seed=1)
+    env.reset()
+    a = torch.randint(0, 5, (n,), dtype=torch.int8, device=env.device)
+    k = torch.randint(1, 4, (n,), dtype=torch.int8, device=env.device)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        env.step(a, k, auto_reset=True)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        env.step(a, k, auto_reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(ticks):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / ticks * 1e3
+
+
+def gather_time(n=65536, cap=64, batch=65536, reps=20):
+    """snac_replay_gather: float32 (s, s', plan) minibatch out of a float64 ring."""
+    from snac_amd import ReplayRing
+
+    env = BatchedDMPEnv(2, True, n, seed=1)
+    env.reset()
+    ring = ReplayRing(env, cap)
+    ring.collect(cap)
+    slot = torch.randint(1, cap, (batch,), device=env.device)
+    ei = torch.randint(0, n, (batch,), device=env.device)
+    ring.gather(slot, ei)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ring.gather(slot, ei)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    moved = batch * (2 * 408 + 2 * 204 + 1600)           # read 2 f64 rows, write 2 f32 rows + 400 f32 plan cells
+    return ms, moved / ms / 1e6
+
+
+def extras():
+    for n in (1, 4096, 65536):
+        print("step() as hipGraph replay 2D dynamic N=%-7d explicit a,k  %8.4f ms/tick" % (n, graph_step_time(n)))
+    ms, gbs = gather_time()
+    print("replay gather 65536 samples from a 64-tick x 65536-env f64 ring  %8.3f ms  %.0f GB/s moved" % (ms, gbs))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extras":
+        extras()
+    else:
+        main()
+        extras()
