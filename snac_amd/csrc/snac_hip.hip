@@ -172,7 +172,7 @@ struct K2D {
     }
     // reset: DMP_Env_2D_dynamic_usedata_plan.py:34-66 (the total_brick floor of 30 is folded into plan_tb)
     __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
-        s.pidx = pidx; s.tb = a.plan_tb[pidx];
+        if (pidx >= 0) { s.pidx = pidx; s.tb = a.plan_tb[pidx]; }    // pidx < 0: the env keeps its plan and total_brick
         s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
     }
     __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave empties env e's interior
@@ -256,7 +256,7 @@ struct K3D {
     }
     // reset: DMP_simulator_3d_dynamic_triangle_usedata.py:45-75
     __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
-        s.pidx = pidx; s.tb = a.plan_tb[pidx];
+        if (pidx >= 0) { s.pidx = pidx; s.tb = a.plan_tb[pidx]; }    // pidx < 0: the env keeps its plan and total_brick
         s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
     }
     __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave zeroes env e's interior
@@ -367,7 +367,7 @@ struct K1D {
     }
     // reset: DMP_Env_1D_static.py:66-83, DMP_Env_1D_dynamic_usedata_plan.py:40-70
     __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
-        s.pidx = pidx; s.tb = a.plan_tb[pidx];
+        if (pidx >= 0) { s.pidx = pidx; s.tb = a.plan_tb[pidx]; }    // pidx < 0: the env keeps its plan and total_brick
         s.r = 2; s.c = 0; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
     }
     __device__ static void clear(uint32_t* lds, int e, int lane) {   // whole wave zeroes env e's interior
@@ -526,14 +526,20 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
         bool done = false;
         const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
         if (__any(nr)) {
+            const int old_pidx = s.pidx, old_tb = s.tb;
             if (nr) {
                 episode += 1;
-                K::reset(a, s, pick_plan<K>(a, pk, episode));
+                const int pidx = pick_plan<K>(a, pk, episode);
+                K::reset(a, s, pidx == old_pidx ? -1 : pidx);   // -1: same plan again (static tables): keep tb, no load
+                if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
             }
             for (unsigned long long m = __ballot(nr); m; m &= m - 1) {
                 const int e = __ffsll(m) - 1;
+                const int pe = __builtin_amdgcn_readlane(s.pidx, e);
                 K::clear(lds, e, lane);
-                K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane);
+                // a vector load here waits for every observation store issued before it (vmcnt is in-order): skip it
+                // when the env keeps its plan
+                if (pe != __builtin_amdgcn_readlane(old_pidx, e)) K::load_plan(lds, a, e, pe, lane);
             }
         }
         if (active) {
