@@ -87,15 +87,16 @@ def test_step_explicit_inputs_vs_oracle(kind):
         assert _same_bits(rg.cpu().numpy(), rc), (kind, t)
         assert np.array_equal(dg.cpu().numpy().astype(np.uint8), dc), (kind, t)
     _check_state(env, orc)
-    assert _same_bits(env.observe().cpu().numpy(), np.stack([o for o in _observe_all(orc)]))
+    assert _same_bits(env.observe().cpu().numpy(), _observe_all(orc))
 
 
 def _observe_all(orc):
-    mod = helpers.oracle()
+    """Current observation of every oracle env (orc_observe), [n, obs_dim]."""
+    L = helpers.oracle().lib()
     out = np.zeros((orc.n, orc.obs_dim))
     for i in range(orc.n):
-        mod.lib().orc_observe(orc.b.contents.envs[i], out[i].ctypes.data)
-        yield out[i]
+        L.orc_observe(orc.b.contents.envs[i], out[i].ctypes.data)
+    return out
 
 
 @pytest.mark.parametrize("kind", KINDS, ids=_ids)
