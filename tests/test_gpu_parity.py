@@ -221,3 +221,27 @@ def test_sharding_is_invisible():
     assert _same_bits(ow[:, :n].cpu().numpy(), ol.cpu().numpy()) and _same_bits(ow[:, n:].cpu().numpy(), oh.cpu().numpy())
     a, b, c = whole.episodic_stats(), lo.episodic_stats(), hi.episodic_stats()
     assert all(a[k] == b[k] + c[k] for k in a)
+
+
+@pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
+def test_3d_plan_table_paths(dyn):
+    """3D with plan tables that are not the reference's {0, 6} pattern: arbitrary heights, and another common height."""
+    rng = np.random.default_rng(5)
+    general = np.zeros((37, 26, 26), np.int32)
+    general[:, 3:23, 3:23] = rng.integers(0, 4, size=(37, 20, 20)) * rng.integers(0, 2, size=(37, 20, 20))   # heights 0..3
+    general[:, 5, 5] = 3
+    binary9 = np.zeros((21, 26, 26), np.int32)
+    binary9[:, 3:23, 3:23] = 9 * (rng.random((21, 20, 20)) < 0.4)
+    binary9[:, 4, 4] = 9
+    for full in (general, binary9):
+        table = full.reshape(len(full), -1)
+        env, orc = _make(3, dyn, 150, seed=12, table=table)
+        assert _same_bits(env.reset().cpu().numpy(), orc.reset())
+        t0 = 0
+        for T in (3, 400, 5, 120):
+            og, rg, dg = env.rollout(T)
+            oc, rc, dc = orc.rollout(T, t0=t0)
+            assert _same_bits(og.cpu().numpy(), oc) and _same_bits(rg.cpu().numpy(), rc)
+            assert np.array_equal(dg.cpu().numpy().astype(np.uint8), dc)
+            t0 += T
+        _check_state(env, orc)
