@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define SNAC_ABI_VERSION 2
+#define SNAC_ABI_VERSION 3
 
 typedef enum snac_status {
     SNAC_OK = 0,
@@ -190,6 +190,42 @@ int snac_iou(const snac_env_desc* desc, const snac_state* st, double* out, void*
 
 /* environment_memory as the reference holds it: out is double[N][env_height][env_width] with the -1 frame */
 int snac_export_grid(const snac_env_desc* desc, const snac_state* st, double* out, void* stream);
+
+/* ---- tree search: the MCTS variants of the reference (Env/1D/DMP_Env_1D_{static,dynamic}_MCTS*.py,
+ * Env/2D/DMP_ENV_2D_{static,dynamic}_MCTS*.py, Env/3D/DMP_simulator_3d_*_MCTS*.py; nine files) ----
+ *
+ * transition(state, action, is_model_dynamic) -> (state', obs, reward, done)
+ * (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175, Env/1D/DMP_Env_1D_dynamic_MCTS.py:82-139,
+ *  Env/3D/DMP_simulator_3d_static_circle_MCTS.py:215-288, Env/3D/DMP_simulator_3d_dynamic_triangle_MCTS.py:195-277;
+ *  called once per tree edge by script/MCTS/utils/mcts_Qvalue_dynamic.py:88,118), batched over m edges.
+ * The state arrays of `st` are used as a NODE POOL of desc->num_envs rows.  For i in [0, m):
+ *     row dst_index[i]  <-  step(row src_index[i], actions[i], step size i)        (index NULL: row i)
+ * with the step rules of (kind, dynamic), no auto-reset, and no change to the episodic sums: the running return, episode
+ * counter, plan row and total_brick travel with the state; SNAC_FLAG_NEED_RESET records `done`.
+ *   actions / step_size   int8[m] or NULL = counter RNG stream 0 keyed by (env_id_base + i, t)
+ *   obs                   [m][obs_dim] (obs_dtype) or NULL;  reward float[m] / done uint8[m] or NULL
+ * Indices are clamped into the pool.  A destination row must not be the source row of a DIFFERENT edge of the same call
+ * (dst_index[i] == src_index[i], i.e. in place, is fine); several edges may share a source. */
+int snac_transition(const snac_env_desc* desc, const snac_state* st, int32_t m, const int32_t* src_index,
+                    const int32_t* dst_index, uint32_t t, const int8_t* actions, const int8_t* step_size, void* obs,
+                    float* reward, uint8_t* done, void* stream);
+
+/* (position, environment_memory, count_brick, count_step) tuples of the reference (the `state` of the MCTS variants,
+ * Env/2D/DMP_ENV_2D_dynamic_MCTS.py:88-91) -> pool rows dst_index[i] (NULL: row i); the inverse of snac_export_grid plus
+ * the header.  position int32[m][2] (row, col; 1D: position, ignored), count_brick / count_step int32[m],
+ * plan_idx int32[m] or NULL (the row keeps its plan), total_brick int32[m] or NULL (plan_tb of the plan row),
+ * environment_memory double[m][env_height][env_width].  The running return restarts at 0; values are clamped into the
+ * ranges the kernels index with. */
+int snac_import_state(const snac_env_desc* desc, const snac_state* st, int32_t m, const int32_t* dst_index,
+                      const int32_t* position, const int32_t* count_brick, const int32_t* count_step,
+                      const int32_t* plan_idx, const int32_t* total_brick, const double* environment_memory, void* stream);
+
+/* equality_operator(o1, o2) (np.array_equal of two observations, Env/2D/DMP_ENV_2D_dynamic_MCTS.py:254-258; how
+ * script/MCTS/utils/mcts_Qvalue_dynamic.py:100-106 recognises an already-expanded child), for m pairs:
+ *     out[i] = all(obs_a[idx_a[i]] == obs_b[idx_b[i]])        (index NULL: row i; rows of obs_dim values, obs_dtype)
+ * rows_a / rows_b: number of rows of the two arrays (indices are clamped). */
+int snac_obs_equal(const snac_env_desc* desc, const void* obs_a, const int32_t* idx_a, int32_t rows_a, const void* obs_b,
+                   const int32_t* idx_b, int32_t rows_b, int32_t m, uint8_t* out, void* stream);
 
 #ifdef __cplusplus
 }

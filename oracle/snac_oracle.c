@@ -256,6 +256,31 @@ int orc_step(orc_env* e, int action, int k, double* obs, double* reward, int* do
     return 0;
 }
 
+/* transition(state, action) of the MCTS variants: step() restated on an explicit state tuple
+ * (Env/1D/DMP_Env_1D_dynamic_MCTS.py:82-139, Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175,
+ * Env/3D/DMP_simulator_3d_static_circle_MCTS.py:215-288, Env/3D/DMP_simulator_3d_dynamic_triangle_MCTS.py:195-277).
+ * gate_cb >= 0: the 3D dynamic class tests `self.count_brick >= self.total_brick` (:258) -- the brick count of the ENV
+ * object, not the one of the state; pass the env's count here.  src == dst is allowed. */
+int orc_transition(const orc_env* src, orc_env* dst, int action, int k, int gate_cb, double* obs, double* reward, int* done) {
+    int rc, tb;
+    if (dst != src) *dst = *src;
+    tb = dst->tb;
+    if (gate_cb >= 0 && dst->dim == 3 && dst->rules_dyn) dst->tb = (gate_cb >= tb) ? INT32_MIN : INT32_MAX;
+    rc = orc_step(dst, action, k, NULL, reward, done);
+    dst->tb = tb;
+    if (rc) return rc;
+    if (obs) orc_observe(dst, obs);
+    return 0;
+}
+
+/* load an explicit state: grid = the bordered environment_memory (H*W ints) */
+int orc_set_state(orc_env* e, const int32_t* grid, int r, int c, int cb, int cs) {
+    if (r < 0 || r >= (e->dim == 1 ? e->W : e->H) || c < 0 || c >= e->W) return -1;
+    for (int i = 0; i < e->H * e->W; ++i) e->grid[i] = grid[i];
+    e->pos[0] = r; e->pos[1] = c; e->cb = cb; e->cs = cs;
+    return 0;
+}
+
 /* IoU: 1D S1:138-151 / D1:121-133; 2D caller-side boolean IoU script/DQN/2d/DQN_2d_dynamic.py:63-71 and
  * D2:153-159; 3D S3:257-276 / D3:258-277 */
 double orc_iou(const orc_env* e) {
@@ -495,4 +520,46 @@ int orc_batch_rollout(orc_batch* b, int T, uint32_t t0, const int8_t* actions, c
 
 void orc_batch_iou(const orc_batch* b, double* out) {
     for (int i = 0; i < b->n; ++i) out[i] = orc_iou(&b->envs[i]);
+}
+
+/* m functional transitions on the batch used as a node pool (include/snac_hip.h snac_transition):
+ *   env[dst_index[i]] <- step(env[src_index[i]], actions[i], step size i),  NULL index = i.
+ * No auto-reset and no episodic sums (a search is not an episode); the running return and the episode counter travel
+ * with the state.  step_size / actions NULL: counter RNG stream 0 keyed by (env_id_base + i, t).  Every source is read
+ * before any destination is written.  Returns -1 on a bad action / index. */
+int orc_batch_transition(orc_batch* b, int m, const int32_t* src_index, const int32_t* dst_index, uint32_t t,
+                         const int8_t* actions, const int8_t* step_size, double* obs, float* reward, uint8_t* done) {
+    orc_env* tmp;
+    int32_t *ep, *ret;
+    uint8_t* nr;
+    int bad = 0;
+    if (m < 0) return -1;
+    for (int i = 0; i < m; ++i) {
+        int s = src_index ? src_index[i] : i, d = dst_index ? dst_index[i] : i;
+        if (s < 0 || s >= b->n || d < 0 || d >= b->n) return -1;
+    }
+    tmp = (orc_env*)malloc((size_t)(m ? m : 1) * sizeof(orc_env));
+    ep = (int32_t*)malloc((size_t)(m ? m : 1) * sizeof(int32_t));
+    ret = (int32_t*)malloc((size_t)(m ? m : 1) * sizeof(int32_t));
+    nr = (uint8_t*)malloc((size_t)(m ? m : 1));
+    for (int i = 0; i < m; ++i) {
+        int s = src_index ? src_index[i] : i;
+        double r = 0.0;
+        int d = 0, a, k;
+        uint32_t w = orc_rng_word(b->seed, 0u, (uint64_t)(b->env_id_base + i), t);
+        a = actions ? actions[i] : (int)(((w >> 16) * (uint32_t)b->num_actions) >> 16);
+        k = step_size ? step_size[i] : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+        if (orc_transition(&b->envs[s], &tmp[i], a, k, -1, obs ? obs + (size_t)i * b->obs_dim : NULL, &r, &d)) bad = 1;
+        ep[i] = b->episode[s];
+        ret[i] = b->ep_return[s] + (int32_t)r;
+        nr[i] = (uint8_t)d;
+        if (reward) reward[i] = (float)r;
+        if (done) done[i] = (uint8_t)d;
+    }
+    for (int i = 0; i < m; ++i) {
+        int d = dst_index ? dst_index[i] : i;
+        b->envs[d] = tmp[i]; b->episode[d] = ep[i]; b->ep_return[d] = ret[i]; b->need_reset[d] = nr[i];
+    }
+    free(tmp); free(ep); free(ret); free(nr);
+    return bad ? -1 : 0;
 }

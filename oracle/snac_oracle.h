@@ -54,6 +54,10 @@ int  orc_reset(orc_env* e, const int32_t* plan, int plan_idx, double* obs);
 /* returns 0, or -1 for an action outside [0, num_actions) (the reference raises after cs += 1) */
 int  orc_step(orc_env* e, int action, int k, double* obs, double* reward, int* done);
 void orc_observe(const orc_env* e, double* obs);
+/* MCTS variants: transition(state, action) = step() on an explicit state (src == dst allowed); gate_cb >= 0: the
+ * brick-limit test of the 3D dynamic class uses this count instead of the state's (see snac_oracle.c) */
+int  orc_transition(const orc_env* src, orc_env* dst, int action, int k, int gate_cb, double* obs, double* reward, int* done);
+int  orc_set_state(orc_env* e, const int32_t* grid, int r, int c, int cb, int cs);
 double orc_iou(const orc_env* e);
 /* static plans (Env/1D/DMP_Env_1D_static.py:34-55, Env/2D/DMP_Env_2D_static.py:31-52,
  * Env/3D/DMP_simulator_3d_static_circle.py:42-65) as integer tables; returns cell count or -1 */
@@ -98,6 +102,9 @@ int  orc_batch_step(orc_batch* b, uint32_t t, const int8_t* actions, const int8_
 int  orc_batch_rollout(orc_batch* b, int T, uint32_t t0, const int8_t* actions, const int8_t* step_size,
                        double* obs, int obs_last_only, float* reward, uint8_t* done, int nthreads);
 void orc_batch_iou(const orc_batch* b, double* out);
+/* m functional transitions, the batch as a node pool: env[dst_index[i]] <- step(env[src_index[i]], ...); NULL = i */
+int  orc_batch_transition(orc_batch* b, int m, const int32_t* src_index, const int32_t* dst_index, uint32_t t,
+                          const int8_t* actions, const int8_t* step_size, double* obs, float* reward, uint8_t* done);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,11 @@ def lib():
         L.orc_batch_rollout.argtypes = [C.POINTER(_Batch), C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_int]
         L.orc_batch_iou.argtypes = [C.POINTER(_Batch), C.c_void_p]
+        L.orc_transition.argtypes = [C.POINTER(_Env), C.POINTER(_Env), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.orc_set_state.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_batch_transition.argtypes = [C.POINTER(_Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -129,6 +134,27 @@ class OracleEnv:
 
     def iou(self):
         return lib().orc_iou(C.byref(self.e))
+
+    def set_state(self, grid, pos, cb, cs):
+        """Load an explicit (position, environment_memory, count_brick, count_step) tuple (after reset(): the plan stays)."""
+        g = np.ascontiguousarray(np.asarray(grid).reshape(-1), np.int32)
+        assert g.size == self.e.H * self.e.W
+        r, c = (int(pos), 0) if np.ndim(pos) == 0 else (int(pos[0]), int(pos[1]))
+        if lib().orc_set_state(C.byref(self.e), _ptr(g), r, c, int(cb), int(cs)):
+            raise ValueError("bad position")
+        return self
+
+    def transition(self, action, k, gate_cb=-1, inplace=False):
+        """MCTS transition(state, action): -> (new OracleEnv, obs, reward, done); this env is left untouched unless inplace."""
+        dst = self
+        if not inplace:
+            dst = OracleEnv.__new__(OracleEnv)
+            dst.e, dst.obs_dim = _Env(), self.obs_dim
+        obs = np.zeros(self.obs_dim, np.float64)
+        r, d = C.c_double(0), C.c_int(0)
+        if lib().orc_transition(C.byref(self.e), C.byref(dst.e), int(action), int(k), int(gate_cb), _ptr(obs), C.byref(r), C.byref(d)):
+            raise ValueError("bad action %d" % action)
+        return dst, obs, r.value, bool(d.value)
 
     @property
     def grid(self):
@@ -194,6 +220,34 @@ class OracleBatch:
         out = np.zeros(self.n, np.float64)
         lib().orc_batch_iou(self.b, _ptr(out))
         return out
+
+    def transition(self, actions, step_size=None, src=None, dst=None, t=0, want_obs=True):
+        """m functional transitions with the batch as node pool: env[dst[i]] <- step(env[src[i]], actions[i], k_i)."""
+        m = len(src) if actions is None else len(actions)
+        a = None if actions is None else np.ascontiguousarray(actions, np.int8)
+        k = None if step_size is None else np.ascontiguousarray(step_size, np.int8)
+        si = None if src is None else np.ascontiguousarray(src, np.int32)
+        di = None if dst is None else np.ascontiguousarray(dst, np.int32)
+        obs = np.zeros((m, self.obs_dim), np.float64) if want_obs else None
+        rew = np.zeros(m, np.float32)
+        done = np.zeros(m, np.uint8)
+        if lib().orc_batch_transition(self.b, m, _ptr(si), _ptr(di), t, _ptr(a), _ptr(k), _ptr(obs), _ptr(rew), _ptr(done)):
+            raise ValueError("bad action or index")
+        return obs, rew, done
+
+    def set_state(self, i, grid, pos, cb, cs, plan_idx=None):
+        """Load a reference-format state into env i (plan_idx: also switch the env to that plan row, as a reset would)."""
+        e = self.b.contents.envs[i]
+        if plan_idx is not None:
+            lib().orc_reset(C.byref(e), _ptr(self.plans[plan_idx]), int(plan_idx), None)
+            if self.b.contents.episode[i] < 0:
+                self.b.contents.episode[i] = 0
+        g = np.ascontiguousarray(np.asarray(grid).reshape(-1), np.int32)
+        r, c = (int(pos), 0) if np.ndim(pos) == 0 else (int(pos[0]), int(pos[1]))
+        if lib().orc_set_state(C.byref(e), _ptr(g), r, c, int(cb), int(cs)):
+            raise ValueError("bad position")
+        self.b.contents.ep_return[i] = 0
+        self.b.contents.need_reset[i] = 0
 
     def _arr(self, name, dtype):
         return np.ctypeslib.as_array(getattr(self.b.contents, name), shape=(self.n,)).astype(dtype, copy=True)

@@ -10,14 +10,15 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SNAC_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 ENV_1D, ENV_2D, ENV_3D = 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 OBS_NONE, OBS_ALL, OBS_LAST = 0, 1, 2
 FLAG_NEED_RESET = 1
 
 EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_reset", "snac_step", "snac_rollout",
-           "snac_rollout_rec", "snac_replay_gather", "snac_observe", "snac_iou", "snac_export_grid")
+           "snac_rollout_rec", "snac_replay_gather", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
+           "snac_import_state", "snac_obs_equal")
 
 
 class Sizes(C.Structure):
@@ -81,6 +82,9 @@ def lib():
         L.snac_observe.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
         L.snac_iou.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
         L.snac_export_grid.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
+        L.snac_transition.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
+        L.snac_import_state.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.snac_obs_equal.argtypes = [C.POINTER(EnvDesc), vp, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
         for n in EXPORTS:
             getattr(L, n)
         if L.snac_version() != ABI_VERSION:

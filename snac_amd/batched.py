@@ -234,6 +234,111 @@ class BatchedDMPEnv:
         child._was_reset = self._was_reset
         return child
 
+    # ---- tree search: the batch as a node pool (MCTS variants of the reference) ----------------------
+    def _index(self, x, m, what):
+        if x is None:
+            return None
+        x = torch.as_tensor(x, device=self.device)
+        if tuple(x.shape) != (m,):
+            raise ValueError("%s must have shape (%d,)" % (what, m))
+        if m and (int(x.min()) < 0 or int(x.max()) >= self.num_envs):
+            raise ValueError("%s out of range" % what)
+        return x.to(torch.int32).contiguous()
+
+    def transition(self, actions, step_size=None, src=None, dst=None, t=0, want_obs=True):
+        """m functional transitions (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175 `transition(state, action)`), the batch used
+        as a pool of tree nodes: row dst[i] <- step(row src[i], actions[i], step_size[i]); src / dst None = row i.  No
+        auto-reset, the episodic sums are untouched.  step_size None: counter RNG keyed by (env_id_base + i, t).  A dst row
+        must not be the src row of another edge of the same call.  Returns (obs [m, D], reward [m], done [m])."""
+        if not self._was_reset:
+            raise _lib.SnacError("transition() before reset() / import_states()")
+        if actions is None:
+            raise ValueError("actions are required")
+        a = torch.as_tensor(actions, device=self.device) if not torch.is_tensor(actions) else actions.to(self.device)
+        m = int(a.numel())
+        a = self._i8(a.reshape(-1), (m,), "actions")
+        k = self._i8(step_size, (m,), "step_size")
+        si, di = self._index(src, m, "src"), self._index(dst, m, "dst")
+        if (si is None or di is None) and m > self.num_envs:
+            raise ValueError("more transitions than pool rows")
+        if si is not None or di is not None:
+            s_ = si if si is not None else torch.arange(m, device=self.device, dtype=torch.int32)
+            d_ = di if di is not None else torch.arange(m, device=self.device, dtype=torch.int32)
+            clash = torch.isin(d_, s_[s_ != d_]) if m else torch.zeros(0, dtype=torch.bool)
+            if m and (bool(clash.any()) or int(torch.unique(d_).numel()) != m):
+                raise ValueError("dst rows must be distinct and must not be the src row of another edge")
+        obs = torch.empty((m, self.obs_dim), dtype=self.obs_dtype, device=self.device) if want_obs else None
+        reward = torch.empty((m,), dtype=torch.float32, device=self.device)
+        done = torch.empty((m,), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_transition(C.byref(self._desc), C.byref(self._state), m, _ptr(si), _ptr(di), int(t) & 0xFFFFFFFF,
+                                                 _ptr(a), _ptr(k), _ptr(obs), _ptr(reward), _ptr(done), self._stream()))
+        return obs, reward, done.view(torch.bool)
+
+    def import_states(self, position, count_brick, count_step, environment_memory, plan_idx=None, total_brick=None, dst=None):
+        """Load states in the reference's own format -- the (position, environment_memory, count_brick, count_step) tuples
+        of the MCTS variants -- into pool rows dst (None: rows 0..m-1).  position [m, 2] (1D: [m]), environment_memory
+        [m, H, W] float64 with its frame; plan_idx None keeps each row's plan; total_brick None = that of the plan row."""
+        sz = self.sizes
+        mem = torch.as_tensor(environment_memory, device=self.device).to(torch.float64)
+        mem = mem.reshape(-1, sz.env_height, sz.env_width).contiguous()
+        m = int(mem.shape[0])
+
+        def i32(x, shape, what):
+            if x is None:
+                return None
+            x = torch.as_tensor(x, device=self.device)
+            if tuple(x.shape) != shape:
+                raise ValueError("%s must have shape %s" % (what, shape))
+            return x.to(torch.int32).contiguous()
+
+        pos = torch.as_tensor(position, device=self.device).to(torch.int32)
+        if self.kind == 1:
+            pos = torch.stack([pos.reshape(m), torch.zeros(m, dtype=torch.int32, device=self.device)], dim=1)
+        pos = i32(pos, (m, 2), "position")
+        lo, hi = sz.half_window, sz.half_window + sz.plan_width - 1
+        if m and (int(pos[:, 0].min()) < lo or int(pos[:, 0].max()) > hi or
+                  (self.kind != 1 and (int(pos[:, 1].min()) < lo or int(pos[:, 1].max()) > hi))):
+            raise ValueError("position outside the plan area")
+        cb, cs = i32(count_brick, (m,), "count_brick"), i32(count_step, (m,), "count_step")
+        p, tb, di = i32(plan_idx, (m,), "plan_idx"), i32(total_brick, (m,), "total_brick"), self._index(dst, m, "dst")
+        if p is None and not self._was_reset:
+            raise _lib.SnacError("import_states() without plan_idx before reset()")
+        if p is not None and m and (int(p.min()) < 0 or int(p.max()) >= self.num_plans):
+            raise ValueError("plan_idx out of range")
+        if di is None and m > self.num_envs:
+            raise ValueError("more states than pool rows")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_import_state(C.byref(self._desc), C.byref(self._state), m, _ptr(di), _ptr(pos), _ptr(cb),
+                                                   _ptr(cs), _ptr(p), _ptr(tb), _ptr(mem), self._stream()))
+        self._was_reset = True
+
+    def obs_equal(self, obs_a, obs_b, idx_a=None, idx_b=None):
+        """equality_operator (np.array_equal of two observations, Env/2D/DMP_ENV_2D_dynamic_MCTS.py:254-258) for m pairs of
+        rows: bool [m] = all(obs_a[idx_a[i]] == obs_b[idx_b[i]]); index None = row i."""
+        for o in (obs_a, obs_b):
+            if o.dim() != 2 or o.shape[1] != self.obs_dim or o.dtype != self.obs_dtype or o.device != self.device or not o.is_contiguous():
+                raise ValueError("observations must be contiguous [rows, %d] %s tensors on %s" % (self.obs_dim, self.obs_dtype, self.device))
+        ra, rb = int(obs_a.shape[0]), int(obs_b.shape[0])
+        m = len(idx_a) if idx_a is not None else (len(idx_b) if idx_b is not None else min(ra, rb))
+
+        def idx(x, rows):
+            if x is None:
+                if m > rows:
+                    raise ValueError("more pairs than rows")
+                return None
+            x = torch.as_tensor(x, device=self.device)
+            if tuple(x.shape) != (m,) or (m and (int(x.min()) < 0 or int(x.max()) >= rows)):
+                raise ValueError("bad row index")
+            return x.to(torch.int32).contiguous()
+
+        ia, ib = idx(idx_a, ra), idx(idx_b, rb)
+        out = torch.empty((m,), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_obs_equal(C.byref(self._desc), _ptr(obs_a), _ptr(ia), ra, _ptr(obs_b), _ptr(ib), rb, m,
+                                                _ptr(out), self._stream()))
+        return out.view(torch.bool)
+
     def observe(self):
         if not self._was_reset:
             raise _lib.SnacError("observe() before reset()")

@@ -76,6 +76,10 @@ struct KArgs {
     int8_t* step_size_out;
     int16_t* plan_idx_out;
     uint8_t* first_out;
+    // snac_transition only: the state arrays are a node pool of `pool` rows; n = number of transitions
+    int32_t pool;
+    const int32_t* src_index;  // row read by transition i (NULL: i)
+    const int32_t* dst_index;  // row written by transition i (NULL: i)
     // aux kernel only
     int32_t aux_op;            // AUX_*
     const uint8_t* mask;
@@ -85,6 +89,11 @@ struct KArgs {
 enum { AUX_RESET = 0, AUX_OBSERVE = 1, AUX_IOU = 2 };
 
 constexpr double FX40 = 1099511627776.0;  // 2^40
+
+// state row of tile element i: identity for the env batch, a clamped gather / scatter index for snac_transition
+__device__ __forceinline__ size_t row_of(const int32_t* idx, int pool, int i) {
+    return idx ? (size_t)min(max(idx[i], 0), pool - 1) : (size_t)i;
+}
 
 // per-lane env scalars (one env per lane in phase 1)
 struct Lane {
@@ -150,21 +159,21 @@ struct K2D {
         const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
         return squeeze16((lo >> 6) & 0x01555555u) | (squeeze16(hi & 0x1555u) << 13);
     }
-    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
         uint64_t* c = cells(lds);
         for (int i = lane; i < 3 * RS; i += 64) { c[i] = 0x000FFFFFFFFFFFFFull; c[23 * RS + i] = 0x000FFFFFFFFFFFFFull; }
-        const uint32_t* src = (const uint32_t*)a.grid + (size_t)env0 * GE;
+        const uint32_t* src = (const uint32_t*)a.grid;
         for (int i = lane; i < nenv * GE; i += 64) {
             const int e = i / GE, row = i - e * GE;
-            c[(row + 3) * RS + e] = encode_row(src[i]);
+            c[(row + 3) * RS + e] = encode_row(src[row_of(idx, a.pool, env0 + e) * GE + row]);
         }
     }
-    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
         const uint64_t* c = cells(lds);
-        uint32_t* dst = (uint32_t*)a.grid + (size_t)env0 * GE;
+        uint32_t* dst = (uint32_t*)a.grid;
         for (int i = lane; i < nenv * GE; i += 64) {
             const int e = i / GE, row = i - e * GE;
-            dst[i] = decode_row(c[(row + 3) * RS + e]);
+            dst[row_of(idx, a.pool, env0 + e) * GE + row] = decode_row(c[(row + 3) * RS + e]);
         }
     }
     __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
@@ -231,21 +240,21 @@ struct K3D {
     __device__ static int16_t* hmap(uint32_t* lds) { return (int16_t*)lds; }
     __device__ static int16_t* plan(uint32_t* lds) { return (int16_t*)(lds + P_OFF); }
 
-    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
         for (int i = lane; i < E * ES / 2; i += 64) lds[i] = 0xFFFFFFFFu;            // everything frame (-1) ...
-        const int16_t* src = (const int16_t*)a.grid + (size_t)env0 * GE;
+        const int16_t* src = (const int16_t*)a.grid;
         int16_t* h = hmap(lds);
         for (int i = lane; i < nenv * GE; i += 64) {                                  // ... then the interiors
             const int e = i / GE, cell = i - e * GE, r = cell / 20, c = cell - r * 20;
-            h[e * ES + (r + 3) * 26 + c + 3] = src[i];
+            h[e * ES + (r + 3) * 26 + c + 3] = src[row_of(idx, a.pool, env0 + e) * GE + cell];
         }
     }
-    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
-        int16_t* dst = (int16_t*)a.grid + (size_t)env0 * GE;
+    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
+        int16_t* dst = (int16_t*)a.grid;
         const int16_t* h = hmap(lds);
         for (int i = lane; i < nenv * GE; i += 64) {
             const int e = i / GE, cell = i - e * GE, r = cell / 20, c = cell - r * 20;
-            dst[i] = h[e * ES + (r + 3) * 26 + c + 3];
+            dst[row_of(idx, a.pool, env0 + e) * GE + cell] = h[e * ES + (r + 3) * 26 + c + 3];
         }
     }
     __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
@@ -345,21 +354,21 @@ struct K1D {
     __device__ static double* sc(uint32_t* lds) { return (double*)(lds + SC_OFF); }
     __device__ static int* pos(uint32_t* lds) { return (int*)(lds + SC_OFF + 4 * E); }
 
-    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
+    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
         for (int i = lane; i < E * ES / 2; i += 64) lds[i] = 0xFFFFFFFFu;
-        const int16_t* src = (const int16_t*)a.grid + (size_t)env0 * GE;
+        const int16_t* src = (const int16_t*)a.grid;
         int16_t* h = hmap(lds);
         for (int i = lane; i < nenv * GE; i += 64) {
             const int e = i / GE, cell = i - e * GE;
-            if (cell < 30) h[e * ES + cell + 2] = src[i];
+            if (cell < 30) h[e * ES + cell + 2] = src[row_of(idx, a.pool, env0 + e) * GE + cell];
         }
     }
-    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane) {
-        int16_t* dst = (int16_t*)a.grid + (size_t)env0 * GE;
+    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
+        int16_t* dst = (int16_t*)a.grid;
         const int16_t* h = hmap(lds);
         for (int i = lane; i < nenv * GE; i += 64) {
             const int e = i / GE, cell = i - e * GE;
-            dst[i] = cell < 30 ? h[e * ES + cell + 2] : (int16_t)0;
+            dst[row_of(idx, a.pool, env0 + e) * GE + cell] = cell < 30 ? h[e * ES + cell + 2] : (int16_t)0;
         }
     }
     __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
@@ -577,6 +586,46 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
     }
 }
 
+// transition(state, action) of the MCTS variants (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175 and the eight sibling files;
+// caller: script/MCTS/utils/mcts_Qvalue_dynamic.py:88,118): ONE step of the same K::step on an explicit state, batched over
+// a.n tree edges.  The state arrays are a node pool; edge i reads row src_index[i] and writes row dst_index[i] (out of
+// place), the observation / reward / done rows are per edge.  No auto-reset, no episodic sums: a search is not an episode.
+template <class K, typename OT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
+    constexpr int E = K::E;
+    const int lane = threadIdx.x & 63;
+    const int tile = (int)blockIdx.x * WPB + (int)(threadIdx.x >> 6);
+    const int env0 = __builtin_amdgcn_readfirstlane(tile * E);
+    if (env0 >= a.n) return;
+    const int nenv = min(E, a.n - env0);
+    const bool active = lane < nenv;
+    const int edge = env0 + (active ? lane : 0);
+    uint32_t* lds = wave_lds<K, WPB>();
+    Lane s;
+    s.clear();
+    s.r = 3; s.c = 3;
+    int episode = 0;
+    const size_t srow = row_of(a.src_index, a.pool, edge), drow = row_of(a.dst_index, a.pool, edge);
+    if (active) { s.unpack(a.hdr[srow]); episode = a.episode[srow]; }
+    K::load_grid(lds, a, env0, nenv, lane, a.src_index);
+    for (int e = 0; e < nenv; ++e) K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane);
+    int reward = 0;
+    bool done = false;
+    if (active) {
+        const uint32_t w = rng_word(env_keys(a.key_step, (uint64_t)(a.env_id_base + edge)), a.t0);
+        const int act = a.actions ? (int)a.actions[edge] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
+        const int k = a.step_size ? (int)a.step_size[edge] : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+        K::step(lds, s, act, k, a.total_step, lane, reward, done);
+        s.ep_ret += reward;
+        s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+        if (a.reward) a.reward[edge] = (float)reward;
+        if (a.done) a.done[edge] = done ? 1 : 0;
+    }
+    if (a.obs) emit_obs<K, OT>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s, a.total_step, lane);
+    K::store_grid(lds, a, env0, nenv, lane, a.dst_index);
+    if (active) { a.hdr[drow] = s.pack(); a.episode[drow] = episode; }
+}
+
 // reset(mask, plan_idx_in) / observe / iou on the same tile machinery
 template <class K, typename OT, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
@@ -638,6 +687,86 @@ __global__ void k_export(const KArgs a, long long total) {
         }
         a.out_f64[i] = (double)v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// states in the reference's own format -> packed records: the inverse of k_export plus the header.  The MCTS variants hand
+// (position, environment_memory, count_brick, count_step) tuples around (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:88-91); this is
+// how such a tuple enters the node pool.  One wave per state.  Values are clamped into the ranges the step kernels index with.
+struct IArgs {
+    int32_t m, pool, num_plans;
+    const int32_t* dst_index;
+    const int32_t* pos;        // [m][2] (row, col); 1D: (position, ignored)
+    const int32_t* cb;
+    const int32_t* cs;
+    const int32_t* plan_idx;   // NULL: the destination row keeps its plan
+    const int32_t* tb;         // NULL: total_brick of the plan row (plan_tb)
+    const double* mem;         // [m][H][W] environment_memory with its frame
+    int4* hdr;
+    int32_t* episode;
+    void* grid;
+    const void* plans;
+    const int16_t* plan_tb;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_import(const IArgs g) {
+    constexpr int CELLS = KIND == 1 ? 34 : 676, LO = KIND == 1 ? 2 : 3, HI = KIND == 1 ? 31 : 22;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (i >= g.m) return;
+    const size_t drow = row_of(g.dst_index, g.pool, i);
+    const double* src = g.mem + (size_t)i * CELLS;
+    Lane s;
+    s.unpack(g.hdr[drow]);
+    s.pidx = min(max(g.plan_idx ? g.plan_idx[i] : s.pidx, 0), g.num_plans - 1);
+    s.tb = g.tb ? min(max(g.tb[i], -32768), 32767) : (int)g.plan_tb[s.pidx];
+    int cross = 0;
+    if (KIND == 1) {
+        if (lane < 32) ((int16_t*)g.grid)[drow * 32 + lane] = lane < 30 ? (int16_t)min(max(llrint(src[lane + 2]), 0ll), 32767ll) : (int16_t)0;
+    } else if (KIND == 2) {
+        for (int row = 0; row < 20; ++row) {
+            const bool on = lane < 20 && src[(row + 3) * 26 + 3 + lane] > 0.0;
+            const unsigned long long bits = __ballot(on);
+            if (lane == 0) ((uint32_t*)g.grid)[drow * 20 + row] = (uint32_t)bits & 0xFFFFFu;
+        }
+    } else {
+        const int16_t* pl = (const int16_t*)g.plans + (size_t)s.pidx * 400;
+        for (int cell = lane; cell < 400; cell += 64) {
+            const int r = cell / 20, c = cell - r * 20;
+            const int v = (int)min(max(llrint(src[(r + 3) * 26 + c + 3]), 0ll), 32767ll);
+            ((int16_t*)g.grid)[drow * 400 + cell] = (int16_t)v;
+            cross += min(v, (int)pl[cell]);
+        }
+        for (int off = 32; off > 0; off >>= 1) cross += __shfl_xor(cross, off);
+    }
+    if (lane == 0) {
+        s.r = min(max(g.pos[2 * i], LO), HI);
+        s.c = KIND == 1 ? 0 : min(max(g.pos[2 * i + 1], LO), HI);
+        s.flags = 0;
+        s.cb = min(max(g.cb[i], 0), 32767);
+        s.cs = min(max(g.cs[i], 0), 32000);
+        s.ep_ret = 0;
+        s.cross = min(cross, 32767);
+        g.hdr[drow] = s.pack();
+        if (g.episode[drow] < 0) g.episode[drow] = 0;
+    }
+}
+
+// equality_operator(o1, o2) of the MCTS variants (np.array_equal on two observations,
+// Env/2D/DMP_ENV_2D_dynamic_MCTS.py:254-258; used to recognise an already-expanded child,
+// script/MCTS/utils/mcts_Qvalue_dynamic.py:100-106): out[i] = all(a[ia[i]] == b[ib[i]]).  One wave per pair.
+template <typename OT>
+__global__ __launch_bounds__(256) void k_equal(const OT* a, const int32_t* ia, int rows_a, const OT* b, const int32_t* ib, int rows_b,
+                                               int m, int D, uint8_t* out) {
+    const int lane = threadIdx.x & 63;
+    const int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (i >= m) return;
+    const OT* pa = a + row_of(ia, rows_a, i) * D;
+    const OT* pb = b + row_of(ib, rows_b, i) * D;
+    const bool differ = lane < D && !(pa[lane] == pb[lane]);
+    const unsigned long long any = __ballot(differ);
+    if (lane == 0) out[i] = any ? 0 : 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -721,13 +850,14 @@ KArgs make_args(const snac_env_desc* d, const snac_state* st) {
     return a;
 }
 
-enum Op { OP_ROLLOUT, OP_AUX };
+enum Op { OP_ROLLOUT, OP_AUX, OP_TRANSITION };
 
 template <class K, typename OT, int WPB>
 void launch_k(Op op, const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + K::E - 1) / K::E;
     const dim3 grid((unsigned)((tiles + WPB - 1) / WPB)), block(WPB * 64);
     if (op == OP_ROLLOUT) hipLaunchKernelGGL((k_rollout<K, OT, WPB>), grid, block, 0, s, a);
+    else if (op == OP_TRANSITION) hipLaunchKernelGGL((k_transition<K, OT, WPB>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_aux<K, OT, WPB>), grid, block, 0, s, a);
 }
 
@@ -757,7 +887,7 @@ void launch_tile(Op op, bool dyn, int E, int obs_dtype, const KArgs& a, hipStrea
 int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool dyn = d->dynamic != 0;
-    const int E = pick_tile(d->kind, d->num_envs);
+    const int E = pick_tile(d->kind, a.n);
     switch (d->kind) {
         case SNAC_ENV_1D: launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D: launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
@@ -858,6 +988,62 @@ int snac_step(const snac_env_desc* d, const snac_state* st, uint32_t t, const in
     a.T = 1; a.t0 = t; a.auto_reset = auto_reset ? 1 : 0; a.obs_mode = obs ? SNAC_OBS_ALL : SNAC_OBS_NONE;
     a.actions = actions; a.step_size = step_size; a.obs = obs; a.reward = reward; a.done = done;
     return launch(OP_ROLLOUT, d, a, stream);
+}
+
+int snac_transition(const snac_env_desc* d, const snac_state* st, int32_t m, const int32_t* src_index, const int32_t* dst_index,
+                    uint32_t t, const int8_t* actions, const int8_t* step_size, void* obs, float* reward, uint8_t* done,
+                    void* stream) {
+    if (int rc = check_common(d, st)) return rc;
+    if (m < 0) return fail(SNAC_ERR_ARG, "m must be >= 0");
+    if (!src_index && !dst_index && m > d->num_envs) return fail(SNAC_ERR_ARG, "m exceeds the pool (num_envs)");
+    if (m == 0) return SNAC_OK;
+    KArgs a = make_args(d, st);
+    a.pool = d->num_envs; a.n = m; a.src_index = src_index; a.dst_index = dst_index;
+    a.T = 1; a.t0 = t; a.actions = actions; a.step_size = step_size; a.obs = obs; a.reward = reward; a.done = done;
+    return launch(OP_TRANSITION, d, a, stream);
+}
+
+int snac_import_state(const snac_env_desc* d, const snac_state* st, int32_t m, const int32_t* dst_index, const int32_t* position,
+                      const int32_t* count_brick, const int32_t* count_step, const int32_t* plan_idx, const int32_t* total_brick,
+                      const double* environment_memory, void* stream) {
+    if (int rc = check_common(d, st)) return rc;
+    if (m < 0) return fail(SNAC_ERR_ARG, "m must be >= 0");
+    if (!dst_index && m > d->num_envs) return fail(SNAC_ERR_ARG, "m exceeds the pool (num_envs)");
+    if (!position || !count_brick || !count_step || !environment_memory) return fail(SNAC_ERR_ARG, "null pointer");
+    if (m == 0) return SNAC_OK;
+    IArgs g;
+    g.m = m; g.pool = d->num_envs; g.num_plans = d->num_plans; g.dst_index = dst_index; g.pos = position; g.cb = count_brick;
+    g.cs = count_step; g.plan_idx = plan_idx; g.tb = total_brick; g.mem = environment_memory; g.hdr = (int4*)st->hdr; g.episode = st->episode;
+    g.grid = st->grid; g.plans = st->plans; g.plan_tb = st->plan_tb;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((m + 3) / 4)), block(256);
+    if (d->kind == SNAC_ENV_1D) hipLaunchKernelGGL((k_import<1>), grid, block, 0, s, g);
+    else if (d->kind == SNAC_ENV_2D) hipLaunchKernelGGL((k_import<2>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((k_import<3>), grid, block, 0, s, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "import launch");
+    return SNAC_OK;
+}
+
+int snac_obs_equal(const snac_env_desc* d, const void* obs_a, const int32_t* idx_a, int32_t rows_a, const void* obs_b,
+                   const int32_t* idx_b, int32_t rows_b, int32_t m, uint8_t* out, void* stream) {
+    if (!d) return fail(SNAC_ERR_ARG, "null desc");
+    if (d->kind < SNAC_ENV_1D || d->kind > SNAC_ENV_3D) return fail(SNAC_ERR_ARG, "unknown env kind");
+    if (d->obs_dtype != SNAC_OBS_F64 && d->obs_dtype != SNAC_OBS_F32) return fail(SNAC_ERR_ARG, "unknown obs_dtype");
+    if (m < 0 || rows_a <= 0 || rows_b <= 0) return fail(SNAC_ERR_ARG, "m must be >= 0 and rows_a / rows_b positive");
+    if ((!idx_a && m > rows_a) || (!idx_b && m > rows_b)) return fail(SNAC_ERR_ARG, "m exceeds the number of rows");
+    if (!obs_a || !obs_b || !out) return fail(SNAC_ERR_ARG, "null pointer");
+    if (m == 0) return SNAC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = d->kind == SNAC_ENV_1D ? 7 : 51;
+    const dim3 grid((unsigned)((m + 3) / 4)), block(256);
+    if (d->obs_dtype == SNAC_OBS_F32)
+        hipLaunchKernelGGL((k_equal<float>), grid, block, 0, s, (const float*)obs_a, idx_a, rows_a, (const float*)obs_b, idx_b, rows_b, m, D, out);
+    else
+        hipLaunchKernelGGL((k_equal<double>), grid, block, 0, s, (const double*)obs_a, idx_a, rows_a, (const double*)obs_b, idx_b, rows_b, m, D, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "equal launch");
+    return SNAC_OK;
 }
 
 int snac_observe(const snac_env_desc* d, const snac_state* st, void* obs, void* stream) {

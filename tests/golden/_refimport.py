@@ -30,7 +30,23 @@ def install_gym_stub():
 
     gym.Env = Env
     gym.Wrapper = Wrapper
+    # the MCTS variants also do `from gym import spaces` and build spaces.Discrete(action_dim)
+    spaces = types.ModuleType("gym.spaces")
+
+    class Discrete(object):
+        def __init__(self, n):
+            self.n = n
+
+    spaces.Discrete = Discrete
+    gym.spaces = spaces
     sys.modules["gym"] = gym
+    sys.modules["gym.spaces"] = spaces
+
+
+def install_cv2_stub():
+    """Env/2D/DMP_ENV_2D_dynamic_MCTS.py imports cv2 at module level; only its unused create_plan() calls into it."""
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
 
 
 def ref_available():

@@ -1,0 +1,327 @@
+"""GPU: tree-search entry points (snac_transition, snac_import_state, snac_obs_equal) against the CPU oracle, and the nine
+MCTS drop-in classes replayed against the goldens recorded from the reference (tests/golden/make_golden_mcts.py)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+import test_mcts as tm
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [(1, False), (1, True), (2, False), (2, True), (3, False), (3, True)]
+
+
+def _tag(dim, dyn):
+    return ("dense_train" if dim > 1 else "sin_train") if dyn else ("p1" if dim == 3 else "p0")
+
+
+def _same_state(env, orc, rows=None):
+    st = orc.state()
+    rows = np.arange(orc.n) if rows is None else np.asarray(rows)
+    mem = env.environment_memory().cpu().numpy().reshape(env.num_envs, -1)
+    assert np.array_equal(mem[rows], st["grid"][rows].astype(np.float64))
+    pos = env.position.cpu().numpy()
+    assert np.array_equal(pos[rows, 0], st["pos"][rows, 0])
+    if env.kind != 1:
+        assert np.array_equal(pos[rows, 1], st["pos"][rows, 1])
+    assert np.array_equal(env.count_brick.cpu().numpy()[rows], st["cb"][rows])
+    assert np.array_equal(env.count_step.cpu().numpy()[rows], st["cs"][rows])
+    assert np.array_equal(env.total_brick.cpu().numpy()[rows], st["tb"][rows])
+    assert np.array_equal(env.plan_idx.cpu().numpy()[rows], st["plan_idx"][rows])
+    assert np.array_equal(env.episode_return.cpu().numpy()[rows], st["ep_return"][rows])
+    assert np.array_equal(env.need_reset.cpu().numpy()[rows].astype(np.uint8), st["need_reset"][rows])
+    assert np.array_equal(env.episode.cpu().numpy()[rows], st["episode"][rows])
+
+
+@pytest.mark.parametrize("dim,dyn", CONFIGS)
+def test_transition_matches_oracle(dim, dyn):
+    """A search-shaped workload: roots from a rollout, then waves of expansions (every action of a sampled parent written to
+    fresh pool rows), in-place steps on a subset, explicit and counter-RNG step sizes, float32 observations too."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(dim, dyn, _tag(dim, dyn))
+    full = table.reshape((-1, 30) if dim == 1 else (-1, 26, 26))
+    pool, roots, seed = 3000, 200, 11
+    env = BatchedDMPEnv(dim, dyn, pool, plans=full, seed=seed)
+    orc = helpers.oracle().OracleBatch(dim, dyn, pool, table, seed=seed)
+    env.reset(); orc.reset()
+    env.rollout(23, obs=None); orc.rollout(23, obs=None)
+    _same_state(env, orc)
+    stats0 = env.episodic_stats()
+    rng = np.random.default_rng(100 + dim)
+    A = env.num_actions
+    used = roots
+    for wave in range(6):
+        parents = rng.integers(0, used, 40)
+        src = np.repeat(parents, A).astype(np.int32)
+        acts = np.tile(np.arange(A), len(parents)).astype(np.int8)
+        m = len(src)
+        dst = (used + np.arange(m)).astype(np.int32)
+        ks = rng.integers(1, 4, m).astype(np.int8) if wave % 2 == 0 else None
+        o, r, d = env.transition(acts, ks, src, dst, t=wave)
+        oo, ro, do = orc.transition(acts, ks, src, dst, t=wave)
+        assert o.cpu().numpy().tobytes() == oo.tobytes(), (dim, dyn, wave)
+        assert r.cpu().numpy().tobytes() == ro.tobytes() and np.array_equal(d.cpu().numpy().astype(np.uint8), do)
+        used += m
+        # a few in-place steps (dst == src) with a bad action mixed in
+        rows = rng.choice(used, 64, replace=False).astype(np.int32)
+        acts2 = rng.integers(0, A, 64).astype(np.int8)
+        o, r, d = env.transition(acts2, None, rows, rows, t=1000 + wave)
+        oo, ro, do = orc.transition(acts2, None, rows, rows, t=1000 + wave)
+        assert o.cpu().numpy().tobytes() == oo.tobytes() and r.cpu().numpy().tobytes() == ro.tobytes()
+        assert np.array_equal(d.cpu().numpy().astype(np.uint8), do)
+    assert used <= pool
+    _same_state(env, orc)
+    assert env.episodic_stats() == stats0                       # a search is not an episode
+    # identity form (no index arrays) on the first m rows, no observation wanted
+    acts = rng.integers(0, A, 500).astype(np.int8)
+    o, r, d = env.transition(acts, want_obs=False)
+    _, ro, do = orc.transition(acts)
+    assert o is None and r.cpu().numpy().tobytes() == ro.tobytes() and np.array_equal(d.cpu().numpy().astype(np.uint8), do)
+    _same_state(env, orc)
+    # the pool keeps working as an env batch afterwards
+    oe, re_, de = env.step(auto_reset=True)
+    oo, ro, do = orc.step(env.t - 1, auto_reset=True)
+    assert oe.cpu().numpy().tobytes() == oo.tobytes() and re_.cpu().numpy().tobytes() == ro.tobytes()
+    with pytest.raises(ValueError):
+        env.transition(acts[:4], None, [0, 1, 2, 3], [1, 7, 8, 9])    # row 1 is written by edge 0 and read by edge 1
+    with pytest.raises(ValueError):
+        env.transition(acts[:2], None, [0, 1], [5, 5])
+    with pytest.raises(ValueError):
+        env.transition(acts[:2], None, [0, pool], [5, 6])
+
+
+def test_transition_f32_obs():
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(2, True, "dense_train")
+    env = BatchedDMPEnv(2, True, 512, plans=table.reshape(-1, 26, 26), seed=3, obs_dtype=torch.float32)
+    orc = helpers.oracle().OracleBatch(2, True, 512, table, seed=3)
+    env.reset(); orc.reset()
+    env.rollout(9, obs=None); orc.rollout(9, obs=None)
+    src = np.arange(256, dtype=np.int32); dst = src + 256
+    acts = (np.arange(256) % 5).astype(np.int8)
+    o, _, _ = env.transition(acts, None, src, dst, t=2)
+    oo, _, _ = orc.transition(acts, None, src, dst, t=2)
+    assert o.dtype == torch.float32 and np.array_equal(o.cpu().numpy(), oo.astype(np.float32))
+
+
+@pytest.mark.parametrize("dim,dyn", CONFIGS)
+def test_import_states_roundtrip(dim, dyn):
+    """environment_memory()/position/... of one batch -> import_states() of another (scattered rows): identical records,
+    IoU (3D: the running min(height, plan) sum is rebuilt), observations and futures."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(dim, dyn, _tag(dim, dyn))
+    full = table.reshape((-1, 30) if dim == 1 else (-1, 26, 26))
+    n, seed = 777, 21
+    a = BatchedDMPEnv(dim, dyn, n, plans=full, seed=seed)
+    a.reset()
+    a.rollout(31, obs=None)
+    a.step(auto_reset=True)                                      # nobody is waiting for a reset: flags clear below
+    keep = ~a.need_reset
+    rows = torch.nonzero(keep).reshape(-1)
+    m = int(rows.numel())
+    b = BatchedDMPEnv(dim, dyn, n + 5, plans=full, seed=seed)
+    perm = torch.randperm(n + 5, generator=torch.Generator().manual_seed(1))[:m].to(a.device)
+    pos = a.position[rows] if dim != 1 else a.position[rows, 0]
+    b.import_states(pos, a.count_brick[rows], a.count_step[rows], a.environment_memory()[rows], plan_idx=a.plan_idx[rows], dst=perm)
+    assert torch.equal(b._grid[perm], a._grid[rows])
+    ha, hb = a._hdr[rows].view(torch.int16), b._hdr[perm].view(torch.int16)
+    assert torch.equal(ha[:, :6], hb[:, :6])                     # position, flags, cb, cs, tb, plan row
+    assert torch.equal(hb[:, 6], torch.zeros_like(hb[:, 6]))     # the running return restarts
+    if dim == 3:
+        assert torch.equal(ha[:, 7], hb[:, 7])                   # running sum of min(height, plan)
+    assert torch.equal(b.iou()[perm], a.iou()[rows])
+    assert torch.equal(b.observe()[perm], a.observe()[rows])
+    acts = torch.randint(0, a.num_actions, (m,), dtype=torch.int8, device=a.device)
+    ks = torch.randint(1, 4, (m,), dtype=torch.int8, device=a.device)
+    oa, ra, da = a.transition(acts, ks, rows, rows)
+    ob, rb, db = b.transition(acts, ks, perm, perm)
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    # total_brick override and the argument checks
+    b.import_states(pos[:3], [1, 2, 3], [4, 5, 6], a.environment_memory()[rows[:3]], plan_idx=[0, 0, 0], total_brick=[-32768, 77, 32767], dst=[0, 1, 2])
+    assert b.total_brick[:3].tolist() == [-32768, 77, 32767] and b.count_step[:3].tolist() == [4, 5, 6]
+    bad = pos[:1].clone()
+    bad[...] = 0
+    with pytest.raises(ValueError):
+        b.import_states(bad, [0], [0], a.environment_memory()[:1], plan_idx=[0])
+    with pytest.raises(ValueError):
+        b.import_states(pos[:1], [0], [0], a.environment_memory()[:1], plan_idx=[b.num_plans])
+    c = BatchedDMPEnv(dim, dyn, 4, plans=full)
+    with pytest.raises(Exception):
+        c.import_states(pos[:1], [0], [0], a.environment_memory()[:1])        # no plan row known yet
+
+
+def test_import_states_matches_oracle_set_state():
+    """Hand-made states (heights above the plan, counts next to their limits) through import_states + transition vs the oracle."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    orc_mod = helpers.oracle()
+    for dim, dyn in CONFIGS:
+        table = helpers.plan_table(dim, dyn, _tag(dim, dyn))
+        full = table.reshape((-1, 30) if dim == 1 else (-1, 26, 26))
+        n = 300
+        rng = np.random.default_rng(7 * dim + dyn)
+        env = BatchedDMPEnv(dim, dyn, n, plans=full, seed=1)
+        orc = orc_mod.OracleBatch(dim, dyn, n, table, seed=1)
+        H, W = (1, 34) if dim == 1 else (26, 26)
+        hw = 2 if dim == 1 else 3
+        mem = -np.ones((n, H, W))
+        hi = {1: 40, 2: 2, 3: 9}[dim]
+        if dim == 1:
+            mem[:, :, hw:W - hw] = rng.integers(0, hi, (n, 1, 30)) * (rng.random((n, 1, 30)) < 0.6)
+        else:
+            mem[:, hw:H - hw, hw:W - hw] = rng.integers(0, hi, (n, 20, 20)) * (rng.random((n, 20, 20)) < 0.3)
+        pos = rng.integers(hw, hw + (30 if dim == 1 else 20), (n, 2))
+        if dim == 3:                                               # the agent stands on an empty cell
+            mem[np.arange(n), pos[:, 0], pos[:, 1]] = 0
+        pidx = rng.integers(0, len(table), n)
+        T = env.total_step
+        cs = np.where(rng.random(n) < 0.3, T - 1 - rng.integers(0, 2, n), rng.integers(0, T - 2, n))
+        cb = rng.integers(0, 60, n)
+        env.import_states(pos if dim != 1 else pos[:, 0], cb, cs, mem, plan_idx=pidx)
+        for i in range(n):
+            orc.set_state(i, mem[i].astype(np.int32), int(pos[i, 0]) if dim == 1 else pos[i], int(cb[i]), int(cs[i]), plan_idx=int(pidx[i]))
+        _same_state(env, orc)
+        assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+        acts = rng.integers(0, env.num_actions, n).astype(np.int8)
+        ks = rng.integers(1, 4, n).astype(np.int8)
+        o, r, d = env.transition(acts, ks)
+        oo, ro, do = orc.transition(acts, ks)
+        assert o.cpu().numpy().tobytes() == oo.tobytes() and r.cpu().numpy().tobytes() == ro.tobytes()
+        assert np.array_equal(d.cpu().numpy().astype(np.uint8), do)
+        _same_state(env, orc)
+        assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+
+
+def test_obs_equal():
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    for dim, dt in ((1, torch.float64), (2, torch.float64), (3, torch.float32)):
+        env = BatchedDMPEnv(dim, False, 8, obs_dtype=dt)
+        D = env.obs_dim
+        g = torch.Generator().manual_seed(dim)
+        a = torch.randint(-1, 3, (1000, D), generator=g).to(dt).cuda()
+        b = a[torch.randint(0, 1000, (700,), generator=g)].clone()
+        ia = torch.randint(0, 1000, (5000,), generator=g).cuda()
+        ib = torch.randint(0, 700, (5000,), generator=g).cuda()
+        b[::7, D - 1] += 1                                        # differ in the last slot only
+        b[3, 0] = float("nan")                                    # np.array_equal: nan != nan
+        want = (a[ia] == b[ib]).all(dim=1)
+        assert torch.equal(env.obs_equal(a, b, ia, ib), want) and bool(want.any()) and not bool(want.all())
+        assert torch.equal(env.obs_equal(a[:700], b), (a[:700] == b).all(dim=1))
+        assert bool(env.obs_equal(b, b)[3]) is False
+        with pytest.raises(ValueError):
+            env.obs_equal(a, b, ia + 1000, ib)
+
+
+# ---- the nine drop-in classes against the reference's goldens -----------------------------------------------------------
+MODS = {
+    "1d.static": ("1D", "DMP_Env_1D_static_MCTS", "deep_mobile_printing_1d1r_MCTS"),
+    "1d.test": ("1D", "DMP_Env_1D_static_MCTS_test", "deep_mobile_printing_1d1r_MCTS_obs_test"),
+    "1d.dynamic": ("1D", "DMP_Env_1D_dynamic_MCTS", "deep_mobile_printing_1d1r_MCTS_obs"),
+    "2d.static": ("2D", "DMP_ENV_2D_static_MCTS", "deep_mobile_printing_2d1r_MCTS"),
+    "2d.test": ("2D", "DMP_ENV_2D_static_MCTS_test", "deep_mobile_printing_2d1r_MCTS_test"),
+    "2d.dynamic": ("2D", "DMP_ENV_2D_dynamic_MCTS", "deep_mobile_printing_2d1r"),
+    "3d.static": ("3D", "DMP_simulator_3d_static_circle_MCTS", "deep_mobile_printing_3d1r"),
+    "3d.test": ("3D", "DMP_simulator_3d_static_circle_MCTS_test", "deep_mobile_printing_3d1r"),
+    "3d.dynamic": ("3D", "DMP_simulator_3d_dynamic_triangle_MCTS", "deep_mobile_printing_3d1r"),
+}
+
+
+def _load(variant):
+    d, mod, cls = MODS[variant]
+    path = os.path.join(helpers.ROOT, "snac_amd", "Env", d)
+    sys.path.insert(0, path)
+    try:
+        sys.modules.pop(mod, None)
+        return getattr(importlib.import_module(mod), cls)
+    finally:
+        sys.path.remove(path)
+
+
+@pytest.mark.parametrize("name", tm.names())
+def test_facade_replays_mcts_goldens(name):
+    """From np.random.seed alone: the same reset / step / transition sequence as the capture script ran on the reference."""
+    r = tm.rec(name)
+    dim, dyn, kind = tm.variant(name)
+    variant = name.split(".")[0] + "." + kind
+    cls = _load(variant)
+    plan = name.split(".")[2]
+    np.random.seed(int(r["seed"]))
+    if dyn:
+        dens, split = plan.split("-")
+        pre = "data_1d_dynamic_sin_envplan_500_" if dim == 1 else "data_%dd_dynamic_%s_envplan_500_" % (dim, dens)
+        env = cls(data_path="/nonexistent/" + pre + split + ".pkl", random_choose_paln=True)
+    else:
+        env = cls(plan_choose=int(plan))
+    assert env.action_space.n == {1: 3, 2: 5, 3: 8}[dim]
+    shape = (1, 34) if dim == 1 else (26, 26)
+    nodes, episode = [], -1
+
+    def unpack(state):
+        pos, grid, cb, cs = state
+        p = (int(pos), 0) if dim == 1 else (int(pos[0]), int(pos[1]))
+        return p, np.asarray(grid), int(cb), int(cs)
+
+    for t in range(len(r["op"])):
+        if int(r["episode"][t]) != episode:
+            episode += 1
+            state, obs = env.reset()
+            assert np.asarray(obs).tobytes() == r["ep_reset_obs"][episode].reshape(1, -1).tobytes()
+            assert int(env.total_brick) == r["ep_total_brick"][episode]
+            assert np.array_equal(np.asarray(env.plan).reshape(-1), r["ep_plan"][episode])
+            nodes = [state]
+        op, a = int(r["op"][t]), int(r["action"][t])
+        if op == 0:
+            state, obs, rew, d = env.step(a)
+            assert env.step_size == r["step_size"][t]
+        else:
+            src = nodes[int(r["parent"][t])]
+            if op == 2:
+                pos, grid, _, _ = src
+                src = (list(pos) if dim != 1 else pos, np.array(grid, copy=True), int(r["in_cb"][t]), int(r["in_cs"][t]))
+            p, g, cb, cs = unpack(src)
+            assert (p, cb, cs) == (tuple(r["in_pos"][t]), r["in_cb"][t], r["in_cs"][t]), (name, t)
+            assert np.array_equal(g.reshape(-1), r["in_grid"][t]), (name, t)      # includes every earlier in-place edit
+            saved = env.conut_brick if dim == 1 else env.count_brick
+            if op == 3:
+                if dim == 1:
+                    env.conut_brick = int(env.total_brick)
+                else:
+                    env.count_brick = int(env.total_brick)
+            state, obs, rew, d = env.transition(src, a)
+            if dim == 1:
+                env.conut_brick = saved
+            else:
+                env.count_brick = saved
+            assert np.array_equal(np.asarray(src[1]).reshape(-1), r["in_grid_after"][t]), (name, t)
+            assert (state[1] is src[1]) == bool(r["aliased"][t])
+        p, g, cb, cs = unpack(state)
+        assert g.shape == shape and g.dtype == np.float64
+        assert (p, cb, cs) == (tuple(r["out_pos"][t]), r["out_cb"][t], r["out_cs"][t]), (name, t)
+        assert np.array_equal(g.reshape(-1), r["out_grid"][t]), (name, t)
+        assert np.asarray(obs).shape == (1, 7 if dim == 1 else 51)
+        assert np.asarray(obs, np.float64).tobytes() == r["obs"][t].reshape(1, -1).tobytes(), (name, t)
+        assert rew == r["reward"][t] and d == bool(r["done"][t]), (name, t)
+        assert env.equality_operator(obs, r["obs"][t].reshape(1, -1)) and not env.equality_operator(obs, np.asarray(obs) + 1)
+        nodes.append(state)
+    if variant == "1d.static":
+        assert env.iou_MCTS(nodes[-1][1]) == _iou1(env, nodes[-1][1]) and not hasattr(_load("1d.test"), "iou_MCTS")
+
+
+def _iou1(env, mem):
+    g = np.asarray(mem)[0][2:32]
+    p = np.asarray(env.plan)
+    cross = g.sum() - np.maximum(g - p, 0).sum()
+    return float(cross / (p.sum() + g.sum() - cross))
