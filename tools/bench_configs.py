@@ -14,6 +14,10 @@ from snac_amd import BatchedDMPEnv  # noqa: E402
 ALG = {1: 88, 2: 481, 3: 574}
 
 
+def env_obs_bytes(kind):
+    return 8 * (7 if kind == 1 else 51)
+
+
 def rollout_time(kind, dynamic, n, T, obs_dtype=torch.float64, reps=5, obs="all"):
     env = BatchedDMPEnv(kind, dynamic, n, seed=1, obs_dtype=obs_dtype)
     env.reset()
@@ -107,7 +111,48 @@ def gather_time(n=65536, cap=64, batch=65536, reps=20):
     return ms, moved / ms / 1e6
 
 
+def transition_time(kind, pool=1 << 20, parents=1 << 17, reps=20):
+    """snac_transition as one search wave: every action of `parents` random pool rows expanded into fresh rows, with the
+    observation of every child (out of place, gathered sources).  Uses the raw ABI call: the Python wrapper's argument
+    checks cost more than the launch."""
+    import ctypes as C
+
+    from snac_amd import _lib
+
+    env = BatchedDMPEnv(kind, True, pool, seed=1)
+    env.reset()
+    env.rollout(20, obs=None)
+    A = env.num_actions
+    m = parents * A
+    src = torch.randint(0, pool - m, (parents,), device=env.device, dtype=torch.int32).repeat_interleave(A).contiguous()
+    dst = (pool - m + torch.arange(m, device=env.device, dtype=torch.int32)).contiguous()
+    acts = torch.arange(A, device=env.device, dtype=torch.int8).repeat(parents).contiguous()
+    obs = torch.empty((m, env.obs_dim), dtype=torch.float64, device=env.device)
+    rew = torch.empty(m, dtype=torch.float32, device=env.device)
+    done = torch.empty(m, dtype=torch.uint8, device=env.device)
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def call():
+        _lib.check(env._lib.snac_transition(C.byref(env._desc), C.byref(env._state), m, vp(src), vp(dst), 0, vp(acts), None, vp(obs),
+                                            vp(rew), vp(done), env._stream()))
+
+    call()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        call()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps, m
+
+
 def extras():
+    for kind, rec in ((1, 64), (2, 80), (3, 800)):
+        ms, m = transition_time(kind, parents=(1 << 17) if kind != 3 else (1 << 16))
+        per = 2 * (16 + 4 + rec) + env_obs_bytes(kind) + 5       # read + write one state record, write obs + reward + done
+        print("transition %dD dynamic: %d edges (random parents x all actions, pool 2^20)  %8.3f ms  %.3e edges/s  alg %.0f GB/s"
+              % (kind, m, ms, m / ms * 1e3, per * m / ms / 1e6))
     for n in (1, 4096, 65536):
         print("step() as hipGraph replay 2D dynamic N=%-7d explicit a,k  %8.4f ms/tick" % (n, graph_step_time(n)))
     ms, gbs = gather_time()
