@@ -68,6 +68,12 @@ enum { SNAC_ENV_1D = 1, SNAC_ENV_2D = 2, SNAC_ENV_3D = 3 };
 enum { SNAC_OBS_F64 = 0, SNAC_OBS_F32 = 1 };
 enum { SNAC_OBS_NONE = 0, SNAC_OBS_ALL = 1, SNAC_OBS_LAST = 2 };
 enum { SNAC_FLAG_NEED_RESET = 1 };   /* snac_env_hdr.flags: the last step returned done */
+/* snac_env_desc.rules: the termination tests of the env copies under script/PPO (and script/Rainbow/env/Env2D.py:166), which
+ * write `>` where the canonical classes write `>=`:
+ *   SNAC_RULE_BRICK_GT  done when count_brick > total_brick   (script/PPO/1d_dynamic/DMP_Env_1D_dynamic_usedata_plan.py:93,
+ *                       script/PPO/2d_static/DMP_Env_2D_static.py:137, script/PPO/3d_static/DMP_simulator_3d_static_circle.py:205)
+ *   SNAC_RULE_TIME_GT   done when count_step > total_step     (script/PPO/3d_static/DMP_simulator_3d_static_circle.py:221) */
+enum { SNAC_RULE_BRICK_GT = 1, SNAC_RULE_TIME_GT = 2 };
 
 /* constants of one env kind: the reference's __init__ blocks (Env/1D/DMP_Env_1D_static.py:7-29,
  * Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:7-32, Env/3D/DMP_simulator_3d_static_circle.py:8-40,
@@ -104,7 +110,7 @@ typedef struct snac_env_desc {
     int32_t total_step;         /* time limit; 0 = the class constant (750 / 600 / 1300 static 3D / 1000 dynamic 3D).
                                    The 3D L-Net variant runs the dynamic rules with 1300
                                    (Env/3D/DMP_simulator_3d_static_circle_Lnet.py:28) */
-    int32_t reserved;           /* must be 0 */
+    int32_t rules;              /* SNAC_RULE_* bits; 0 = the canonical classes */
 } snac_env_desc;
 
 typedef struct snac_state {

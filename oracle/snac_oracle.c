@@ -50,6 +50,15 @@ int orc_configure(orc_env* e, int obs_norm, int rules_dyn, int total_step, int f
     return 0;
 }
 
+/* the env copies under script/PPO write `>` in some termination tests: count_brick > total_brick
+ * (script/PPO/1d_dynamic/DMP_Env_1D_dynamic_usedata_plan.py:93, script/PPO/2d_static/DMP_Env_2D_static.py:137,
+ * script/PPO/3d_static/DMP_simulator_3d_static_circle.py:205) and count_step > total_step (3d_static :221) */
+int orc_set_rules(orc_env* e, int brick_gt, int time_gt) {
+    e->brick_gt = brick_gt ? 1 : 0;
+    e->time_gt = time_gt ? 1 : 0;
+    return 0;
+}
+
 #define G(e, r, c) ((e)->grid[(r) * (e)->W + (c)])
 #define P(e, r, c) ((e)->plan[(r) * (e)->W + (c)])
 
@@ -124,11 +133,11 @@ static int step1(orc_env* e, int action, int k, double* reward, int* done) {
         p = e->pos[0];
         e->cb += 1;
         e->grid[p] += 1;
-        if (e->cb >= e->tb) {                        /* S1:107-114 */
+        if (e->cb >= e->tb + e->brick_gt) {                        /* S1:107-114 */
             *reward = 0.0; *done = 1;
             return 0;
         }
-        *done = (e->cs >= e->total_step);            /* S1:116 */
+        *done = (e->cs >= e->total_step + e->time_gt);            /* S1:116 */
         if (e->grid[p] > e->plan[p - e->hw]) *reward = -1.0;
         else if (e->grid[p] == e->plan[p - e->hw]) *reward = 10.0;
         else *reward = 1.0;
@@ -137,7 +146,7 @@ static int step1(orc_env* e, int action, int k, double* reward, int* done) {
         return -1;                                   /* `position` unbound in the reference */
     }
     e->pos[0] = p;
-    *done = (e->cs >= e->total_step);                /* S1:130 */
+    *done = (e->cs >= e->total_step + e->time_gt);                /* S1:130 */
     *reward = 0.0;
     return 0;
 }
@@ -154,12 +163,12 @@ static int step2(orc_env* e, int action, int k, double* reward, int* done) {
     else if (action == 4) {
         e->cb += 1;
         G(e, pos[0], pos[1]) += 1;
-        if (e->cb >= e->tb) {                        /* D2:117-126 */
+        if (e->cb >= e->tb + e->brick_gt) {                        /* D2:117-126 */
             if (G(e, pos[0], pos[1]) > 1) G(e, pos[0], pos[1]) = 1;
             *reward = 0.0; *done = 1;
             return 0;
         }
-        *done = (e->cs >= e->total_step);            /* D2:128 */
+        *done = (e->cs >= e->total_step + e->time_gt);            /* D2:128 */
         /* compare the un-clamped cell, then clamp: D2:129-135.  The `<` case leaves `reward` unbound in
          * the reference; it cannot occur (cell >= 1 >= plan). */
         if (G(e, pos[0], pos[1]) > P(e, pos[0], pos[1])) *reward = 0.0;
@@ -171,7 +180,7 @@ static int step2(orc_env* e, int action, int k, double* reward, int* done) {
         return -1;
     }
     e->pos[0] = pos[0]; e->pos[1] = pos[1];
-    *done = (e->cs >= e->total_step);                /* D2:141 */
+    *done = (e->cs >= e->total_step + e->time_gt);                /* D2:141 */
     *reward = 0.0;
     return 0;
 }
@@ -227,16 +236,16 @@ static int step3(orc_env* e, int action, int k, double* reward, int* done) {
             int after[8];
             check_sur(e, after);                     /* D3:199: re-evaluated AFTER the build */
             if (after[0] && after[1] && after[2] && after[3]) { *done = 1; *reward = -100.0; return 0; }
-            if (e->cb >= e->tb) { *done = 1; *reward = 0.0; return 0; }
+            if (e->cb >= e->tb + e->brick_gt) { *done = 1; *reward = 0.0; return 0; }
             if (build) { *done = 0; *reward = reward_check(e, tr, tc); return 0; }  /* D3:214-221 */
         } else {
             int boxed = check[0] && check[1] && check[2] && check[3];  /* S3:210: neighbours BEFORE the build */
-            if (e->cb >= e->tb || boxed) { *done = 1; *reward = 0.0; return 0; }
+            if (e->cb >= e->tb + e->brick_gt || boxed) { *done = 1; *reward = 0.0; return 0; }
             if (build) { *done = 0; *reward = reward_check(e, tr, tc); return 0; }
         }
     }
     /* moves, blocked moves, blocked builds: S3:226-230, D3:226-231 */
-    *done = (e->cs >= e->total_step);
+    *done = (e->cs >= e->total_step + e->time_gt);
     if (!e->rules_dyn) *done = *done || (check[0] && check[1] && check[2] && check[3]);
     *reward = 0.0;
     return 0;
@@ -265,7 +274,7 @@ int orc_transition(const orc_env* src, orc_env* dst, int action, int k, int gate
     int rc, tb;
     if (dst != src) *dst = *src;
     tb = dst->tb;
-    if (gate_cb >= 0 && dst->dim == 3 && dst->rules_dyn) dst->tb = (gate_cb >= tb) ? INT32_MIN : INT32_MAX;
+    if (gate_cb >= 0 && dst->dim == 3 && dst->rules_dyn) dst->tb = (gate_cb >= tb) ? -0x3fffffff : 0x3fffffff;   /* always / never reached */
     rc = orc_step(dst, action, k, NULL, reward, done);
     dst->tb = tb;
     if (rc) return rc;
@@ -427,6 +436,10 @@ orc_batch* orc_batch_create(int dim, int dynamic, int n, const int32_t* plans, i
     b->stat_steps = (int64_t*)calloc((size_t)n, sizeof(int64_t));
     for (int i = 0; i < n; ++i) { b->envs[i] = proto; b->episode[i] = -1; }
     return b;
+}
+
+void orc_batch_set_rules(orc_batch* b, int brick_gt, int time_gt) {
+    for (int i = 0; i < b->n; ++i) orc_set_rules(&b->envs[i], brick_gt, time_gt);
 }
 
 void orc_batch_destroy(orc_batch* b) {

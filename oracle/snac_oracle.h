@@ -44,11 +44,14 @@ typedef struct orc_env {
     int32_t obs_norm;    /* observation scalars cb/tb, cs/T (default: = dynamic) */
     int32_t rules_dyn;   /* 3D: termination rules of the dynamic class (default: = dynamic) */
     int32_t frame;       /* value of the frame cells: -1, or 2 in the 2D L-Net variant */
+    int32_t brick_gt;    /* 1: done when cb > tb (script/PPO copies), 0: cb >= tb */
+    int32_t time_gt;     /* 1: done when cs > T (script/PPO/3d_static), 0: cs >= T */
 } orc_env;
 
 /* ---- single env ---- */
 int  orc_init(orc_env* e, int dim, int dynamic);
 int  orc_configure(orc_env* e, int obs_norm, int rules_dyn, int total_step, int frame);
+int  orc_set_rules(orc_env* e, int brick_gt, int time_gt);   /* the `>` termination tests of the script/PPO env copies */
 /* plan: 30 (1D) or 676 (2D/3D) ints; obs: obs_dim doubles (may be NULL) */
 int  orc_reset(orc_env* e, const int32_t* plan, int plan_idx, double* obs);
 /* returns 0, or -1 for an action outside [0, num_actions) (the reference raises after cs += 1) */
@@ -91,6 +94,7 @@ typedef struct orc_batch {
 orc_batch* orc_batch_create(int dim, int dynamic, int n, const int32_t* plans, int num_plans,
                             uint64_t seed, int64_t env_id_base);
 void orc_batch_destroy(orc_batch* b);
+void orc_batch_set_rules(orc_batch* b, int brick_gt, int time_gt);
 /* mask NULL = all; plan_idx_in NULL = counter RNG (dynamic) / plan 0 (static); obs [n][obs_dim] or NULL */
 int  orc_batch_reset(orc_batch* b, const uint8_t* mask, const int32_t* plan_idx_in, double* obs);
 /* one vector step at tick t.  actions/step_size NULL = counter RNG.  auto_reset: envs whose previous

@@ -25,7 +25,7 @@ class _Env(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "dynamic", "hw", "H", "W", "total_step", "num_actions", "obs_dim")] + [
         ("grid", C.c_int32 * MAX_CELLS), ("plan", C.c_int32 * MAX_CELLS), ("pos", C.c_int32 * 2),
         ("cb", C.c_int32), ("cs", C.c_int32), ("tb", C.c_int32), ("step_size", C.c_int32), ("plan_idx", C.c_int32),
-        ("obs_norm", C.c_int32), ("rules_dyn", C.c_int32), ("frame", C.c_int32)]
+        ("obs_norm", C.c_int32), ("rules_dyn", C.c_int32), ("frame", C.c_int32), ("brick_gt", C.c_int32), ("time_gt", C.c_int32)]
 
 
 class _Batch(C.Structure):
@@ -72,6 +72,8 @@ def lib():
         L.orc_batch_rollout.argtypes = [C.POINTER(_Batch), C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_int]
         L.orc_batch_iou.argtypes = [C.POINTER(_Batch), C.c_void_p]
+        L.orc_set_rules.argtypes = [C.POINTER(_Env), C.c_int, C.c_int]
+        L.orc_batch_set_rules.argtypes = [C.POINTER(_Batch), C.c_int, C.c_int]
         L.orc_transition.argtypes = [C.POINTER(_Env), C.POINTER(_Env), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.orc_set_state.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -115,6 +117,10 @@ class OracleEnv:
 
     def configure(self, obs_norm, rules_dyn, total_step=0, frame=-1):
         lib().orc_configure(C.byref(self.e), int(obs_norm), int(rules_dyn), int(total_step), int(frame))
+        return self
+
+    def set_rules(self, brick_gt=False, time_gt=False):
+        lib().orc_set_rules(C.byref(self.e), int(brick_gt), int(time_gt))
         return self
 
     def reset(self, plan, plan_idx=0):
@@ -177,6 +183,17 @@ class OracleBatch:
             raise MemoryError
         self.n, self.obs_dim, self.dim, self.dynamic = n, self.b.contents.obs_dim, dim, bool(dynamic)
         self.total_step, self.num_actions = self.b.contents.total_step, self.b.contents.num_actions
+
+    def set_rules(self, brick_gt=False, time_gt=False):
+        lib().orc_batch_set_rules(self.b, int(brick_gt), int(time_gt))
+        return self
+
+    def set_total_step(self, total_step):
+        """The time limit of every env (snac_env_desc.total_step)."""
+        for i in range(self.n):
+            self.b.contents.envs[i].total_step = int(total_step)
+        self.b.contents.total_step = self.total_step = int(total_step)
+        return self
 
     def __del__(self):
         if getattr(self, "b", None):

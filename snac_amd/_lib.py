@@ -15,6 +15,7 @@ ENV_1D, ENV_2D, ENV_3D = 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 OBS_NONE, OBS_ALL, OBS_LAST = 0, 1, 2
 FLAG_NEED_RESET = 1
+RULE_BRICK_GT, RULE_TIME_GT = 1, 2
 
 EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_reset", "snac_step", "snac_rollout",
            "snac_rollout_rec", "snac_replay_gather", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
@@ -30,7 +31,7 @@ class Sizes(C.Structure):
 class EnvDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dynamic", C.c_int32), ("num_envs", C.c_int32), ("num_plans", C.c_int32),
                 ("obs_dtype", C.c_int32), ("static_plan", C.c_int32), ("seed", C.c_uint64), ("env_id_base", C.c_int64),
-                ("total_step", C.c_int32), ("reserved", C.c_int32)]
+                ("total_step", C.c_int32), ("rules", C.c_int32)]
 
 
 class RolloutRecord(C.Structure):

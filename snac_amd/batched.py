@@ -30,10 +30,13 @@ class BatchedDMPEnv:
     plans     [P, 30] / [P, 26, 26] array of full plans as the reference stores them; default: the static plan
               `plan_choose` (static) or the converted training set of `density` (dynamic)
     seed      counter-RNG seed (include/snac_hip.h); env_id_base: global id of local env 0 (multi-GPU shards)
+    brick_gt / time_gt   the strict termination tests of the env copies under script/PPO (SNAC_RULE_* in snac_hip.h):
+              done when count_brick > total_brick / count_step > total_step instead of >=
     """
 
     def __init__(self, kind, dynamic, num_envs, plans=None, plan_choose=0, density="dense", split="train",
-                 device="cuda", seed=1, obs_dtype=torch.float64, env_id_base=0, total_step=None, plan_tb=None):
+                 device="cuda", seed=1, obs_dtype=torch.float64, env_id_base=0, total_step=None, plan_tb=None,
+                 brick_gt=False, time_gt=False):
         if not torch.cuda.is_available():
             raise _lib.SnacError("BatchedDMPEnv needs a ROCm GPU: there is no CPU fallback")
         self.kind = _KINDS[kind]
@@ -75,7 +78,9 @@ class BatchedDMPEnv:
         self._stats = torch.zeros((3, N), dtype=torch.int64, device=dev)
         self._desc = _lib.EnvDesc(self.kind, int(self.dynamic), N, self.num_plans,
                                   _lib.OBS_F64 if obs_dtype == torch.float64 else _lib.OBS_F32, 0,
-                                  self.seed & 0xFFFFFFFFFFFFFFFF, self.env_id_base, self.total_step, 0)
+                                  self.seed & 0xFFFFFFFFFFFFFFFF, self.env_id_base, self.total_step,
+                                  (_lib.RULE_BRICK_GT if brick_gt else 0) | (_lib.RULE_TIME_GT if time_gt else 0))
+        self.brick_gt, self.time_gt = bool(brick_gt), bool(time_gt)
         self._state = _lib.State(self._hdr.data_ptr(), self._episode.data_ptr(), self._grid.data_ptr(),
                                  self._plans.data_ptr(), self._plan_tb.data_ptr(), self._stats[0].data_ptr(),
                                  self._stats[1].data_ptr(), self._stats[2].data_ptr())
@@ -228,7 +233,8 @@ class BatchedDMPEnv:
         transition(state, action).  Episodic sums start at zero; counter-RNG streams are keyed by the NEW local index."""
         index = torch.as_tensor(index, device=self.device, dtype=torch.long)
         child = BatchedDMPEnv(self.kind, self.dynamic, int(index.numel()), plans=self.plans_full, device=self.device, seed=self.seed,
-                              obs_dtype=self.obs_dtype, env_id_base=self.env_id_base, total_step=self.total_step)
+                              obs_dtype=self.obs_dtype, env_id_base=self.env_id_base, total_step=self.total_step,
+                              brick_gt=self.brick_gt, time_gt=self.time_gt)
         child._hdr.copy_(self._hdr[index]); child._episode.copy_(self._episode[index]); child._grid.copy_(self._grid[index])
         child.t = self.t
         child._was_reset = self._was_reset

@@ -56,6 +56,8 @@ __device__ inline uint32_t rng_word(EnvKeys k, uint32_t t) { return mix32(mix32(
 struct KArgs {
     int32_t n, num_plans, static_plan, T, auto_reset, obs_mode;
     int32_t total_step;        // the env's time limit (snac_env_desc.total_step or the kind's default)
+    int32_t ts_done;           // count_step >= ts_done ends the episode: total_step (+ 1 with SNAC_RULE_TIME_GT)
+    int32_t brick_gt;          // 1: count_brick > total_brick ends the episode (SNAC_RULE_BRICK_GT), 0: >=
     uint32_t t0, key_step, key_plan;
     int64_t env_id_base;
     int4* hdr;                 // snac_env_hdr[N] as 16-byte words
@@ -188,7 +190,7 @@ struct K2D {
         if (lane < GE) cells(lds)[(lane + 3) * RS + e] = ((uint64_t)ROW_HI << 32) | ROW_LO;
     }
     // step: DMP_Env_2D_dynamic_usedata_plan.py:85-147
-    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
         uint64_t* cw = cells(lds) + s.r * RS + lane;
         const uint64_t w = *cw;
         const int off = 2 * s.c;
@@ -204,7 +206,7 @@ struct K2D {
         if (act == 1) s.c = min(s.c + k, 22);
         if (act == 2) s.r = min(s.r + k, 22);                        // "up" is row + k (:100-103)
         if (act == 3) s.r = max(s.r - k, 3);
-        const bool term = drop && s.cb >= s.tb;                      // :117-126, tested before the time limit
+        const bool term = drop && s.cb >= s.tb + bg;                 // :117-126, tested before the time limit (bg: SNAC_RULE_BRICK_GT)
         done = term || s.cs >= ts;
         // un-clamped cell vs plan (:129-133): 5 iff the cell was empty and is planned
         reward = (drop && !term && !was && planned) ? 5 : 0;
@@ -274,7 +276,7 @@ struct K3D {
         for (int i = lane; i < GE; i += 64) { const int r = i / 20, c = i - r * 20; h[(r + 3) * 26 + c + 3] = 0; }
     }
     // step: DMP_simulator_3d_static_circle.py:153-230, DMP_simulator_3d_dynamic_triangle_usedata.py:142-231
-    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r * 26 + s.c;         // the agent's cell
         s.cs += 1;
         reward = 0;
@@ -311,9 +313,9 @@ struct K3D {
                 const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0))
                                               : boxed_pre;
                 if (boxed_post) { reward = -100; done = true; fin = true; }
-                else if (s.cb >= s.tb) { reward = 0; done = true; fin = true; }          // :207-213
+                else if (s.cb >= s.tb + bg) { reward = 0; done = true; fin = true; }     // :207-213
             } else {
-                if (s.cb >= s.tb || boxed_pre) { reward = 0; done = true; fin = true; }  // :210-215
+                if (s.cb >= s.tb + bg || boxed_pre) { reward = 0; done = true; fin = true; }  // :210-215
             }
             if (!fin && built) {                                     // reward_check (:232-239); time limit NOT tested
                 reward = newh > pl ? -1 : (newh == pl ? 10 : 1);
@@ -383,7 +385,7 @@ struct K1D {
         if (lane < 30) hmap(lds)[e * ES + lane + 2] = 0;
     }
     // step: DMP_Env_1D_static.py:85-136
-    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r;
         const int hnew = (int)*h + 1;
         const int pl = plan(lds)[lane * ES + s.r - 2];
@@ -392,7 +394,7 @@ struct K1D {
         if (drop) { s.cb += 1; *h = (int16_t)hnew; }
         if (act == 0) s.r = max(s.r - k, 2);                         // clip_position :57-64
         if (act == 1) s.r = min(s.r + k, 31);
-        const bool term = drop && s.cb >= s.tb;                      // :107-114, before the time limit
+        const bool term = drop && s.cb >= s.tb + bg;                 // :107-114, before the time limit
         done = term || s.cs >= ts;
         reward = (drop && !term) ? (hnew > pl ? -1 : (hnew == pl ? 10 : 1)) : 0;   // :117-123
     }
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
             const uint32_t w = rng_word(sk, a.t0 + (uint32_t)t);
             const int act = a.actions ? (int)a.actions[row + lane] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
             const int k = a.step_size ? (int)a.step_size[row + lane] : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
-            K::step(lds, s, act, k, a.total_step, lane, reward, done);
+            K::step(lds, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
             s.ep_ret += reward;
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
             if (a.reward) a.reward[row + lane] = (float)reward;
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
         const uint32_t w = rng_word(env_keys(a.key_step, (uint64_t)(a.env_id_base + edge)), a.t0);
         const int act = a.actions ? (int)a.actions[edge] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
         const int k = a.step_size ? (int)a.step_size[edge] : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
-        K::step(lds, s, act, k, a.total_step, lane, reward, done);
+        K::step(lds, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
         s.ep_ret += reward;
         s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
         if (a.reward) a.reward[edge] = (float)reward;
@@ -831,6 +833,7 @@ int check_common(const snac_env_desc* d, const snac_state* st) {
     if (d->static_plan < 0 || d->static_plan >= d->num_plans) return fail(SNAC_ERR_ARG, "static_plan out of range");
     if (d->obs_dtype != SNAC_OBS_F64 && d->obs_dtype != SNAC_OBS_F32) return fail(SNAC_ERR_ARG, "unknown obs_dtype");
     if (d->total_step < 0 || d->total_step > 32000) return fail(SNAC_ERR_ARG, "total_step out of range");
+    if (d->rules & ~(SNAC_RULE_BRICK_GT | SNAC_RULE_TIME_GT)) return fail(SNAC_ERR_ARG, "unknown bits in rules");
     if (!st->hdr || !st->episode || !st->grid || !st->plans || !st->plan_tb || !st->stat_episodes || !st->stat_return ||
         !st->stat_iou_fx)
         return fail(SNAC_ERR_ARG, "null pointer in snac_state");
@@ -843,6 +846,8 @@ KArgs make_args(const snac_env_desc* d, const snac_state* st) {
     a.n = d->num_envs; a.num_plans = d->num_plans; a.static_plan = d->static_plan;
     a.total_step = d->total_step > 0 ? d->total_step
                                      : (d->kind == SNAC_ENV_1D ? 750 : (d->kind == SNAC_ENV_2D ? 600 : (d->dynamic ? 1000 : 1300)));
+    a.brick_gt = (d->rules & SNAC_RULE_BRICK_GT) ? 1 : 0;
+    a.ts_done = a.total_step + ((d->rules & SNAC_RULE_TIME_GT) ? 1 : 0);
     a.key_step = stream_key(d->seed, 0); a.key_plan = stream_key(d->seed, 1);
     a.env_id_base = d->env_id_base;
     a.hdr = (int4*)st->hdr; a.episode = st->episode; a.grid = st->grid; a.plans = st->plans; a.plan_tb = st->plan_tb;

@@ -50,7 +50,8 @@ class _Facade(_Base):
     def _setup(self, plans_full, total_step=None):
         from .batched import BatchedDMPEnv  # imports torch; raises without a ROCm GPU
 
-        self._env = BatchedDMPEnv(self._dim, self._dynamic, 1, plans=plans_full, total_step=total_step)
+        self._env = BatchedDMPEnv(self._dim, self._dynamic, 1, plans=plans_full, total_step=total_step,
+                                  brick_gt=getattr(self, "_brick_gt", False), time_gt=getattr(self, "_time_gt", False))
         self._table = np.asarray(plans_full, np.float64)
 
     # ---- shared plumbing ---------------------------------------------------------------------------
@@ -225,6 +226,38 @@ class deep_mobile_printing_1d1r_hindsight(deep_mobile_printing_1d1r_static):
     def step(self, action, step_size):
         self._sync_plan()
         return deep_mobile_printing_1d1r_static.step(self, action, step_size)
+
+
+class deep_mobile_printing_1d1r_hindsight_dynamic(_Env1D):
+    """Env/1D/DMP_Env_1D_dynamic_hindsight_replay.py :: deep_mobile_printing_1d1r_hindsight() -- a fresh random sin curve
+    per reset() (create_plan :29-42, plans.random_sin_plan), raw counters, observation [obs, plan], step(action, step_size)"""
+    _dynamic = False            # raw count_brick / count_step; one plan row, rewritten at every reset
+
+    def __init__(self):
+        self._init_common()
+        self._setup(np.full((1, 30), 20.0))
+
+    def create_plan(self):
+        y, area, self.one_hot = _plans.random_sin_plan(self.plan_width, self.plan_height)
+        return y, area
+
+    def reset(self):
+        self.one_hot = None
+        y, area = self.create_plan()
+        self._plan_dirty = False
+        self._table[0] = y
+        self._env.set_plan_row(0, y, update_tb=True)
+        obs, (r, _) = self._do_reset(0)
+        self.total_brick = area
+        self.brick_memory = [[-1, -1]]
+        self.position_memory = [r]
+        return [obs.reshape(1, 7), self.plan]
+
+    def step(self, action, step_size):
+        self._sync_plan()
+        obs, reward, done, (r, _) = self._do_step(action, step_size)
+        self._after_step(action, r)
+        return [obs.reshape(1, 7), self.plan], reward, done
 
 
 class deep_mobile_printing_1d1r_dynamic(_Env1D):

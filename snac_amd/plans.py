@@ -41,6 +41,18 @@ def static_plan(dim, plan_choose):
     return plan
 
 
+def random_sin_plan(plan_width=30, plan_height=20):
+    """The random sin-curve plan generator of Env/1D/DMP_Env_1D_dynamic_hindsight_replay.py:29-42 (create_plan): the same
+    numpy calls in the same order on numpy's global stream, so a seeded script sees the same plans.
+    -> (plan float64[30], area, [k_1, k_2, phase])"""
+    k_1 = np.random.uniform(3, 12)
+    k_2 = np.random.randint(1, 4)
+    phase = np.random.uniform(-1, 1) * np.pi
+    x = np.arange(plan_width)
+    y = np.round((k_1 * np.sin(2 * np.pi / plan_width * (k_2 * x + phase)) + plan_height))
+    return y, sum(y), [k_1, k_2, phase]
+
+
 def dataset(dim, density="dense", split="train"):
     """Converted copy of Env/<dim>D/data_*_envplan_500_<split>.pkl -> float64 array [P, ...] like np.asarray(joblib.load(..))."""
     key = "1d_sin_%s" % split if dim == 1 else "%dd_%s_%s" % (dim, density, split)

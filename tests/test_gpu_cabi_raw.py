@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 class EnvDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dynamic", C.c_int32), ("num_envs", C.c_int32), ("num_plans", C.c_int32),
                 ("obs_dtype", C.c_int32), ("static_plan", C.c_int32), ("seed", C.c_uint64), ("env_id_base", C.c_int64),
-                ("total_step", C.c_int32), ("reserved", C.c_int32)]
+                ("total_step", C.c_int32), ("rules", C.c_int32)]
 
 
 class State(C.Structure):
