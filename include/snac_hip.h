@@ -107,7 +107,7 @@ typedef struct snac_env_desc {
     int32_t static_plan;        /* plan row used by resets when dynamic == 0 or no plan index is supplied */
     uint64_t seed;              /* counter-RNG seed */
     int64_t env_id_base;        /* global id of local env 0 */
-    int32_t total_step;         /* time limit; 0 = the class constant (750 / 600 / 1300 static 3D / 1000 dynamic 3D).
+    int32_t total_step;         /* time limit, at most 3000; 0 = the class constant (750 / 600 / 1300 static 3D / 1000 dynamic 3D).
                                    The 3D L-Net variant runs the dynamic rules with 1300
                                    (Env/3D/DMP_simulator_3d_static_circle_Lnet.py:28) */
     int32_t rules;              /* SNAC_RULE_* bits; 0 = the canonical classes */
@@ -146,7 +146,8 @@ int snac_reset(const snac_env_desc* desc, const snac_state* st, const uint8_t* m
  *               the value the reference draws with np.random.randint(1, 4) at the top of step()
  *   auto_reset  != 0: an env whose previous step returned done is reset first (plan from the counter RNG)
  *   obs [N][obs_dim] or NULL, reward float[N] or NULL, done uint8[N] or NULL
- * Actions outside [0, num_actions) only advance count_step (the reference raises). */
+ * Actions outside [0, num_actions) only advance count_step (the reference raises).  Explicit step sizes are clamped into
+ * {1,2,3} -- the only values the reference's randint(1, 4) produces -- so that no input can move an agent off the plan area. */
 int snac_step(const snac_env_desc* desc, const snac_state* st, uint32_t t, const int8_t* actions,
               const int8_t* step_size, int auto_reset, void* obs, float* reward, uint8_t* done, void* stream);
 

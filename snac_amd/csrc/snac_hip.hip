@@ -556,7 +556,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
         if (active) {
             const uint32_t w = rng_word(sk, a.t0 + (uint32_t)t);
             const int act = a.actions ? (int)a.actions[row + lane] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
-            const int k = a.step_size ? (int)a.step_size[row + lane] : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+            const int k = a.step_size ? min(max((int)a.step_size[row + lane], 1), 3) : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
             K::step(lds, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
             s.ep_ret += reward;
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
     if (active) {
         const uint32_t w = rng_word(env_keys(a.key_step, (uint64_t)(a.env_id_base + edge)), a.t0);
         const int act = a.actions ? (int)a.actions[edge] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
-        const int k = a.step_size ? (int)a.step_size[edge] : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+        const int k = a.step_size ? min(max((int)a.step_size[edge], 1), 3) : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
         K::step(lds, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
         s.ep_ret += reward;
         s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void k_import(const IArgs g) {
         s.c = KIND == 1 ? 0 : min(max(g.pos[2 * i + 1], LO), HI);
         s.flags = 0;
         s.cb = min(max(g.cb[i], 0), 32767);
-        s.cs = min(max(g.cs[i], 0), 32000);
+        s.cs = min(max(g.cs[i], 0), 3000);
         s.ep_ret = 0;
         s.cross = min(cross, 32767);
         g.hdr[drow] = s.pack();
@@ -832,7 +832,8 @@ int check_common(const snac_env_desc* d, const snac_state* st) {
     if (d->num_plans <= 0 || d->num_plans > 32767) return fail(SNAC_ERR_ARG, "num_plans out of range");
     if (d->static_plan < 0 || d->static_plan >= d->num_plans) return fail(SNAC_ERR_ARG, "static_plan out of range");
     if (d->obs_dtype != SNAC_OBS_F64 && d->obs_dtype != SNAC_OBS_F32) return fail(SNAC_ERR_ARG, "unknown obs_dtype");
-    if (d->total_step < 0 || d->total_step > 32000) return fail(SNAC_ERR_ARG, "total_step out of range");
+    // the running return is an int16 and a step pays at most 10: 3000 steps cannot overflow it (the reference: <= 1300)
+    if (d->total_step < 0 || d->total_step > 3000) return fail(SNAC_ERR_ARG, "total_step out of range (0..3000)");
     if (d->rules & ~(SNAC_RULE_BRICK_GT | SNAC_RULE_TIME_GT)) return fail(SNAC_ERR_ARG, "unknown bits in rules");
     if (!st->hdr || !st->episode || !st->grid || !st->plans || !st->plan_tb || !st->stat_episodes || !st->stat_return ||
         !st->stat_iou_fx)
