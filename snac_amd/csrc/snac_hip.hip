@@ -80,6 +80,7 @@ struct KArgs {
     uint8_t* first_out;
     // snac_transition only: the state arrays are a node pool of `pool` rows; n = number of transitions
     int32_t pool;
+    int32_t stats_on;          // single-step kernel: update the episodic sums (snac_step) or not (snac_transition)
     const int32_t* src_index;  // row read by transition i (NULL: i)
     const int32_t* dst_index;  // row written by transition i (NULL: i)
     // aux kernel only
@@ -181,6 +182,14 @@ struct K2D {
     __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
         if (lane < GE) lds[P_OFF + lane * RS + e] = ((const uint32_t*)a.plans)[pidx * GE + lane];
     }
+    // the one plan word a single step() can read: the agent's row (fetched early, placed once the tile is loaded)
+    struct PlanCell { uint32_t v; };
+    __device__ static PlanCell fetch_plan_cell(const KArgs& a, const Lane& s) {
+        return PlanCell{((const uint32_t*)a.plans)[s.pidx * GE + (s.r - 3)]};
+    }
+    __device__ static void put_plan_cell(uint32_t* lds, const Lane& s, const PlanCell& pc, int lane) {
+        lds[P_OFF + (s.r - 3) * RS + lane] = pc.v;
+    }
     // reset: DMP_Env_2D_dynamic_usedata_plan.py:34-66 (the total_brick floor of 30 is folded into plan_tb)
     __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
         if (pidx >= 0) { s.pidx = pidx; s.tb = a.plan_tb[pidx]; }    // pidx < 0: the env keeps its plan and total_brick
@@ -264,6 +273,24 @@ struct K3D {
         uint32_t* dst = lds + P_OFF + e * (PS / 2);
 #pragma unroll
         for (int d = lane; d < GE / 2; d += 64) dst[d] = src[d];
+    }
+    // the plan cells a single step() can read: the four build targets around the agent (fetched early, independent of
+    // the action, placed once the tile is loaded)
+    struct PlanCell { int16_t v[4]; };
+    __device__ static int target(const Lane& s, int d) {             // interior index of neighbour d, or -1 on the frame
+        const int tr = s.r + (d == 2 ? 1 : (d == 3 ? -1 : 0)) - 3, tc = s.c + (d == 0 ? -1 : (d == 1 ? 1 : 0)) - 3;
+        return ((unsigned)tr < 20u && (unsigned)tc < 20u) ? tr * 20 + tc : -1;
+    }
+    __device__ static PlanCell fetch_plan_cell(const KArgs& a, const Lane& s) {
+        PlanCell pc;
+        const int16_t* pl = (const int16_t*)a.plans + (size_t)s.pidx * GE;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { const int i = target(s, d); pc.v[d] = pl[max(i, 0)]; }
+        return pc;
+    }
+    __device__ static void put_plan_cell(uint32_t* lds, const Lane& s, const PlanCell& pc, int lane) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { const int i = target(s, d); if (i >= 0) plan(lds)[lane * PS + i] = pc.v[d]; }
     }
     // reset: DMP_simulator_3d_dynamic_triangle_usedata.py:45-75
     __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
@@ -375,6 +402,14 @@ struct K1D {
     }
     __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
         if (lane < GE / 2) lds[P_OFF + e * (ES / 2) + lane] = ((const uint32_t*)((const int16_t*)a.plans + (size_t)pidx * GE))[lane];
+    }
+    // the one plan cell a single step() can read: the agent's column (fetched early, placed once the tile is loaded)
+    struct PlanCell { int16_t v; };
+    __device__ static PlanCell fetch_plan_cell(const KArgs& a, const Lane& s) {
+        return PlanCell{((const int16_t*)a.plans)[(size_t)s.pidx * GE + s.r - 2]};
+    }
+    __device__ static void put_plan_cell(uint32_t* lds, const Lane& s, const PlanCell& pc, int lane) {
+        plan(lds)[lane * ES + s.r - 2] = pc.v;
     }
     // reset: DMP_Env_1D_static.py:66-83, DMP_Env_1D_dynamic_usedata_plan.py:40-70
     __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
@@ -591,7 +626,8 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
 // transition(state, action) of the MCTS variants (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175 and the eight sibling files;
 // caller: script/MCTS/utils/mcts_Qvalue_dynamic.py:88,118): ONE step of the same K::step on an explicit state, batched over
 // a.n tree edges.  The state arrays are a node pool; edge i reads row src_index[i] and writes row dst_index[i] (out of
-// place), the observation / reward / done rows are per edge.  No auto-reset, no episodic sums: a search is not an episode.
+// place), the observation / reward / done rows are per edge.  snac_transition: no auto-reset, no episodic sums (a search
+// is not an episode).  snac_step is the same kernel on the identity rows with both switched on.
 template <class K, typename OT, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
     constexpr int E = K::E;
@@ -609,12 +645,25 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
     int episode = 0;
     const size_t srow = row_of(a.src_index, a.pool, edge), drow = row_of(a.dst_index, a.pool, edge);
     if (active) { s.unpack(a.hdr[srow]); episode = a.episode[srow]; }
+    const uint64_t gid = (uint64_t)(a.env_id_base + edge);
+    // snac_step with auto_reset: an env whose previous step returned done starts a new episode first (as in k_rollout)
+    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+    if (nr) {
+        const int old_pidx = s.pidx, old_tb = s.tb;
+        episode += 1;
+        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode);
+        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    }
+    // one step reads one plan cell (3D: one of four): fetch it now, next to the tile's records, instead of staging plans
+    const typename K::PlanCell pc = K::fetch_plan_cell(a, s);
     K::load_grid(lds, a, env0, nenv, lane, a.src_index);
-    for (int e = 0; e < nenv; ++e) K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane);
+    for (unsigned long long m = __ballot(nr); m; m &= m - 1) K::clear(lds, __ffsll(m) - 1, lane);
+    if (active) K::put_plan_cell(lds, s, pc, lane);
     int reward = 0;
     bool done = false;
     if (active) {
-        const uint32_t w = rng_word(env_keys(a.key_step, (uint64_t)(a.env_id_base + edge)), a.t0);
+        const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
         const int act = a.actions ? (int)a.actions[edge] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
         const int k = a.step_size ? min(max((int)a.step_size[edge], 1), 3) : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
         K::step(lds, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
@@ -622,6 +671,19 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
         s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
         if (a.reward) a.reward[edge] = (float)reward;
         if (a.done) a.done[edge] = done ? 1 : 0;
+    }
+    if (a.stats_on && __any(done)) {                             // snac_step: episodic sums (the IoU needs the whole plan)
+        if constexpr (K::A != 8)
+            for (unsigned long long m = __ballot(done); m; m &= m - 1) {
+                const int e = __ffsll(m) - 1;
+                K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane);
+            }
+        const double v = K::iou(lds, s, lane);
+        if (done) {
+            a.stat_episodes[drow] += 1;
+            a.stat_return[drow] += s.ep_ret;
+            a.stat_iou_fx[drow] += __double2ll_rn(v * FX40);
+        }
     }
     if (a.obs) emit_obs<K, OT>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s, a.total_step, lane);
     K::store_grid(lds, a, env0, nenv, lane, a.dst_index);
@@ -991,9 +1053,10 @@ int snac_step(const snac_env_desc* d, const snac_state* st, uint32_t t, const in
               int auto_reset, void* obs, float* reward, uint8_t* done, void* stream) {
     if (int rc = check_common(d, st)) return rc;
     KArgs a = make_args(d, st);
+    a.pool = d->num_envs; a.stats_on = 1;                        // the single-step kernel on the identity rows
     a.T = 1; a.t0 = t; a.auto_reset = auto_reset ? 1 : 0; a.obs_mode = obs ? SNAC_OBS_ALL : SNAC_OBS_NONE;
     a.actions = actions; a.step_size = step_size; a.obs = obs; a.reward = reward; a.done = done;
-    return launch(OP_ROLLOUT, d, a, stream);
+    return launch(OP_TRANSITION, d, a, stream);
 }
 
 int snac_transition(const snac_env_desc* d, const snac_state* st, int32_t m, const int32_t* src_index, const int32_t* dst_index,
