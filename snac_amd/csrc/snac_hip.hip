@@ -939,17 +939,22 @@ void launch_dt(Op op, int obs_dtype, const KArgs& a, hipStream_t s) {
 int pick_tile(int kind, int n) {
     static const int forced = [] { const char* e = std::getenv("SNAC_TILE"); return e ? std::atoi(e) : 0; }();
     if (kind == SNAC_ENV_3D) return forced == 16 ? 16 : 8;   // 8: 17 KB of LDS per wave, 9 waves per CU; measured +10-15 % over 16
-    if (forced == 16 || forced == 32 || forced == 64) return forced;
-    if (n >= 64 * 1024) return 64;   // >= one wave per SIMD on 256 CUs; measured best at N = 65536 (profiles/)
-    if (n >= 32 * 1024) return 32;
-    return 16;
+    if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
+    // measured per kind (tools/ab_time.py sweeps): 2D wants large tiles early (E x 408-byte store runs),
+    // 1D's 56-byte rows do not care and prefer more, smaller waves
+    const int shift = kind == SNAC_ENV_1D ? 1 : 0;
+    if (n >= (64 * 1024) << shift) return 64;   // 2D: >= one wave per SIMD on 256 CUs; best at N = 65536 (profiles/)
+    if (n >= (32 * 1024) << shift) return 32;
+    if (n >= (16 * 1024) << shift) return 16;
+    return 8;                        // small batches: one-wave blocks of 8 envs, so that 4096 envs still reach every CU
 }
 
 template <template <bool, int> class KT, int WPB>
 void launch_tile(Op op, bool dyn, int E, int obs_dtype, const KArgs& a, hipStream_t s) {
     if (E == 64) dyn ? launch_dt<KT, true, 64, WPB>(op, obs_dtype, a, s) : launch_dt<KT, false, 64, WPB>(op, obs_dtype, a, s);
     else if (E == 32) dyn ? launch_dt<KT, true, 32, WPB>(op, obs_dtype, a, s) : launch_dt<KT, false, 32, WPB>(op, obs_dtype, a, s);
-    else dyn ? launch_dt<KT, true, 16, WPB>(op, obs_dtype, a, s) : launch_dt<KT, false, 16, WPB>(op, obs_dtype, a, s);
+    else if (E == 16) dyn ? launch_dt<KT, true, 16, WPB>(op, obs_dtype, a, s) : launch_dt<KT, false, 16, WPB>(op, obs_dtype, a, s);
+    else dyn ? launch_dt<KT, true, 8, 1>(op, obs_dtype, a, s) : launch_dt<KT, false, 8, 1>(op, obs_dtype, a, s);
 }
 
 int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
@@ -960,7 +965,8 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
         case SNAC_ENV_1D: launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D: launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
-            if (E == 8) dyn ? launch_dt<K3D, true, 8, 4>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 4>(op, d->obs_dtype, a, s);
+            if (E == 8 && a.n < 8192) dyn ? launch_dt<K3D, true, 8, 1>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 1>(op, d->obs_dtype, a, s);
+            else if (E == 8) dyn ? launch_dt<K3D, true, 8, 4>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 4>(op, d->obs_dtype, a, s);
             else dyn ? launch_dt<K3D, true, 16, 2>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 16, 2>(op, d->obs_dtype, a, s);
             break;
     }
