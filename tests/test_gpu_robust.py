@@ -56,3 +56,21 @@ def test_time_limit_above_3000_is_refused():
     with pytest.raises(SnacError, match="total_step"):
         env.reset()
     BatchedDMPEnv(2, True, 8, total_step=3000).reset()
+
+
+def test_step_into_preallocated_outputs():
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    a, b = BatchedDMPEnv(2, True, 1000, seed=6), BatchedDMPEnv(2, True, 1000, seed=6)
+    a.reset(); b.reset()
+    bufs = (torch.empty((1000, 51), dtype=torch.float64, device="cuda"), torch.empty(1000, dtype=torch.float32, device="cuda"),
+            torch.empty(1000, dtype=torch.uint8, device="cuda"))
+    for _ in range(30):
+        o1, r1, d1 = a.step(auto_reset=True)
+        o2, r2, d2 = b.step(auto_reset=True, out=bufs)
+        assert o2.data_ptr() == bufs[0].data_ptr() and torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    with pytest.raises(ValueError):
+        b.step(out=(bufs[0][:10], bufs[1], bufs[2]))
+    with pytest.raises(ValueError):
+        b.step(out=(bufs[0].float(), bufs[1], bufs[2]))
