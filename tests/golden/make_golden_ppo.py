@@ -1,6 +1,10 @@
-"""Golden vectors for the env copies under script/PPO (THIS container only):
+"""Golden vectors for the env copies under script/PPO and script/SAC/environments (THIS container only):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_ppo.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_ppo.py          # -> traj_ppo.npz
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_ppo.py sac      # -> traj_sac.npz
+
+The SAC copies (script/SAC/environments/DMP_*.py) are the PPO ones with a 3-tuple step() (no info) and, for 1D / 2D, without
+gym spaces; same flat observations and the same `>` termination tests (1D dynamic :94, 2D static :133, 3D static :216,:232).
 
 stable-baselines flavoured forks of the six canonical classes: gym spaces, flat observations, 4-tuple step():
 
@@ -37,6 +41,15 @@ FORKS = {
     "3d_static": (3, False, "DMP_simulator_3d_static_circle.py", "deep_mobile_printing_3d1r"),
     "3d_dynamic": (3, True, "DMP_simulator_3d_dynamic_triangle_usedata.py", "deep_mobile_printing_3d1r"),
 }
+SAC_FORKS = {
+    "1d_static": (1, False, "DMP_Env_1D_static.py", "deep_mobile_printing_1d1r"),
+    "1d_dynamic": (1, True, "DMP_Env_1D_dynamic.py", "deep_mobile_printing_1d1r"),
+    "2d_static": (2, False, "DMP_Env_2D_static.py", "deep_mobile_printing_2d1r"),
+    "2d_dynamic": (2, True, "DMP_Env_2D_dynamic.py", "deep_mobile_printing_2d1r"),
+    "3d_static": (3, False, "DMP_simulator_3d_static_circle.py", "deep_mobile_printing_3d1r"),
+    "3d_dynamic": (3, True, "DMP_simulator_3d_dynamic_triangle_usedata.py", "deep_mobile_printing_3d1r"),
+}
+SUITE = "ppo"
 CASES = [
     ("1d_static", 0, "uniform", 1600), ("1d_static", 2, "drop", 1600),
     ("1d_dynamic", ("sin", "train"), "drop", 2400), ("1d_dynamic", ("sin", "val"), "uniform", 1600),
@@ -58,9 +71,10 @@ def install_box_stub():
 
 
 def load(fork):
-    dim, dyn, fn, cname = FORKS[fork]
-    path = os.path.join(_refimport.REF, "script", "PPO", fork, fn)
-    spec = importlib.util.spec_from_file_location("ppo_%s" % fork, path)
+    dim, dyn, fn, cname = (FORKS if SUITE == "ppo" else SAC_FORKS)[fork]
+    path = os.path.join(_refimport.REF, "script", "PPO", fork, fn) if SUITE == "ppo" else os.path.join(
+        _refimport.REF, "script", "SAC", "environments", fn)
+    spec = importlib.util.spec_from_file_location("%s_%s" % (SUITE, fork), path)
     mod = importlib.util.module_from_spec(spec)
     had = hasattr(np, "int")
     if not had:
@@ -83,9 +97,11 @@ def run(fork, plan, mix, n_steps, seed):
     np.random.seed(seed)
     env = cls(data_path=_refimport.dataset_path(dim, *plan), random_choose_paln=True) if dyn else cls(plan_choose=plan)
     restore()
-    assert env.action_space.n == mg.DIMS[dim]["A"]
     D = W + 2 + ((30 if dim == 1 else 400) if dyn else 0)
-    assert env.observation_space.shape == (D,)
+    if SUITE == "ppo" or dim == 3:
+        assert env.action_space.n == mg.DIMS[dim]["A"] and env.observation_space.shape == (D,)
+    else:
+        assert not hasattr(env, "action_space")
     rec = dict(actions=acts.astype(np.int8), step_size=np.zeros(n_steps, np.int8), win=np.zeros((n_steps, W), np.int16),
                sc=np.zeros((n_steps, 2)), reward=np.zeros(n_steps), done=np.zeros(n_steps, np.uint8), pos=np.zeros((n_steps, 2), np.int16))
     starts, finals, ious, tbs, pidx, rwin, rsc, plans = [], [], [], [], [], [], [], []
@@ -106,8 +122,9 @@ def run(fork, plan, mix, n_steps, seed):
 
     reset(0)
     for t in range(n_steps):
-        obs, r, d, info = env.step(int(acts[t]))
-        assert info == {}
+        ret = env.step(int(acts[t]))
+        assert len(ret) == (4 if SUITE == "ppo" else 3) and (SUITE != "ppo" or ret[3] == {})
+        obs, r, d = ret[:3]
         rec["win"][t], rec["sc"][t] = split(obs)
         rec["step_size"][t] = env.step_size
         rec["reward"][t] = float(r)
@@ -126,12 +143,14 @@ def run(fork, plan, mix, n_steps, seed):
 
 
 def main():
+    global SUITE
+    SUITE = "sac" if len(sys.argv) > 1 and sys.argv[1] == "sac" else "ppo"
     _refimport.install_gym_stub()
     _refimport.install_cv2_stub()
     install_box_stub()
     _refimport.load_ref_classes()
     out, names = {}, []
-    seed = 700
+    seed = 700 if SUITE == "ppo" else 1700
     for fork, plan, mix, n in CASES:
         seed += 1
         name = "%s.%s.%s" % (fork, plan if not isinstance(plan, tuple) else "-".join(plan), mix)
@@ -143,7 +162,7 @@ def main():
         print("%-36s episodes %3d lengths %s tb %s rewards %s" % (name, len(lens), lens[:5].tolist(), r["ep_total_brick"][:3].tolist(),
                                                                  sorted(set(r["reward"].tolist()))))
     out["cases"] = np.array(names)
-    fn = os.path.join(HERE, "traj_ppo.npz")
+    fn = os.path.join(HERE, "traj_%s.npz" % SUITE)
     np.savez_compressed(fn, **out)
     print("wrote", fn, os.path.getsize(fn))
 

@@ -9,27 +9,31 @@ import pytest
 
 import helpers
 
-_Z = None
+_Z = {}
 RULES = {"1d_static": (0, 0), "1d_dynamic": (1, 0), "2d_static": (1, 0), "2d_dynamic": (0, 0), "3d_static": (1, 1), "3d_dynamic": (0, 0)}
-FILES = {"1d_static": "DMP_Env_1D_static", "1d_dynamic": "DMP_Env_1D_dynamic_usedata_plan", "2d_static": "DMP_Env_2D_static",
-         "2d_dynamic": "DMP_Env_2d_dynamic_usedata_plan", "3d_static": "DMP_simulator_3d_static_circle",
-         "3d_dynamic": "DMP_simulator_3d_dynamic_triangle_usedata"}
+FILES = {"ppo": {"1d_static": "DMP_Env_1D_static", "1d_dynamic": "DMP_Env_1D_dynamic_usedata_plan", "2d_static": "DMP_Env_2D_static",
+                 "2d_dynamic": "DMP_Env_2d_dynamic_usedata_plan", "3d_static": "DMP_simulator_3d_static_circle",
+                 "3d_dynamic": "DMP_simulator_3d_dynamic_triangle_usedata"},
+         "sac": {"1d_static": "DMP_Env_1D_static", "1d_dynamic": "DMP_Env_1D_dynamic", "2d_static": "DMP_Env_2D_static",
+                 "2d_dynamic": "DMP_Env_2D_dynamic", "3d_static": "DMP_simulator_3d_static_circle",
+                 "3d_dynamic": "DMP_simulator_3d_dynamic_triangle_usedata"}}
 
 
-def _file():
-    global _Z
-    if _Z is None:
-        _Z = np.load(os.path.join(helpers.GOLDEN, "traj_ppo.npz"))
-    return _Z
+def _file(suite):
+    if suite not in _Z:
+        _Z[suite] = np.load(os.path.join(helpers.GOLDEN, "traj_%s.npz" % suite))
+    return _Z[suite]
 
 
 def _names():
-    return _file()["cases"].tolist()
+    """'ppo:<case>' / 'sac:<case>' (script/PPO and script/SAC/environments copies; tests/golden/make_golden_ppo.py)."""
+    return ["%s:%s" % (suite, n) for suite in ("ppo", "sac") for n in _file(suite)["cases"].tolist()]
 
 
 def _rec(name):
-    z = _file()
-    return {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(name + "/")}
+    suite, case = name.split(":")
+    z = _file(suite)
+    return {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(case + "/")}
 
 
 def _replay(name, reset, step, state):
@@ -57,7 +61,7 @@ def _replay(name, reset, step, state):
 @pytest.mark.parametrize("name", _names())
 def test_oracle_replays_ppo_goldens(name):
     orc = helpers.oracle()
-    fork = name.split(".")[0]
+    fork = name.split(":")[1].split(".")[0]
     dim, dyn = int(fork[0]), fork.endswith("dynamic")
     env = orc.OracleEnv(dim, dyn).configure(obs_norm=0, rules_dyn=int(dyn)).set_rules(*RULES[fork])
 
@@ -96,9 +100,10 @@ def test_strict_rules_change_exactly_the_boundary_step():
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------
-def _load(fork):
-    path = os.path.join(helpers.ROOT, "snac_amd", "script", "PPO", fork, FILES[fork] + ".py")
-    spec = importlib.util.spec_from_file_location("ppo_shim_%s" % fork, path)
+def _load(suite, fork):
+    sub = os.path.join("PPO", fork) if suite == "ppo" else os.path.join("SAC", "environments")
+    path = os.path.join(helpers.ROOT, "snac_amd", "script", sub, FILES[suite][fork] + ".py")
+    spec = importlib.util.spec_from_file_location("%s_shim_%s" % (suite, fork), path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return getattr(mod, "deep_mobile_printing_%sd1r" % fork[0])
@@ -107,9 +112,10 @@ def _load(fork):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", _names())
 def test_ppo_facades_on_hip(name):
-    fork, plan = name.split(".")[0], name.split(".")[1]
+    suite, case = name.split(":")
+    fork, plan = case.split(".")[0], case.split(".")[1]
     dim, dyn = int(fork[0]), fork.endswith("dynamic")
-    cls = _load(fork)
+    cls = _load(suite, fork)
     rec0 = _rec(name)
     np.random.seed(int(rec0["seed"]))
     if dyn:
@@ -120,7 +126,10 @@ def test_ppo_facades_on_hip(name):
         env = cls(plan_choose=int(plan))
     W = helpers.DIMS[dim]["W"]
     D = W + 2 + ((30 if dim == 1 else 400) if dyn else 0)
-    assert env.action_space.n == helpers.DIMS[dim]["A"] and env.observation_space.shape == (D,)
+    if suite == "ppo" or dim == 3:
+        assert env.action_space.n == helpers.DIMS[dim]["A"] and env.observation_space.shape == (D,)
+    else:
+        assert not hasattr(env, "action_space") and not hasattr(env, "observation_space")
 
     def tail_ok(o, e, rec):
         if dyn:
@@ -138,8 +147,10 @@ def test_ppo_facades_on_hip(name):
         return o
 
     def step(a, k, t, rec):
-        o, r, d, info = env.step(a)
-        assert info == {} and o.shape == (D,) and env.step_size == k
+        ret = env.step(a)
+        assert len(ret) == (4 if suite == "ppo" else 3) and (suite != "ppo" or ret[3] == {})
+        o, r, d = ret[:3]
+        assert o.shape == (D,) and env.step_size == k
         tail_ok(o, cur["e"], rec)
         return o, r, d
 
