@@ -45,6 +45,29 @@ def main():
         assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
         print("soak %dD %-7s %d envs x %d ticks = %.2e env-steps, %d episodes: every obs / reward / done identical to the oracle (%.0f s)" % (
             dim, "dynamic" if dyn else "static", n, total, n * total, e["episodes"], time.time() - t0), flush=True)
+        # the per-tick API (single-step kernel, auto-reset) and tree-search edges on the same batch
+        ticks = max(200, total // 10)
+        for i in range(ticks):
+            og, rg, dg = env.step(auto_reset=True)
+            oc, rc, dc = orc.step(t + i, auto_reset=True, nthreads=nt)
+            assert og.cpu().numpy().tobytes() == oc.tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes(), (dim, dyn, "step", i)
+            assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+        rng = np.random.default_rng(dim)
+        waves = 200
+        for w in range(waves):
+            m = n // 2
+            src = rng.integers(0, n // 2, m).astype(np.int32)
+            dst = (n // 2 + rng.permutation(n // 2)[:m]).astype(np.int32)
+            acts = rng.integers(0, env.num_actions, m).astype(np.int8)
+            og, rg, dg = env.transition(acts, None, src, dst, t=w)
+            oc, rc, dc = orc.transition(acts, None, src, dst, t=w)
+            assert og.cpu().numpy().tobytes() == oc.tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes(), (dim, dyn, "edge", w)
+            assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+        s = orc.stats()
+        e = env.episodic_stats()
+        assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
+        print("     + %d step() ticks with auto-reset and %d transition waves of %d edges: identical (%.0f s)" % (
+            ticks, waves, n // 2, time.time() - t0), flush=True)
 
 
 if __name__ == "__main__":
