@@ -82,7 +82,68 @@ int main() {
     HIP_OK(hipMemcpy(hs.data(), stats, hs.size() * 8, hipMemcpyDeviceToHost));
     long long eps = 0, eps2 = 0;
     for (int i = 0; i < N; ++i) { eps += hs[i]; eps2 += b->stat_episodes[i]; }
+    if (!(same && eps == eps2)) { std::printf("MISMATCH in the rollout\n"); return 6; }
+
+    // ---- tree search from the same host: the batch as a node pool (snac_transition), reference-format states in and out
+    // (snac_export_grid / snac_import_state), equality_operator (snac_obs_equal) --------------------------------------------
+    const int M = 300;                                  // edges: parents in [0, 300), children written to rows [400, 700)
+    std::vector<int32_t> src(M), dst(M);
+    std::vector<int8_t> acts(M), ks(M);
+    for (int i = 0; i < M; ++i) { src[i] = (i * 7) % 300; dst[i] = 400 + i; acts[i] = (int8_t)(i % 5); ks[i] = (int8_t)(1 + i % 3); }
+    int32_t *d_src, *d_dst;
+    int8_t *d_a, *d_k;
+    uint8_t* d_eq;
+    HIP_OK(hipMalloc((void**)&d_src, M * 4)); HIP_OK(hipMalloc((void**)&d_dst, M * 4));
+    HIP_OK(hipMalloc((void**)&d_a, M)); HIP_OK(hipMalloc((void**)&d_k, M)); HIP_OK(hipMalloc((void**)&d_eq, M));
+    HIP_OK(hipMemcpy(d_src, src.data(), M * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_dst, dst.data(), M * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_a, acts.data(), M, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_k, ks.data(), M, hipMemcpyHostToDevice));
+    SNAC_CHECK(snac_transition(&d, &st, M, d_src, d_dst, 0, d_a, d_k, d_obs, d_rew, d_done, stream));
+    // a child's observation compared with itself and with its neighbour's (equality_operator)
+    std::vector<int32_t> other(M);
+    for (int i = 0; i < M; ++i) other[i] = (i + 1) % M;
+    int32_t* d_other;
+    HIP_OK(hipMalloc((void**)&d_other, M * 4));
+    HIP_OK(hipMemcpy(d_other, other.data(), M * 4, hipMemcpyHostToDevice));
+    SNAC_CHECK(snac_obs_equal(&d, d_obs, nullptr, M, d_obs, d_other, M, M, d_eq, stream));
+    // environment_memory of the children out, and back in as (position, memory, count_brick, count_step) tuples to rows 0..
+    double* d_mem;
+    HIP_OK(hipMalloc((void**)&d_mem, (size_t)N * 676 * 8));
+    SNAC_CHECK(snac_export_grid(&d, &st, d_mem, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    std::vector<double> o3((size_t)M * 51), o4((size_t)M * 51);
+    std::vector<float> r3(M), r4(M);
+    std::vector<uint8_t> d3(M), d4(M), eq(M);
+    HIP_OK(hipMemcpy(o3.data(), d_obs, o3.size() * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(r3.data(), d_rew, M * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(d3.data(), d_done, M, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(eq.data(), d_eq, M, hipMemcpyDeviceToHost));
+    if (orc_batch_transition(b, M, src.data(), dst.data(), 0, acts.data(), ks.data(), o4.data(), r4.data(), d4.data())) return 7;
+    bool ok = std::memcmp(o3.data(), o4.data(), o3.size() * 8) == 0 && std::memcmp(r3.data(), r4.data(), M * 4) == 0 &&
+              std::memcmp(d3.data(), d4.data(), M) == 0;
+    for (int i = 0; i < M && ok; ++i)
+        ok = eq[i] == (std::memcmp(&o4[(size_t)i * 51], &o4[(size_t)other[i] * 51], 51 * 8) == 0 ? 1 : 0);
+    std::vector<snac_env_hdr> hdr(N);
+    HIP_OK(hipMemcpy(hdr.data(), st.hdr, N * sizeof(snac_env_hdr), hipMemcpyDeviceToHost));
+    std::vector<int32_t> pos(2 * M), cb(M), cs(M), pidx(M);
+    for (int i = 0; i < M; ++i) {
+        const snac_env_hdr& h = hdr[dst[i]];
+        const orc_env& e = b->envs[dst[i]];
+        ok = ok && h.pos_r == e.pos[0] && h.pos_c == e.pos[1] && h.count_brick == e.cb && h.count_step == e.cs && h.total_brick == e.tb;
+        pos[2 * i] = h.pos_r; pos[2 * i + 1] = h.pos_c; cb[i] = h.count_brick; cs[i] = h.count_step; pidx[i] = h.plan_idx;
+    }
+    int32_t *d_pos, *d_cb, *d_cs, *d_pidx;
+    HIP_OK(hipMalloc((void**)&d_pos, 2 * M * 4)); HIP_OK(hipMalloc((void**)&d_cb, M * 4));
+    HIP_OK(hipMalloc((void**)&d_cs, M * 4)); HIP_OK(hipMalloc((void**)&d_pidx, M * 4));
+    HIP_OK(hipMemcpy(d_pos, pos.data(), 2 * M * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_cb, cb.data(), M * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_cs, cs.data(), M * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_pidx, pidx.data(), M * 4, hipMemcpyHostToDevice));
+    SNAC_CHECK(snac_import_state(&d, &st, M, nullptr, d_pos, d_cb, d_cs, d_pidx, nullptr, d_mem + (size_t)400 * 676, stream));
+    SNAC_CHECK(snac_observe(&d, &st, d_obs, stream));   // rows 0..M-1 now hold the children: same observations as above
+    HIP_OK(hipStreamSynchronize(stream));
+    std::vector<double> o5((size_t)M * 51);
+    HIP_OK(hipMemcpy(o5.data(), d_obs, o5.size() * 8, hipMemcpyDeviceToHost));
+    ok = ok && std::memcmp(o5.data(), o4.data(), o5.size() * 8) == 0;
     orc_batch_destroy(b);
-    std::printf("%s: %d envs x %d ticks, %lld episodes (oracle %lld)\n", same && eps == eps2 ? "PARITY OK" : "MISMATCH", N, T, eps, eps2);
-    return same && eps == eps2 ? 0 : 6;
+    std::printf("%s: %d envs x %d ticks, %lld episodes (oracle %lld); %d tree edges, import / export, equality\n",
+                ok ? "PARITY OK" : "MISMATCH", N, T, eps, eps2, M);
+    return ok ? 0 : 8;
 }
