@@ -143,3 +143,33 @@ def test_api_argument_checks():
         env.rollout(3, out=torch.empty((3, 4, 51), dtype=torch.float32, device=env.device))
     assert env.input_plan().shape == (4, 20, 20) and env.plan().shape == (4, 26, 26)
     assert env.environment_memory().shape == (4, 26, 26)
+
+
+@pytest.mark.parametrize("kind", [2, 3])
+def test_four_million_envs_in_one_launch_equal_their_shards(kind):
+    """Index arithmetic far beyond the benchmark sizes: 2^22 envs (a 3.4 GB observation tensor per two ticks) stepped in
+    one launch must equal the same global env ids stepped as 8 shards (shard results are oracle-checked at small N)."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    N, S, T = 1 << 22, 8, 2
+    big = BatchedDMPEnv(kind, True, N, seed=77)
+    big.reset()
+    big.rollout(3, obs=None)
+    o, r, d = big.rollout(T)
+    assert o.shape == (T, N, 51)
+    for sh in (0, 3, S - 1):
+        n = N // S
+        part = BatchedDMPEnv(kind, True, n, seed=77, env_id_base=sh * n)
+        part.reset()
+        part.rollout(3, obs=None)
+        po, pr, pd = part.rollout(T)
+        sl = slice(sh * n, (sh + 1) * n)
+        assert torch.equal(po, o[:, sl]) and torch.equal(pr, r[:, sl]) and torch.equal(pd, d[:, sl])
+        assert torch.equal(part._grid, big._grid[sl]) and torch.equal(part._hdr, big._hdr[sl])
+    # the single-step kernel and tree-search edges at the same scale: the last rows of the pool
+    src = torch.arange(N - 4096, N, dtype=torch.int32, device=big.device)
+    acts = torch.zeros(4096, dtype=torch.int8, device=big.device)
+    before = big._hdr[N - 4096:].clone()
+    o1, _, _ = big.transition(acts, None, src, src)
+    assert o1.shape == (4096, 51) and not torch.equal(big._hdr[N - 4096:], before)
