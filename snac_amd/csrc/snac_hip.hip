@@ -1,6 +1,6 @@
 // snac_hip.hip -- gfx950 (MI355X) kernels and the C ABI of include/snac_hip.h.
 //
-// Execution shape (DESIGN.md "Kernel"): one wavefront owns a TILE of E consecutive envs (E = 16/32/64; 3D: 8/16).
+// Execution shape (DESIGN.md "Kernel"): one wavefront owns a TILE of E consecutive envs (E = 8/16/32/64 by batch size; 3D: 8).
 //   phase 1  lane l steps env (tile base + l): counter RNG, move / drop / build transition, reward, done,
 //            auto-reset, episodic sums -- plain per-lane VALU code, the env grids live in this wave's LDS
 //   phase 2  the whole wave writes the tile's observations: for each env, lanes 0..48 fetch one window cell
