@@ -543,7 +543,10 @@ __device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, cons
 }
 
 // T fused vector steps (T = 1: one step() call) for one tile of E envs per wave.
-template <class K, typename OT, int WPB>
+// EXPL: actions and / or step sizes come from the caller's arrays.  The counter-RNG instantiation (EXPL = false) has no
+// global load in its loop at all: with the null tests at run time the compiler joins both paths behind one
+// `s_waitcnt vmcnt(0)`, and vmcnt counts the observation stores too -- every tick would wait for the previous tick's rows.
+template <class K, typename OT, int WPB, bool EXPL>
 __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
     constexpr int E = K::E;
     const int lane = threadIdx.x & 63;
@@ -590,8 +593,11 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
         }
         if (active) {
             const uint32_t w = rng_word(sk, a.t0 + (uint32_t)t);
-            const int act = a.actions ? (int)a.actions[row + lane] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
-            const int k = a.step_size ? min(max((int)a.step_size[row + lane], 1), 3) : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+            int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+            if constexpr (EXPL) {
+                if (a.actions) act = (int)a.actions[row + lane];
+                if (a.step_size) k = min(max((int)a.step_size[row + lane], 1), 3);
+            }
             K::step(lds, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
             s.ep_ret += reward;
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
@@ -924,7 +930,10 @@ template <class K, typename OT, int WPB>
 void launch_k(Op op, const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + K::E - 1) / K::E;
     const dim3 grid((unsigned)((tiles + WPB - 1) / WPB)), block(WPB * 64);
-    if (op == OP_ROLLOUT) hipLaunchKernelGGL((k_rollout<K, OT, WPB>), grid, block, 0, s, a);
+    if (op == OP_ROLLOUT) {
+        if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout<K, OT, WPB, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_rollout<K, OT, WPB, false>), grid, block, 0, s, a);
+    }
     else if (op == OP_TRANSITION) hipLaunchKernelGGL((k_transition<K, OT, WPB>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_aux<K, OT, WPB>), grid, block, 0, s, a);
 }
