@@ -103,3 +103,37 @@ class ReplayRing:
         slot = (self.head - 1 - age) % self.cap
         env_index = torch.randint(0, self.env.num_envs, (batch,), device=dev, generator=generator)
         return self.gather(slot, env_index, with_plan=with_plan)
+
+    def sample_sequences(self, batch, time_step, generator=None, with_plan=True, oversample=4):
+        """DRQN-style minibatch (Memory.get_batch of script/DRQN/2d/DRQN_2D_dynamic_training.py:131-143): `batch` windows of
+        `time_step` consecutive transitions of one env that lie inside ONE episode -> dict of tensors
+        s / s_next [B, L, D] float32, action / reward / done [B, L], plan [B, 20, 20] (1D: [B, 30]).
+        Windows are drawn uniformly over all valid windows in the ring (the reference draws an episode first, then a
+        window inside it, so it favours short episodes; neither is a parity surface -- the reference uses python's
+        `random`).  Candidates are drawn `oversample` x batch at a time and filtered on the device."""
+        L, B = int(time_step), int(batch)
+        v = self.valid_ticks()
+        if L < 1 or v < L:
+            raise ValueError("time_step must be in [1, valid_ticks()]")
+        dev, N = self.env.device, self.env.num_envs
+        steps = torch.arange(L, device=dev)
+        got_slot, got_env, have = [], [], 0
+        for _ in range(64):
+            n = max(B * oversample, 64)
+            age = torch.randint(L - 1, v, (n,), device=dev, generator=generator)        # age of the window's FIRST transition
+            env_index = torch.randint(0, N, (n,), device=dev, generator=generator)
+            slots = (self.head - 1 - age[:, None] + steps[None, :]) % self.cap            # [n, L], oldest first
+            inside = self.first[slots[:, 1:], env_index[:, None]].sum(dim=1) == 0 if L > 1 else torch.ones(n, dtype=torch.bool, device=dev)
+            got_slot.append(slots[inside]); got_env.append(env_index[inside])
+            have += int(inside.sum())
+            if have >= B:
+                break
+        if have < B:
+            raise ValueError("no episode in the ring holds %d consecutive steps" % L)
+        slots, env_index = torch.cat(got_slot)[:B], torch.cat(got_env)[:B]
+        flat = self.gather(slots.reshape(-1), env_index[:, None].expand(B, L).reshape(-1), with_plan=False)
+        out = {k: t.view(B, L, *t.shape[1:]) for k, t in flat.items()}
+        if with_plan:
+            out["plan"] = self.gather(slots[:, 0], env_index, with_plan=True)["plan"]
+        out["slot"], out["env"] = slots, env_index
+        return out

@@ -122,3 +122,35 @@ def test_snapshot_restore_and_fork():
         assert torch.equal(env.environment_memory()[p], child.environment_memory()[j])
     with pytest.raises(ValueError):
         BatchedDMPEnv(3, True, 8).load_state_dict(sd)
+
+
+@pytest.mark.parametrize("kind", [(2, True), (3, True)], ids=str)
+def test_sequence_sampling_stays_inside_one_episode(kind):
+    """DRQN-style windows (Memory.get_batch, script/DRQN/2d/DRQN_2D_dynamic_training.py:131-143): every window is L consecutive
+    transitions of one env within one episode, and its tuples are the reference's (chained: s[j+1] == s_next[j])."""
+    import torch
+    from snac_amd import BatchedDMPEnv, ReplayRing
+
+    dim, dyn = kind
+    n, cap, L, B = 64, 96, 8, 500
+    env = BatchedDMPEnv(dim, dyn, n, seed=12)
+    env.reset()
+    ring = ReplayRing(env, cap)
+    ring.collect(cap)
+    ring.collect(40)                                              # wrapped: windows may cross the physical end of the ring
+    g = torch.Generator(device="cuda").manual_seed(1)
+    out = ring.sample_sequences(B, L, generator=g)
+    assert out["s"].shape == (B, L, env.obs_dim) and out["action"].shape == (B, L) and out["done"].shape == (B, L)
+    slots, ei = out["slot"], out["env"]
+    assert torch.equal((slots[:, 1:] - slots[:, :-1]) % cap, torch.ones((B, L - 1), dtype=slots.dtype, device=slots.device))
+    first = ring.first[slots, ei[:, None]]
+    assert int(first[:, 1:].sum()) == 0                          # no episode starts inside a window ...
+    assert not bool(out["done"][:, :-1].any())                   # ... so only the last step may be terminal
+    assert torch.equal(out["s"][:, 1:], out["s_next"][:, :-1])   # consecutive tuples chain
+    flat = ring.gather(slots.reshape(-1), ei[:, None].expand(B, L).reshape(-1), with_plan=False)
+    assert torch.equal(flat["s_next"].view(B, L, -1), out["s_next"]) and torch.equal(flat["reward"].view(B, L), out["reward"])
+    assert torch.equal(out["plan"], ring.gather(slots[:, 0], ei)["plan"])
+    oldest = (ring.head - ring.valid_ticks()) % cap
+    assert bool((((slots - oldest) % cap) < ring.valid_ticks()).all())          # only addressable slots
+    with pytest.raises(ValueError):
+        ring.sample_sequences(8, cap + 1)
