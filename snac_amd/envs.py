@@ -522,3 +522,18 @@ class deep_mobile_printing_3d1r_dynamic(_Env3D):
     def step(self, action):
         obs, reward, done, pos = self._grid_step(action)
         return [obs, self.input_plan, pos], reward, done
+
+
+class deep_mobile_printing_3d1r_hindsight_dynamic(deep_mobile_printing_3d1r_dynamic):
+    """Env/3D/DMP_simulator_3d_dynamic_triangle_hindsight_replay.py :: deep_mobile_printing_3d1r_hindsight(data_path,
+    random_choose_paln=True) -- the dataset class with step(action, step_size); reset() returns [obs with the RAW counters,
+    input_plan] (:71-73) while step() keeps the canonical normalised 3-list (:199-228)"""
+
+    def reset(self):
+        obs, plan, _ = deep_mobile_printing_3d1r_dynamic.reset(self)
+        return [obs, plan]                                       # both counters are 0 at reset: raw == normalised
+
+    def step(self, action, step_size):
+        self._sync_plan()
+        obs, reward, done, pos = self._grid_step(action, step_size)
+        return [obs, self.input_plan, pos], reward, done

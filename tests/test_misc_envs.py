@@ -1,0 +1,120 @@
+"""Remaining Env/ modules: the 3D dynamic hindsight class (step(action, step_size) on dataset plans) and the three
+*_static_test.py modules the reference's test scripts import (canonical dynamics, another render()).  Goldens recorded by
+tests/golden/make_golden_misc.py, replayed through the oracle (CPU) and, from np.random.seed alone, the drop-in classes (GPU)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+
+_Z = None
+
+
+def _file():
+    global _Z
+    if _Z is None:
+        _Z = np.load(os.path.join(helpers.GOLDEN, "traj_misc.npz"))
+    return _Z
+
+
+def _names():
+    return _file()["cases"].tolist()
+
+
+def _rec(name):
+    z = _file()
+    return {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(name + "/")}
+
+
+def _kind(name):
+    if name.startswith("3dhd"):
+        return 3, True
+    return int(name[4]), False
+
+
+def _replay(name, reset, step, state):
+    rec = _rec(name)
+    starts = dict((int(s), e) for e, s in enumerate(rec["ep_start"]))
+    S = len(rec["actions"])
+    for t in range(S):
+        if t in starts:
+            e = starts[t]
+            o = np.asarray(reset(e, rec), np.float64).reshape(-1)
+            assert o.tobytes() == np.concatenate([rec["ep_reset_win"][e].astype(np.float64), rec["ep_reset_sc"][e]]).tobytes()
+        o, r, d = step(int(rec["actions"][t]), int(rec["step_size"][t]))
+        want = np.concatenate([rec["win"][t].astype(np.float64), rec["sc"][t]])
+        assert np.asarray(o, np.float64).reshape(-1).tobytes() == want.tobytes(), (name, t)
+        assert r == rec["reward"][t] and bool(d) == bool(rec["done"][t]), (name, t)
+        if (t + 1) in starts or t == S - 1:
+            e = starts[t + 1] - 1 if (t + 1) in starts else len(rec["ep_start"]) - 1
+            grid, iou = state()
+            assert np.array_equal(np.asarray(grid).reshape(-1), rec["ep_final_grid"][e].astype(np.float64))
+            assert np.float64(iou).tobytes() == np.float64(rec["ep_iou"][e]).tobytes()
+
+
+@pytest.mark.parametrize("name", _names())
+def test_oracle_replays_misc_goldens(name):
+    orc = helpers.oracle()
+    dim, dyn = _kind(name)
+    env = orc.OracleEnv(dim, dyn)
+    if dyn:
+        dens, split = name.split(".")[1].split("-")
+        table = helpers.plan_table(3, True, "%s_%s" % (dens, split))
+    else:
+        table = orc.static_plan(dim, int(name.split(".")[1][1:]))[None]
+
+    def reset(e, rec):
+        o = env.reset(table[rec["ep_plan_idx"][e]].reshape(-1), int(rec["ep_plan_idx"][e]))
+        assert env.e.tb == rec["ep_total_brick"][e]
+        return o                                                  # both counters 0: raw == normalised
+
+    _replay(name, reset, lambda a, k: env.step(a, k), lambda: (env.grid.astype(np.float64), env.iou()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", _names())
+def test_misc_facades_on_hip(name):
+    dim, dyn = _kind(name)
+    sub = "%dD" % dim
+    path = os.path.join(helpers.ROOT, "snac_amd", "Env", sub)
+    if path not in sys.path:
+        sys.path.append(path)
+    rec0 = _rec(name)
+    np.random.seed(int(rec0["seed"]))
+    if dyn:
+        cls = getattr(importlib.import_module("DMP_simulator_3d_dynamic_triangle_hindsight_replay"), "deep_mobile_printing_3d1r_hindsight")
+        dens, split = name.split(".")[1].split("-")
+        env = cls(data_path="/nonexistent/data_3d_dynamic_%s_envplan_500_%s.pkl" % (dens, split), random_choose_paln=True)
+
+        def reset(e, rec):
+            obs = env.reset()
+            assert len(obs) == 2 and obs[1] is env.input_plan and env.index_random == rec["ep_plan_idx"][e]
+            assert int(env.total_brick) == rec["ep_total_brick"][e]
+            return obs[0]
+
+        def step(a, k):
+            obs, r, d = env.step(a, k)
+            assert len(obs) == 3 and obs[1] is env.input_plan and list(obs[2]) == list(env.position_memory[-1]) and env.step_size == k
+            return obs[0], r, d
+    else:
+        mod = {1: "DMP_Env_1D_static_test", 2: "DMP_Env_2D_static_test", 3: "DMP_simulator_3d_static_circle_test"}[dim]
+        env = getattr(importlib.import_module(mod), "deep_mobile_printing_%dd1r" % dim)(plan_choose=int(name.split(".")[1][1:]))
+
+        def reset(e, rec):
+            return env.reset()
+
+        def step(a, k):
+            obs, r, d = env.step(a)
+            assert env.step_size == k and env.count_brick >= 0     # the *_test spelling exists in 1D too
+            return obs, r, d
+
+    def iou():
+        if dim != 2:
+            return env.iou()
+        g, p = env.environment_memory[3:23, 3:23], env.plan[3:23, 3:23]
+        return float(np.sum(np.logical_and(g, p)) / np.sum(np.logical_or(g, p)))
+
+    _replay(name, reset, step, lambda: (env.environment_memory, iou()))
