@@ -537,3 +537,31 @@ class deep_mobile_printing_3d1r_hindsight_dynamic(deep_mobile_printing_3d1r_dyna
         self._sync_plan()
         obs, reward, done, pos = self._grid_step(action, step_size)
         return [obs, self.input_plan, pos], reward, done
+
+
+class deep_mobile_printing_2d1r_hindsight_dynamic(deep_mobile_printing_2d1r_dynamic):
+    """Env/2D/DMP_Env_2D_dynamic_hindsight_replay_usedata.py :: deep_mobile_printing_2d1r_hindsight(data_path,
+    random_choose_paln=True) -- the dataset class with raw counters in every observation and step(action, step_size).
+
+    PARITY UNPINNED for this class: the reference's reset() first rasterises a random triangle with cv2 (create_plan, :37-59)
+    and throws it away (:61-64); cv2 is not available where the goldens are recorded, so no golden exists, and the number
+    of np.random draws that throw-away plan costs depends on the rasteriser.  This class skips it: the dynamics are the
+    pinned 2D dataset dynamics, but a seeded script sees a different np.random stream than with the reference."""
+
+    def create_plan(self):
+        raise NotImplementedError("the reference's random-triangle rasteriser needs cv2 (and its result is discarded by reset())")
+
+    def _raw(self, obs):
+        o = np.array(obs, np.float64)
+        o[0, -2], o[0, -1] = self.count_brick, self.count_step
+        return o
+
+    def reset(self):
+        obs, plan, pos = deep_mobile_printing_2d1r_dynamic.reset(self)
+        self.plan_choose = 0
+        return [self._raw(obs), plan, pos]
+
+    def step(self, action, step_size):
+        self._sync_plan()
+        obs, reward, done, pos = self._grid_step(action, step_size)
+        return [self._raw(obs), self.input_plan, pos], reward, done

@@ -118,3 +118,33 @@ def test_misc_facades_on_hip(name):
         return float(np.sum(np.logical_and(g, p)) / np.sum(np.logical_or(g, p)))
 
     _replay(name, reset, step, lambda: (env.environment_memory, iou()))
+
+
+@pytest.mark.gpu
+def test_2d_dynamic_hindsight_class_against_the_oracle():
+    """Env/2D/DMP_Env_2D_dynamic_hindsight_replay_usedata.py cannot run where goldens are recorded (cv2): its drop-in is
+    checked against the oracle only -- the pinned 2D dataset dynamics with raw counters and caller-supplied step sizes."""
+    path = os.path.join(helpers.ROOT, "snac_amd", "Env", "2D")
+    if path not in sys.path:
+        sys.path.append(path)
+    cls = getattr(importlib.import_module("DMP_Env_2D_dynamic_hindsight_replay_usedata"), "deep_mobile_printing_2d1r_hindsight")
+    orc = helpers.oracle()
+    table = helpers.plan_table(2, True, "sparse_val")
+    np.random.seed(3)
+    env = cls(data_path="/nonexistent/data_2d_dynamic_sparse_envplan_500_val.pkl", random_choose_paln=True)
+    ref = orc.OracleEnv(2, True).configure(obs_norm=0, rules_dyn=1)
+    rng = np.random.default_rng(5)
+    obs = env.reset()
+    o = ref.reset(table[env.index_random], env.index_random)
+    assert len(obs) == 3 and obs[0].tobytes() == o.reshape(1, -1).tobytes() and int(env.total_brick) == ref.e.tb
+    for t in range(1500):
+        a, k = int(rng.integers(0, 5)) if rng.random() > 0.4 else 4, int(rng.integers(1, 4))
+        obs, r, d = env.step(a, k)
+        o, r2, d2 = ref.step(a, k)
+        assert obs[0].tobytes() == o.reshape(1, -1).tobytes() and r == r2 and d == d2 and list(obs[2]) == list(ref.pos)
+        if d:
+            obs = env.reset()
+            o = ref.reset(table[env.index_random], env.index_random)
+            assert obs[0].tobytes() == o.reshape(1, -1).tobytes()
+    with pytest.raises(NotImplementedError):
+        env.create_plan()
