@@ -67,6 +67,11 @@ class ReplayRing:
             self.ticks += n
             done_ticks += n
 
+    def append(self, actions, step_size=None):
+        """One vector step with the caller's actions ([N], e.g. an epsilon-greedy policy's), appended to the ring."""
+        actions = torch.as_tensor(actions, device=self.env.device)
+        self.collect(1, actions=actions.reshape(1, -1), step_size=None if step_size is None else torch.as_tensor(step_size).reshape(1, -1))
+
     def slots(self):
         """Ring slots that hold addressable transitions, oldest first (int64 tensor on the device)."""
         v = self.valid_ticks()
