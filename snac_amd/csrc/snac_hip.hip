@@ -97,6 +97,11 @@ constexpr double FX40 = 1099511627776.0;  // 2^40
 __device__ __forceinline__ size_t row_of(const int32_t* idx, int pool, int i) {
     return idx ? (size_t)min(max(idx[i], 0), pool - 1) : (size_t)i;
 }
+// the same inside the cooperative tile loops: the rows of the tile's elements are staged in LDS once (rows[e]) instead of
+// one more global load per element
+__device__ __forceinline__ size_t tile_row(const int* rows, int env0, int e) {
+    return rows ? (size_t)rows[e] : (size_t)(env0 + e);
+}
 
 // per-lane env scalars (one env per lane in phase 1)
 struct Lane {
@@ -162,21 +167,21 @@ struct K2D {
         const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
         return squeeze16((lo >> 6) & 0x01555555u) | (squeeze16(hi & 0x1555u) << 13);
     }
-    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
+    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int* rows = nullptr) {
         uint64_t* c = cells(lds);
         for (int i = lane; i < 3 * RS; i += 64) { c[i] = 0x000FFFFFFFFFFFFFull; c[23 * RS + i] = 0x000FFFFFFFFFFFFFull; }
         const uint32_t* src = (const uint32_t*)a.grid;
         for (int i = lane; i < nenv * GE; i += 64) {
             const int e = i / GE, row = i - e * GE;
-            c[(row + 3) * RS + e] = encode_row(src[row_of(idx, a.pool, env0 + e) * GE + row]);
+            c[(row + 3) * RS + e] = encode_row(src[tile_row(rows, env0, e) * GE + row]);
         }
     }
-    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
+    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int* rows = nullptr) {
         const uint64_t* c = cells(lds);
         uint32_t* dst = (uint32_t*)a.grid;
         for (int i = lane; i < nenv * GE; i += 64) {
             const int e = i / GE, row = i - e * GE;
-            dst[row_of(idx, a.pool, env0 + e) * GE + row] = decode_row(c[(row + 3) * RS + e]);
+            dst[tile_row(rows, env0, e) * GE + row] = decode_row(c[(row + 3) * RS + e]);
         }
     }
     __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
@@ -251,21 +256,21 @@ struct K3D {
     __device__ static int16_t* hmap(uint32_t* lds) { return (int16_t*)lds; }
     __device__ static int16_t* plan(uint32_t* lds) { return (int16_t*)(lds + P_OFF); }
 
-    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
+    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int* rows = nullptr) {
         for (int i = lane; i < E * ES / 2; i += 64) lds[i] = 0xFFFFFFFFu;            // everything frame (-1) ...
         const int16_t* src = (const int16_t*)a.grid;
         int16_t* h = hmap(lds);
         for (int i = lane; i < nenv * GE; i += 64) {                                  // ... then the interiors
             const int e = i / GE, cell = i - e * GE, r = cell / 20, c = cell - r * 20;
-            h[e * ES + (r + 3) * 26 + c + 3] = src[row_of(idx, a.pool, env0 + e) * GE + cell];
+            h[e * ES + (r + 3) * 26 + c + 3] = src[tile_row(rows, env0, e) * GE + cell];
         }
     }
-    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
+    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int* rows = nullptr) {
         int16_t* dst = (int16_t*)a.grid;
         const int16_t* h = hmap(lds);
         for (int i = lane; i < nenv * GE; i += 64) {
             const int e = i / GE, cell = i - e * GE, r = cell / 20, c = cell - r * 20;
-            dst[row_of(idx, a.pool, env0 + e) * GE + cell] = h[e * ES + (r + 3) * 26 + c + 3];
+            dst[tile_row(rows, env0, e) * GE + cell] = h[e * ES + (r + 3) * 26 + c + 3];
         }
     }
     __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
@@ -383,21 +388,21 @@ struct K1D {
     __device__ static double* sc(uint32_t* lds) { return (double*)(lds + SC_OFF); }
     __device__ static int* pos(uint32_t* lds) { return (int*)(lds + SC_OFF + 4 * E); }
 
-    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
+    __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int* rows = nullptr) {
         for (int i = lane; i < E * ES / 2; i += 64) lds[i] = 0xFFFFFFFFu;
         const int16_t* src = (const int16_t*)a.grid;
         int16_t* h = hmap(lds);
         for (int i = lane; i < nenv * GE; i += 64) {
             const int e = i / GE, cell = i - e * GE;
-            if (cell < 30) h[e * ES + cell + 2] = src[row_of(idx, a.pool, env0 + e) * GE + cell];
+            if (cell < 30) h[e * ES + cell + 2] = src[tile_row(rows, env0, e) * GE + cell];
         }
     }
-    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int32_t* idx = nullptr) {
+    __device__ static void store_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int* rows = nullptr) {
         int16_t* dst = (int16_t*)a.grid;
         const int16_t* h = hmap(lds);
         for (int i = lane; i < nenv * GE; i += 64) {
             const int e = i / GE, cell = i - e * GE;
-            dst[row_of(idx, a.pool, env0 + e) * GE + cell] = cell < 30 ? h[e * ES + cell + 2] : (int16_t)0;
+            dst[tile_row(rows, env0, e) * GE + cell] = cell < 30 ? h[e * ES + cell + 2] : (int16_t)0;
         }
     }
     __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
@@ -663,7 +668,9 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
     }
     // one step reads one plan cell (3D: one of four): fetch it now, next to the tile's records, instead of staging plans
     const typename K::PlanCell pc = K::fetch_plan_cell(a, s);
-    K::load_grid(lds, a, env0, nenv, lane, a.src_index);
+    int* const rows = (int*)K::sc(lds);                          // free until write_scalars: the tile's gather / scatter rows
+    if (a.src_index && active) rows[lane] = (int)srow;
+    K::load_grid(lds, a, env0, nenv, lane, a.src_index ? rows : nullptr);
     for (unsigned long long m = __ballot(nr); m; m &= m - 1) K::clear(lds, __ffsll(m) - 1, lane);
     if (active) K::put_plan_cell(lds, s, pc, lane);
     int reward = 0;
@@ -692,7 +699,8 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
         }
     }
     if (a.obs) emit_obs<K, OT>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s, a.total_step, lane);
-    K::store_grid(lds, a, env0, nenv, lane, a.dst_index);
+    if (a.dst_index && active) rows[lane] = (int)drow;           // the scalar slots have been written out by now
+    K::store_grid(lds, a, env0, nenv, lane, a.dst_index ? rows : nullptr);
     if (active) { a.hdr[drow] = s.pack(); a.episode[drow] = episode; }
 }
 
