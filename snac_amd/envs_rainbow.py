@@ -1,0 +1,184 @@
+"""The env copies under script/Rainbow/env of the reference (Env1D.py, Env2D.py, Env3D.py: six classes configured by an
+`args` namespace).  Same HIP path as snac_amd.envs; the differences are host-side layout plus the rule bits of the kernel:
+
+  Env1DStatic(args)                    (1, 7) raw counters; brick test `>` (Env1D.py:135)
+  Env1DDynamic(args, data_path, ...)   (1, 7) raw counters; brick test `>` (:317)
+  Env2DStatic(args)                    (1, 51); brick test `>` (Env2D.py:166)
+  Env2DDynamic(args, data_path, ...)   (451, 1) column [window 49, count_brick, count_step, input_plan 400]
+  Env3DStatic(args)                    (1, 51); brick test `>` (Env3D.py:234), time test `>` (:257); an over-built cell pays
+                                       -0.01 instead of -1 (:267) -- mapped on the host, the kernel's rewards are integers
+  Env3DDynamic(args, data_path, ...)   (451,)
+args.uniform_step (the four classes that read it): the step size is 1 and np.random is not touched; otherwise one
+np.random.randint(1, 4) per step as everywhere.  args.plan_choose None means 0.  Shims: snac_amd/script/Rainbow/env/.
+"""
+from collections import deque
+
+import numpy as np
+
+from .envs import (deep_mobile_printing_1d1r_dynamic, deep_mobile_printing_1d1r_static, deep_mobile_printing_2d1r_dynamic,
+                   deep_mobile_printing_2d1r_static, deep_mobile_printing_3d1r_dynamic, deep_mobile_printing_3d1r_static)
+
+
+class _Rainbow(object):
+    _brick_gt = True
+    _uniform_ok = True           # the class reads args.uniform_step
+
+    def _rb_init(self, args, window_cells):
+        self._args = args
+        self.window = args.history_length
+        self.uniform_step = bool(args.uniform_step) if self._uniform_ok else False
+        self.state_buffer = deque([], maxlen=self.window)
+        self.features = window_cells + 1
+
+    def get_features(self):
+        return self.features
+
+    def action_space(self):
+        return self.action_dim
+
+    def _reset_buffer(self):
+        import torch
+
+        for _ in range(self.window):
+            self.state_buffer.append(torch.zeros(1, self.HALF_WINDOW_SIZE * 2 + 3))
+
+    def _k(self):
+        return 1 if self.uniform_step else None                  # None: _do_step draws np.random.randint(1, 4)
+
+    def _raw(self, obs):
+        o = np.array(obs, np.float64).reshape(1, -1)
+        o[0, -2], o[0, -1] = self.count_brick, self.count_step
+        return o
+
+    def _iou(self):
+        return self.iou()
+
+    def _rebuild(self, plan_choose):
+        """set_plan_choose: the plan table lives on the device, so the env is rebuilt around the new static plan."""
+        import types
+
+        a = types.SimpleNamespace(**vars(self._args))
+        a.plan_choose = plan_choose
+        self.__init__(a)
+
+
+def _plan_choose(args):
+    return args.plan_choose if args.plan_choose is not None else 0
+
+
+class Env1DStatic(_Rainbow, deep_mobile_printing_1d1r_static):
+    """script/Rainbow/env/Env1D.py :: Env1DStatic(args)"""
+
+    def __init__(self, args):
+        deep_mobile_printing_1d1r_static.__init__(self, _plan_choose(args))
+        self.create_plan()
+        self._rb_init(args, 5)
+
+    def set_plan_choose(self, plan_choose):
+        self._rebuild(plan_choose)
+
+    def reset(self):
+        self._reset_buffer()
+        return deep_mobile_printing_1d1r_static.reset(self)
+
+    def step(self, action):
+        if not 0 <= int(action) < 3:
+            # the reference starts from position = -1 (:113): the window slice is empty and the observation is (1, 2)
+            self.step_size = 1 if self.uniform_step else int(np.random.randint(1, 4))
+            try:
+                deep_mobile_printing_1d1r_static.step(self, action, self.step_size)
+            except UnboundLocalError:
+                pass
+            return np.array([[float(self.count_brick), float(self.count_step)]]), 0, bool(self.count_step >= self.total_step)
+        return deep_mobile_printing_1d1r_static.step(self, action, self._k())
+
+
+class Env1DDynamic(_Rainbow, deep_mobile_printing_1d1r_dynamic):
+    """script/Rainbow/env/Env1D.py :: Env1DDynamic(args, data_path, random_choose_paln=True)"""
+
+    def __init__(self, args, data_path, random_choose_paln=True):
+        deep_mobile_printing_1d1r_dynamic.__init__(self, data_path, random_choose_paln)
+        self._rb_init(args, 5)
+
+    def reset(self):
+        self._reset_buffer()
+        return self._raw(deep_mobile_printing_1d1r_dynamic.reset(self)[1])
+
+    def step(self, action):
+        obs, reward, done, (r, _) = self._do_step(action, self._k())
+        self._after_step(action, r)
+        return self._raw(obs), reward, done
+
+
+class Env2DStatic(_Rainbow, deep_mobile_printing_2d1r_static):
+    """script/Rainbow/env/Env2D.py :: Env2DStatic(args)"""
+
+    def __init__(self, args):
+        deep_mobile_printing_2d1r_static.__init__(self, _plan_choose(args))
+        self.plan, self.total_brick = self.create_plan()
+        self.state_dim = (args.half_window_size * 2 + 1) ** 2 + 2
+        self._rb_init(args, 49)
+
+    def set_plan_choose(self, plan_choose):
+        self._rebuild(plan_choose)
+
+    def reset(self):
+        self._reset_buffer()
+        return deep_mobile_printing_2d1r_static.reset(self)
+
+    def step(self, action):
+        return deep_mobile_printing_2d1r_static.step(self, action, self._k())
+
+
+class Env2DDynamic(_Rainbow, deep_mobile_printing_2d1r_dynamic):
+    """script/Rainbow/env/Env2D.py :: Env2DDynamic(args, data_path, random_choose_paln=True): canonical `>=` tests"""
+    _brick_gt = False
+    _uniform_ok = False
+
+    def __init__(self, args, data_path, random_choose_paln=True):
+        deep_mobile_printing_2d1r_dynamic.__init__(self, data_path, random_choose_paln)
+        self.features = 51 - 1
+
+    def _col(self, obs):
+        return np.hstack((self._raw(obs).reshape(-1), np.asarray(self.input_plan, np.float64).reshape(-1))).reshape((-1, 1))
+
+    def reset(self):
+        return self._col(deep_mobile_printing_2d1r_dynamic.reset(self)[0])
+
+    def step(self, action):
+        obs, reward, done = deep_mobile_printing_2d1r_dynamic.step(self, action)
+        return self._col(obs[0]), reward, done
+
+
+class Env3DStatic(_Rainbow, deep_mobile_printing_3d1r_static):
+    """script/Rainbow/env/Env3D.py :: Env3DStatic(args)"""
+    _time_gt = True
+
+    def __init__(self, args):
+        deep_mobile_printing_3d1r_static.__init__(self, _plan_choose(args))
+        self.plan, self.total_brick = self.create_plan()
+        self._rb_init(args, 49)
+
+    def step(self, action):
+        obs, reward, done = deep_mobile_printing_3d1r_static.step(self, action, self._k())
+        return obs, (-0.01 if reward == -1.0 else reward), done   # reward_check :266-272
+
+
+class Env3DDynamic(_Rainbow, deep_mobile_printing_3d1r_dynamic):
+    """script/Rainbow/env/Env3D.py :: Env3DDynamic(args, data_path, random_choose_paln=True): canonical `>=` tests"""
+    _brick_gt = False
+    _uniform_ok = False
+
+    def __init__(self, args, data_path, random_choose_paln=True):
+        deep_mobile_printing_3d1r_dynamic.__init__(self, data_path, random_choose_paln)
+        self.features = 51 - 1
+
+    def _flat(self, obs):
+        return np.hstack((self._raw(obs), np.asarray(self.input_plan, np.float64).reshape(1, -1))).squeeze()
+
+    def reset(self):
+        return self._flat(deep_mobile_printing_3d1r_dynamic.reset(self)[0])
+
+    def step(self, action):
+        obs, reward, done = deep_mobile_printing_3d1r_dynamic.step(self, action)
+        return self._flat(obs[0]), reward, done
