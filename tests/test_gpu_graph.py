@@ -1,6 +1,5 @@
 """GPU: the per-tick step() launch is hipGraph-capturable (no allocation, sync or host read inside the C ABI call), so a
 launch-bound policy loop can be replayed as a graph.  Inputs are static device tensors refilled between replays."""
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu

@@ -1,6 +1,5 @@
 """GPU: inputs the reference never produces must not corrupt state: explicit step sizes outside {1,2,3} are clamped, actions
 outside [0, A) only advance count_step, an over-long time limit is refused."""
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu

@@ -2,7 +2,7 @@
 import ctypes as C, os, time, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from snac_amd import BatchedDMPEnv, _lib
+from snac_amd import BatchedDMPEnv
 env = BatchedDMPEnv(2, True, 4096, seed=1); env.reset()
 N=4096
 a = torch.randint(0,5,(N,),dtype=torch.int8,device="cuda"); k = torch.randint(1,4,(N,),dtype=torch.int8,device="cuda")
