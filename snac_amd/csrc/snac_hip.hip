@@ -204,7 +204,7 @@ struct K2D {
         if (lane < GE) cells(lds)[(lane + 3) * RS + e] = ((uint64_t)ROW_HI << 32) | ROW_LO;
     }
     // step: DMP_Env_2D_dynamic_usedata_plan.py:85-147
-    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
         uint64_t* cw = cells(lds) + s.r * RS + lane;
         const uint64_t w = *cw;
         const int off = 2 * s.c;
@@ -247,14 +247,12 @@ struct K2D {
 template <bool DYN_, int E_>
 struct K3D {
     static constexpr bool DYN = DYN_;
-    static constexpr int E = E_, D = 51, W = 49, A = 8, TS = DYN_ ? 1000 : 1300, GE = 400, ES = 678, PS = 402;
-    static constexpr int P_OFF = E * ES / 2;                         // dwords
-    static constexpr int SC_OFF = E * (ES + PS) / 2 + ((E * (ES + PS) / 2) & 1);
+    static constexpr int E = E_, D = 51, W = 49, A = 8, TS = DYN_ ? 1000 : 1300, GE = 400, ES = 678;
+    static constexpr int SC_OFF = E * ES / 2 + ((E * ES / 2) & 1);   // dwords
     static constexpr int LDS_WORDS = SC_OFF + 4 * E;
     __device__ static double* sc(uint32_t* lds) { return (double*)(lds + SC_OFF); }
 
     __device__ static int16_t* hmap(uint32_t* lds) { return (int16_t*)lds; }
-    __device__ static int16_t* plan(uint32_t* lds) { return (int16_t*)(lds + P_OFF); }
 
     __device__ static void load_grid(uint32_t* lds, const KArgs& a, int env0, int nenv, int lane, const int* rows = nullptr) {
         for (int i = lane; i < E * ES / 2; i += 64) lds[i] = 0xFFFFFFFFu;            // everything frame (-1) ...
@@ -273,30 +271,12 @@ struct K3D {
             dst[tile_row(rows, env0, e) * GE + cell] = h[e * ES + (r + 3) * 26 + c + 3];
         }
     }
-    __device__ static void load_plan(uint32_t* lds, const KArgs& a, int e, int pidx, int lane) {  // whole wave
-        const uint32_t* src = (const uint32_t*)((const int16_t*)a.plans + (size_t)pidx * GE);
-        uint32_t* dst = lds + P_OFF + e * (PS / 2);
-#pragma unroll
-        for (int d = lane; d < GE / 2; d += 64) dst[d] = src[d];
-    }
-    // the plan cells a single step() can read: the four build targets around the agent (fetched early, independent of
-    // the action, placed once the tile is loaded)
-    struct PlanCell { int16_t v[4]; };
-    __device__ static int target(const Lane& s, int d) {             // interior index of neighbour d, or -1 on the frame
-        const int tr = s.r + (d == 2 ? 1 : (d == 3 ? -1 : 0)) - 3, tc = s.c + (d == 0 ? -1 : (d == 1 ? 1 : 0)) - 3;
-        return ((unsigned)tr < 20u && (unsigned)tc < 20u) ? tr * 20 + tc : -1;
-    }
-    __device__ static PlanCell fetch_plan_cell(const KArgs& a, const Lane& s) {
-        PlanCell pc;
-        const int16_t* pl = (const int16_t*)a.plans + (size_t)s.pidx * GE;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { const int i = target(s, d); pc.v[d] = pl[max(i, 0)]; }
-        return pc;
-    }
-    __device__ static void put_plan_cell(uint32_t* lds, const Lane& s, const PlanCell& pc, int lane) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { const int i = target(s, d); if (i >= 0) plan(lds)[lane * PS + i] = pc.v[d]; }
-    }
+    // The plan is NOT staged: a step needs at most one plan cell (the build target), fetched from the L2-resident table
+    // inside step().  Leaving the 800-byte plan out of LDS is what lets 14 waves (instead of 9) share a CU.
+    __device__ static void load_plan(uint32_t*, const KArgs&, int, int, int) {}
+    struct PlanCell {};
+    __device__ static PlanCell fetch_plan_cell(const KArgs&, const Lane&) { return PlanCell{}; }
+    __device__ static void put_plan_cell(uint32_t*, const Lane&, const PlanCell&, int) {}
     // reset: DMP_simulator_3d_dynamic_triangle_usedata.py:45-75
     __device__ static void reset(const KArgs& a, Lane& s, int pidx) {
         if (pidx >= 0) { s.pidx = pidx; s.tb = a.plan_tb[pidx]; }    // pidx < 0: the env keeps its plan and total_brick
@@ -308,7 +288,7 @@ struct K3D {
         for (int i = lane; i < GE; i += 64) { const int r = i / 20, c = i - r * 20; h[(r + 3) * 26 + c + 3] = 0; }
     }
     // step: DMP_simulator_3d_static_circle.py:153-230, DMP_simulator_3d_dynamic_triangle_usedata.py:142-231
-    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r * 26 + s.c;         // the agent's cell
         s.cs += 1;
         reward = 0;
@@ -336,7 +316,7 @@ struct K3D {
             if (built) {
                 s.cb += 1;
                 h[dl] = (int16_t)newh;
-                pl = plan(lds)[lane * PS + (s.r + dr - 3) * 20 + (s.c + dc - 3)];
+                pl = ((const int16_t*)a.plans)[(size_t)s.pidx * GE + (s.r + dr - 3) * 20 + (s.c + dc - 3)];
                 s.cross += newh <= pl ? 1 : 0;                       // running sum of min(height, plan) for iou()
             }
             bool fin = false;
@@ -358,14 +338,6 @@ struct K3D {
     // iou (:257-276) = sum(min(g, plan)) / (tb + cb - sum); the sum is tracked incrementally in s.cross
     __device__ static double iou(uint32_t*, const Lane& s, int) {
         return (double)s.cross / (double)(s.tb + s.cb - s.cross);
-    }
-    // the same from the grid (snac_iou)
-    __device__ static double iou_full(uint32_t* lds, const Lane& s, int lane) {
-        const int16_t* h = hmap(lds) + lane * ES;
-        const int16_t* pl = plan(lds) + lane * PS;
-        int cross = 0;
-        for (int i = 0; i < GE; ++i) { const int r = i / 20, c = i - r * 20; cross += min((int)h[(r + 3) * 26 + c + 3], (int)pl[i]); }
-        return (double)cross / (double)(s.tb + s.cb - cross);
     }
     __device__ static int key0(const Lane& s) { return ((s.r - 3) * 26 + (s.c - 3)) * 2; }   // byte offset of the window corner
     __device__ static int key1(const Lane&) { return 0; }
@@ -425,7 +397,7 @@ struct K1D {
         if (lane < 30) hmap(lds)[e * ES + lane + 2] = 0;
     }
     // step: DMP_Env_1D_static.py:85-136
-    __device__ static void step(uint32_t* lds, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
+    __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r;
         const int hnew = (int)*h + 1;
         const int pl = plan(lds)[lane * ES + s.r - 2];
@@ -603,7 +575,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
                 if (a.actions) act = (int)a.actions[row + lane];
                 if (a.step_size) k = min(max((int)a.step_size[row + lane], 1), 3);
             }
-            K::step(lds, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
+            K::step(lds, a, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
             s.ep_ret += reward;
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
             if (a.reward) a.reward[row + lane] = (float)reward;
@@ -679,7 +651,7 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
         const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
         const int act = a.actions ? (int)a.actions[edge] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
         const int k = a.step_size ? min(max((int)a.step_size[edge], 1), 3) : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
-        K::step(lds, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
+        K::step(lds, a, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
         s.ep_ret += reward;
         s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
         if (a.reward) a.reward[edge] = (float)reward;
@@ -739,9 +711,7 @@ __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
         K::store_grid(lds, a, env0, nenv, lane);
     }
     if (a.aux_op == AUX_IOU) {
-        double v;
-        if constexpr (K::A == 8) v = K::iou_full(lds, s, lane);
-        else v = K::iou(lds, s, lane);
+        const double v = K::iou(lds, s, lane);                   // 3D: from the running sum kept in the header
         if (active) a.out_f64[env] = v;
         return;
     }
