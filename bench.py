@@ -148,7 +148,10 @@ def main():
         if world > 1 and backend == "nccl":
             # the pass's one exchange (24 bytes, RCCL): enqueued behind the rollout on RCCL's stream, it overlaps the next
             # pass instead of holding it up; every pass still performs it and all are complete before the clock stops
-            pending.append((dist.all_reduce(s, op=dist.ReduceOp.SUM, async_op=True), s))
+            try:
+                pending.append((dist.all_reduce(s, op=dist.ReduceOp.SUM, async_op=True), s))
+            except Exception:                                   # keep the measurement alive: fall back to the blocking form
+                stats.copy_(allreduce_(s))
         else:
             stats.copy_(allreduce_(s))
     for work, s in pending:
