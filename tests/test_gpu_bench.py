@@ -67,3 +67,29 @@ def test_rccl_int64_all_reduce_single_rank():
         assert t.tolist() == [3, -7, 1 << 45] and m.item() == 1.5
     finally:
         dist.destroy_process_group()
+
+
+def test_overlapped_all_reduce_form_on_rccl():
+    """bench.py enqueues its per-pass exchange with async_op=True on RCCL and waits for all of them before the clock stops.
+    One GPU cannot host two RCCL ranks, so the call form is exercised on a 1-rank RCCL group: int64 [3] tensor, several
+    in flight, results intact."""
+    import subprocess
+    import sys
+
+    code = r'''
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", RANK="0", WORLD_SIZE="1")
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+pending = []
+for i in range(5):
+    s = torch.tensor([i, 2 * i, 3 * i], dtype=torch.int64, device="cuda")
+    pending.append((dist.all_reduce(s, op=dist.ReduceOp.SUM, async_op=True), s))
+for w, s in pending:
+    w.wait()
+torch.cuda.synchronize()
+assert [s.tolist() for _, s in pending] == [[i, 2 * i, 3 * i] for i in range(5)]
+dist.destroy_process_group()
+print("OK")
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-300:], r.stderr[-800:])
