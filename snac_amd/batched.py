@@ -298,6 +298,33 @@ class BatchedDMPEnv:
                                                  _ptr(a), _ptr(k), _ptr(obs), _ptr(reward), _ptr(done), self._stream()))
         return obs, reward, done.view(torch.bool)
 
+    def evaluate(self, rows, horizon, gamma, first_reward=None):
+        """Default-policy evaluation of tree leaves, the "Evaluation" block of the vanilla MCTS procedure
+        (script/MCTS/utils/mcts.py:100-110): from each pool row in `rows`, up to `horizon` uniformly random steps that stop
+        at the first `done`, and   estimate = first_reward + sum_t reward_t * gamma**t   accumulated in that order in
+        float64 (gamma**t as python computes it), so that it equals the reference loop bit for bit given the same
+        actions.  Actions and step sizes come from the counter RNG (tick t of leaf i is keyed by (env_id_base + i, t));
+        a leaf whose last step returned done is not rolled out.  The pool rows are left untouched (the leaves are forked).
+        Returns (estimate float64 [m], steps int64 [m]: the number of steps actually taken)."""
+        rows = torch.as_tensor(rows, device=self.device, dtype=torch.long)
+        m, H = int(rows.numel()), int(horizon)
+        est = torch.zeros(m, dtype=torch.float64, device=self.device) if first_reward is None else \
+            torch.as_tensor(first_reward, device=self.device).to(torch.float64).clone()
+        if m == 0 or H <= 0:
+            return est, torch.zeros(m, dtype=torch.int64, device=self.device)
+        terminal = self.need_reset[rows]
+        leaves = self.fork(rows)
+        leaves.t = 0
+        leaves._hdr.view(torch.int8)[:, 2] &= ~_lib.FLAG_NEED_RESET        # a terminal leaf is masked below, not reset
+        _, reward, done = leaves.rollout(H, obs=None)
+        alive = ~terminal
+        steps = torch.zeros(m, dtype=torch.int64, device=self.device)
+        for t in range(H):                                           # sequential on purpose: the reference's summation order
+            est = torch.where(alive, est + reward[t].to(torch.float64) * (float(gamma) ** t), est)
+            steps += alive
+            alive = alive & ~done[t]
+        return est, steps
+
     def import_states(self, position, count_brick, count_step, environment_memory, plan_idx=None, total_brick=None, dst=None):
         """Load states in the reference's own format -- the (position, environment_memory, count_brick, count_step) tuples
         of the MCTS variants -- into pool rows dst (None: rows 0..m-1).  position [m, 2] (1D: [m]), environment_memory

@@ -325,3 +325,47 @@ def _iou1(env, mem):
     p = np.asarray(env.plan)
     cross = g.sum() - np.maximum(g - p, 0).sum()
     return float(cross / (p.sum() + g.sum() - cross))
+
+
+@pytest.mark.parametrize("dim,dyn", [(1, False), (2, True), (3, True), (3, False)])
+def test_default_policy_evaluation_matches_the_reference_loop(dim, dyn):
+    """BatchedDMPEnv.evaluate against a restatement of script/MCTS/utils/mcts.py:100-110 on the oracle: random steps until
+    done or the horizon, estimate += reward * gamma**t in python floats -- bit-equal, terminal leaves untouched."""
+    import rng_spec
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(dim, dyn, _tag(dim, dyn))
+    full = table.reshape((-1, 30) if dim == 1 else (-1, 26, 26))
+    n, seed, H, gamma = 400, 13, 60 if dim != 3 else 40, 0.9
+    env = BatchedDMPEnv(dim, dyn, n, plans=full, seed=seed)
+    orc_mod = helpers.oracle()
+    orc = orc_mod.OracleBatch(dim, dyn, n, table, seed=seed)
+    env.reset(); orc.reset()
+    T0 = {1: 37, 2: 600, 3: 21}[dim]                              # 2D: everybody still running hits the time limit at tick 600
+    env.rollout(T0, obs=None); orc.rollout(T0, obs=None)          # some rows end on a terminal step
+    rng = np.random.default_rng(dim)
+    rows = rng.integers(0, n, 150)
+    first = rng.integers(-1, 11, 150).astype(np.float64)
+    before = (env._hdr.clone(), env._grid.clone())
+    est, steps = env.evaluate(rows, H, gamma, first_reward=first)
+    assert torch.equal(env._hdr, before[0]) and torch.equal(env._grid, before[1])
+    st = orc.state()
+    A = env.num_actions
+    n_term = 0
+    for i, row in enumerate(rows):
+        e = orc_mod.OracleEnv(dim, dyn)
+        e.reset(table[st["plan_idx"][row]].reshape(-1), int(st["plan_idx"][row]))
+        pos = st["pos"][row]
+        e.set_state(st["grid"][row], int(pos[0]) if dim == 1 else pos, st["cb"][row], st["cs"][row])
+        estimate, terminal, t = float(first[i]), bool(st["need_reset"][row]), 0
+        n_term += terminal
+        while (not terminal) and t < H:
+            w = rng_spec.words(seed, 0, np.uint64(i), np.uint64(t))
+            a, k = int(rng_spec.action_of(w, A)), int(rng_spec.step_size_of(w))
+            _, _, r, terminal = e.transition(a, k, inplace=True)
+            estimate += r * (gamma ** t)
+            t += 1
+        assert np.float64(est[i].item()).tobytes() == np.float64(estimate).tobytes(), (dim, dyn, i)
+        assert int(steps[i]) == t
+    assert n_term > 0 or dim == 1
