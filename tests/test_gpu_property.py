@@ -75,3 +75,39 @@ def test_launch_boundaries_are_invisible(kind, n, seed, split):
         assert torch.equal(o, o1[t]) and torch.equal(r, r1[t]) and torch.equal(d, d1[t])
     assert torch.equal(envs[0].environment_memory(), envs[1].environment_memory())
     assert torch.equal(envs[0].environment_memory(), envs[2].environment_memory())
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+@given(kind=KIND, pool=st.integers(2, 300), seed=st.integers(0, 2**40), warm=st.integers(0, 40), waves=st.integers(1, 4),
+       data=st.data())
+def test_random_tree_edges_match_the_oracle(kind, pool, seed, warm, waves, data):
+    """snac_transition on arbitrary pools: random sources (shared parents allowed), random distinct destinations disjoint
+    from the sources of other edges (or equal to the edge's own source), explicit or counter-RNG step sizes."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    dim, dyn = kind
+    table = helpers.plan_table(dim, dyn, ("dense_train" if dim > 1 else "sin_train") if dyn else "p0")
+    full = table.reshape((-1, 30) if dim == 1 else (-1, 26, 26))
+    env = BatchedDMPEnv(dim, dyn, pool, plans=full, seed=seed)
+    orc = helpers.oracle().OracleBatch(dim, dyn, pool, table, seed=seed)
+    env.reset(); orc.reset()
+    if warm:
+        env.rollout(warm, obs=None); orc.rollout(warm, obs=None)
+    rng = np.random.default_rng(seed % (2**32))
+    for w in range(waves):
+        n_dst = data.draw(st.integers(1, max(1, pool // 2)))
+        dst = rng.choice(pool, n_dst, replace=False).astype(np.int32)
+        free = np.setdiff1d(np.arange(pool), dst)                      # rows that are not written: legal sources for anyone
+        inplace = rng.random(n_dst) < 0.3
+        src = np.where(inplace | (len(free) == 0), dst, rng.choice(free if len(free) else dst, n_dst)).astype(np.int32)
+        acts = rng.integers(0, env.num_actions, n_dst).astype(np.int8)
+        ks = rng.integers(1, 4, n_dst).astype(np.int8) if data.draw(st.booleans()) else None
+        o, r, d = env.transition(acts, ks, src, dst, t=w)
+        oo, ro, do = orc.transition(acts, ks, src, dst, t=w)
+        assert o.cpu().numpy().tobytes() == oo.tobytes() and r.cpu().numpy().tobytes() == ro.tobytes()
+        assert np.array_equal(d.cpu().numpy().astype(np.uint8), do)
+    st_o = orc.state()
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(pool, -1), st_o["grid"].astype(np.float64))
+    assert np.array_equal(env.count_step.cpu().numpy(), st_o["cs"]) and np.array_equal(env.count_brick.cpu().numpy(), st_o["cb"])
+    assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
