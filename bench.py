@@ -1,6 +1,6 @@
 """bench.py -- env-steps/s of the fused rollout on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts the N ranks itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (config.workload): 2D dynamic dense (Env/2D/DMP_Env_2D_dynamic_usedata_plan.py, plans = the converted
@@ -10,10 +10,16 @@ step sizes and plan indices from the counter RNG, auto-reset, writing the float6
 done flag of EVERY env-step to HBM -- one snac_rollout launch.  Inputs (state, plan table) are resident in HBM
 before the timed region.  Multi-GPU: envs are sharded by global id (weak scaling, no data-path collective); the
 only collective is one RCCL all-reduce of three int64 episodic sums per pass, inside the timed region.
+
+`--gpus N` is binding: without WORLD_SIZE in the environment the process becomes a launcher (it never touches the
+GPU) that starts N rank processes -- the one-command form of the reference driver (multiprocess.py:89-97); with
+WORLD_SIZE set (torch.distributed.run) it must equal N, anything else is a non-zero exit.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,55 +27,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic bytes per env-step (DESIGN.md "Roofline")
-ALG_BYTES = {(2, "f64"): 481, (2, "f32"): 277, (1, "f64"): 88, (3, "f64"): 574}
+# algorithmic bytes per env-step (DESIGN.md "Roofline"); f32 = the same with 4-byte observations
+ALG_BYTES = {(2, "f64"): 481, (2, "f32"): 277, (1, "f64"): 88, (1, "f32"): 60, (3, "f64"): 574, (3, "f32"): 370}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HEADLINE = "env-steps/sec at N=65536 envs (2D dynamic dense); bit-exact vs CPU"
 
 
-def cpu_baseline(kind, dynamic, n, T, seed):
-    """The C oracle (oracle/snac_oracle.c, OpenMP over the host cores) on the same workload, timed on the host:
-    one full pass of n envs x T steps in chunks, float64 observations of every step written to a reused buffer."""
-    import numpy as np
-
-    from oracle import snac_oracle
-    from snac_amd import plans
-
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    full = plans.dataset(kind, "dense", "train") if dynamic else plans.static_plan(kind, 0)[None]
-    table = full.reshape(len(full), -1).astype(np.int32)
-    L = snac_oracle.lib()
-    chunk = 10
-    best = None
-    # a few thread counts up to what the process may use (a shared host rarely scales to all of them), and a
-    # single thread (the scalar port); report the fastest
-    counts = sorted({c for c in (1, 8, 32, 64, avail) if c <= avail})
-    for cores, budget in [(c, 5.0) for c in counts]:
-        orc = snac_oracle.OracleBatch(kind, dynamic, n, table, seed=seed)
-        orc.reset()
-        obs = np.zeros((chunk, n, orc.obs_dim), np.float64)
-        rew = np.zeros((chunk, n), np.float32)
-        done = np.zeros((chunk, n), np.uint8)
-        args = (None, None, obs.ctypes.data, 0, rew.ctypes.data, done.ctypes.data, cores)
-        L.orc_batch_rollout(orc.b, chunk, 0, *args)  # warm-up chunk
-        t0 = time.perf_counter()
-        steps, t = 0, chunk
-        while t < T and time.perf_counter() - t0 < budget:
-            L.orc_batch_rollout(orc.b, chunk, t, *args)
-            t += chunk
-            steps += chunk * n
-        rate = steps / (time.perf_counter() - t0)
-        if best is None or rate > best["value"]:
-            best = dict(value=rate, unit="env-steps/s", cores=cores, kind="port",
-                        sample="C oracle (oracle/snac_oracle.c), %d OpenMP thread(s), %d envs x %d vector steps of the same "
-                               "workload, f64 obs/reward/done of every step written" % (cores, n, steps // n))
-        del orc
-    return best
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -80,25 +44,219 @@ def main():
     ap.add_argument("--T", type=int, default=0, help="vector steps per pass (default: total_step)")
     ap.add_argument("--obs-f32", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a torch.distributed environment
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """Start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), forward rank 0's JSON line and
+    return the worst exit status.  This process has not initialised the GPU and never does."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd(),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    # rank 0 prints one short JSON line (far below the pipe buffer), so polling without draining cannot block it
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        failed = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if failed:                                                # one rank died: the others would wait in a collective
+            rc = failed[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                      # the exact children we started, nothing else
+        time.sleep(0.05)
+    out0 = procs[0].stdout.read()
+    for p in procs:
+        rc = rc or p.wait()
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        rc = 3
+    for ln in lines:
+        print(ln)
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (SURVEY.md section 8d i-iii); rank 0 at N = 1 only
+def _table(kind, dynamic):
+    import numpy as np
+
+    from snac_amd import plans
+
+    full = plans.dataset(kind, "dense", "train") if dynamic else plans.static_plan(kind, 0)[None]
+    return full.reshape(len(full), -1).astype(np.int32)
+
+
+def _oracle_rate(kind, dynamic, n, T, seed, cores, budget):
+    import numpy as np
+
+    from oracle import snac_oracle
+
+    L = snac_oracle.lib()
+    chunk = 10
+    orc = snac_oracle.OracleBatch(kind, dynamic, n, _table(kind, dynamic), seed=seed)
+    orc.reset()
+    obs = np.zeros((chunk, n, orc.obs_dim), np.float64)
+    rew = np.zeros((chunk, n), np.float32)
+    done = np.zeros((chunk, n), np.uint8)
+    args = (None, None, obs.ctypes.data, 0, rew.ctypes.data, done.ctypes.data, cores)
+    L.orc_batch_rollout(orc.b, chunk, 0, *args)  # warm-up chunk
+    t0 = time.perf_counter()
+    steps, t = 0, chunk
+    while t < T and time.perf_counter() - t0 < budget:
+        L.orc_batch_rollout(orc.b, chunk, t, *args)
+        t += chunk
+        steps += chunk * n
+    return steps / (time.perf_counter() - t0), steps // n
+
+
+def _python_loop_rate(kind, dynamic, seed, n=1024, budget=5.0):
+    """(iii) the per-env Python loop shaped like VectorizedEnvWrapper.step (multiprocess.py:24-32): n independent env
+    objects, a for-loop calling step() on each, np.asarray of the collected lists; the step size drawn per step with
+    np.random.randint(1, 4) as the reference classes do; reset on done.  The env objects are oracle.OracleEnv (this leg
+    is the checker, not the product)."""
+    import numpy as np
+
+    from oracle import snac_oracle
+
+    table = _table(kind, dynamic)
+    rs = np.random.RandomState(seed)
+    envs = [snac_oracle.OracleEnv(kind, dynamic) for _ in range(n)]
+    for e in envs:
+        e.reset(table[rs.randint(0, len(table))])
+    A = envs[0].e.num_actions
+    ticks = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget:
+        actions = rs.randint(A, size=n)
+        obs, rewards, dones = [], [], []
+        for i, e in enumerate(envs):
+            o, r, d = e.step(actions[i], rs.randint(1, 4))
+            if d:
+                e.reset(table[rs.randint(0, len(table))])
+            obs.append(o), rewards.append(r), dones.append(d)
+        np.asarray(obs), np.asarray(rewards), np.asarray(dones)
+        ticks += 1
+    return n * ticks / (time.perf_counter() - t0), ticks
+
+
+def cpu_baseline(kind, dynamic, n, T, seed):
+    """The C oracle (oracle/snac_oracle.c) on the same workload, timed on the host: envs x T steps in chunks, float64
+    observations of every step written to a reused buffer.  `value` = the best OpenMP thread count (i); also the single
+    thread (ii) and the per-env Python loop at N = 1024 (iii)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # a few thread counts up to what the process may use (a shared host rarely scales to all of them)
+    counts = sorted({c for c in (1, 8, 32, 64, avail) if c <= avail})
+    best, single = None, None
+    what = "C oracle (oracle/snac_oracle.c), %d OpenMP thread(s), %d envs x %d vector steps of the same workload, " \
+           "f64 obs/reward/done of every step written"
+    for cores in counts:
+        rate, ticks = _oracle_rate(kind, dynamic, n, T, seed, cores, 4.0)
+        rec = dict(value=rate, unit="env-steps/s", cores=cores, kind="port", sample=what % (cores, n, ticks))
+        if cores == 1:
+            single = dict(value=rate, unit="env-steps/s", cores=1, sample=rec["sample"])
+        if best is None or rate > best["value"]:
+            best = rec
+    best["single_thread"] = single
+    rate, ticks = _python_loop_rate(kind, dynamic, seed)
+    best["python_loop_n1024"] = dict(
+        value=rate, unit="env-steps/s", cores=1,
+        sample="python for-loop over 1024 env objects per vector step (shape of multiprocess.py:24-32), %d vector steps" % ticks)
+    return best
+
+
+# ------------------------------------------------------------------------------------------------
+def measured_write_peak(torch, dev, nbytes=1 << 31, ms_budget=50.0):
+    """The box's write ceiling, live: hipMemsetAsync over a 2 GiB buffer on the current stream, ~50 ms of it, timed with
+    events on that stream.  (No kernel pattern exceeds it on this pool, profiles/r01_wr_ceiling.txt.)  GB/s or None."""
+    import ctypes as C
+
+    hip = None
+    for name in ("libamdhip64.so.7", "libamdhip64.so"):          # already loaded by torch: dlopen returns that copy
+        try:
+            hip = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    if hip is None or not hasattr(hip, "hipMemsetAsync"):
+        return None
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    hip.hipMemsetAsync.restype = C.c_int
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def run(k):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(k):
+            if hip.hipMemsetAsync(C.c_void_p(buf.data_ptr()), 0, nbytes, stream) != 0:
+                return None
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b)
+
+    if run(2) is None:
+        return None
+    one = run(4)
+    if not one:
+        return None
+    k = max(4, int(ms_budget / (one / 4)))
+    ms = run(k)
+    del buf
+    return nbytes * k / (ms * 1e-3) / 1e9 if ms else None
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))                          # before any GPU call in this process
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a number for the wrong job size\n"
+                         % (args.gpus, world))
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
 
     from snac_amd import BatchedDMPEnv
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     # RCCL ("nccl" on ROCm) in production; SNAC_BENCH_BACKEND=gloo lets the N > 1 path be exercised with several
     # ranks sharing one GPU (tests): the three int64 sums then take a CPU round trip.
     backend = os.environ.get("SNAC_BENCH_BACKEND", "nccl")
-    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        sys.stderr.write("bench.py: %d RCCL ranks need %d GPUs, this node shows %d\n" % (world, world, ndev))
+        sys.exit(2)
+    local = local % max(ndev, 1) if backend != "nccl" else local
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, "process group size %d != --gpus %d" % (dist.get_world_size(), args.gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -162,22 +320,30 @@ def main():
     dt = time.perf_counter() - t0
     dt = float(allreduce_(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    # every rank's own kernel time (events on its launch stream), and the proof of how many ranks the collective saw
+    per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
+    per_rank[rank] = kern_ms
+    per_rank = allreduce_(per_rank).tolist()
+    ranks_seen = int(allreduce_(torch.ones(1, dtype=torch.int64, device=dev)).item())
 
     if rank == 0:
         total_steps = world * n * T * args.steps
         dkey = "f32" if args.obs_f32 else "f64"
-        alg = ALG_BYTES.get((args.kind, dkey), ALG_BYTES[(2, "f64")])
+        alg = ALG_BYTES[(args.kind, dkey)]
         achieved = alg * n * T / (kern_ms * 1e-3) / 1e9
         s = stats.tolist()
         # measured HBM bytes per launch (rocprofv3 PMC passes of this same command, tools/profile.sh ->
         # profiles/traffic.json), turned into GB/s with the live launch duration; null for other workloads
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile) and (args.kind, dynamic, n, T, dkey) == (2, True, 65536, 600, "f64"):
+        headline = (args.kind, dynamic, n, T, dkey) == (2, True, 65536, 600, "f64")
+        if os.path.exists(tfile) and headline:
             with open(tfile) as fh:
                 traffic = json.load(fh)["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
+        wpeak = measured_write_peak(torch, dev)
+        what = "%dD %s dense" % (args.kind, "dynamic" if dynamic else "static")
         out = {
-            "metric": "env-steps/sec at N=65536 envs (2D dynamic dense); bit-exact vs CPU",
+            "metric": HEADLINE if headline else "env-steps/sec at N=%d envs (%s, %s obs); bit-exact vs CPU" % (n, what, dkey),
             "value": total_steps / dt,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -187,22 +353,29 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if not args.obs_f32 else "f32",
+            "dtype": dkey,
             "data": "synthetic",
-            "config": {"workload": "%dD %s %s, %d envs/GPU, %d vector steps/pass, uniform random actions (counter RNG), "
-                                   "auto-reset, %s obs of every step written" % (
-                                       args.kind, "dynamic" if dynamic else "static", "dense", n, T, dkey),
+            "config": {"workload": "%s, %d envs/GPU, %d vector steps/pass, uniform random actions (counter RNG), "
+                                   "auto-reset, %s obs of every step written" % (what, n, T, dkey),
                        "envs_per_gpu": n, "vector_steps_per_pass": T, "env_steps_per_pass": n * T * world,
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac_traffic": (traffic / HBM_PEAK_GBS) if traffic else None,
+                         "peak_measured_write": wpeak,
+                         "frac_of_measured_write": ((traffic or achieved) / wpeak) if wpeak else None,
                          "kernel": "k_rollout", "kernel_ms": kern_ms, "alg_bytes_per_env_step": alg},
+            "backend": backend if world > 1 else None,
+            "rccl_ranks": ranks_seen if (world > 1 and backend == "nccl") else None,
+            "ranks": ranks_seen,
+            "kernel_ms_per_rank": per_rank,
             "episodic": {"episodes": s[0], "mean_return": (s[1] / s[0]) if s[0] else None,
                          "mean_iou": (s[2] / 2.0 ** 40 / s[0]) if s[0] else None},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.kind, dynamic, n, T, 1)
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

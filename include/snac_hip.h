@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define SNAC_ABI_VERSION 3
+#define SNAC_ABI_VERSION 4
 
 typedef enum snac_status {
     SNAC_OK = 0,
@@ -74,6 +74,24 @@ enum { SNAC_FLAG_NEED_RESET = 1 };   /* snac_env_hdr.flags: the last step return
  *                       script/PPO/2d_static/DMP_Env_2D_static.py:137, script/PPO/3d_static/DMP_simulator_3d_static_circle.py:205)
  *   SNAC_RULE_TIME_GT   done when count_step > total_step     (script/PPO/3d_static/DMP_simulator_3d_static_circle.py:221) */
 enum { SNAC_RULE_BRICK_GT = 1, SNAC_RULE_TIME_GT = 2 };
+/* Observation-layout variants of the reference's env copies, as flags of the same kernels (snac_env_desc.frame_value /
+ * obs_scalars / obs_tail).  A row of `obs` is then   [window, scalar, scalar | position | plan | record]   with
+ * snac_obs_dim(desc) values; every kernel that writes observations (reset, step, rollout, transition, observe) honours them.
+ *   frame_value   value shown for the frame cells of the window (and by snac_export_grid): -1 (0 is read as -1), or 2 --
+ *                 Env/2D/DMP_Env_2D_static_Lnet.py:61-64 fills the frame with 2.  1D / 2D only (the 3D rules test -1).
+ *   obs_scalars   SNAC_SCALARS_RAW: count_brick, count_step; SNAC_SCALARS_NORM: count_brick/total_brick,
+ *                 count_step/total_step; SNAC_SCALARS_DEFAULT: raw for dynamic == 0, normalised for dynamic == 1 (the
+ *                 canonical classes).  The L-Net 2D class normalises with a static plan (DMP_Env_2D_static_Lnet.py:75);
+ *                 the env copies under script/PPO return raw counters with dataset plans
+ *                 (script/PPO/2d_dynamic/DMP_Env_2d_dynamic_usedata_plan.py:70-71).
+ *   obs_tail      bit set, appended in this order:
+ *     SNAC_TAIL_POSITION  1D: position (Env/1D/DMP_Env_1D_static_Lnet.py:83 -> 8 values); 2D / 3D: row, col
+ *     SNAC_TAIL_PLAN      the env's plan, 1D: 30 heights, 2D / 3D: input_plan 20x20 row-major -- the flat observation of
+ *                         script/PPO/{1d,2d,3d}_dynamic (37 / 451 values)
+ *     SNAC_TAIL_RECORD    8 values: reward, done, pos_r, pos_c, count_brick, count_step, total_brick, plan_idx of the env
+ *                         after the step -- everything a single-env caller reads back, in ONE row (one D2H copy) */
+enum { SNAC_SCALARS_DEFAULT = 0, SNAC_SCALARS_RAW = 1, SNAC_SCALARS_NORM = 2 };
+enum { SNAC_TAIL_POSITION = 1, SNAC_TAIL_PLAN = 2, SNAC_TAIL_RECORD = 4 };
 
 /* constants of one env kind: the reference's __init__ blocks (Env/1D/DMP_Env_1D_static.py:7-29,
  * Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:7-32, Env/3D/DMP_simulator_3d_static_circle.py:8-40,
@@ -111,6 +129,10 @@ typedef struct snac_env_desc {
                                    The 3D L-Net variant runs the dynamic rules with 1300
                                    (Env/3D/DMP_simulator_3d_static_circle_Lnet.py:28) */
     int32_t rules;              /* SNAC_RULE_* bits; 0 = the canonical classes */
+    int32_t frame_value;        /* 0 / -1: the canonical -1; 2: the 2D L-Net frame (1D / 2D only) */
+    int32_t obs_scalars;        /* SNAC_SCALARS_* */
+    int32_t obs_tail;           /* SNAC_TAIL_* bits */
+    int32_t reserved;           /* 0 */
 } snac_env_desc;
 
 typedef struct snac_state {
@@ -129,6 +151,10 @@ const char* snac_last_error(void);
 
 /* constants of (kind, dynamic); replaces the attribute reads of the reference constructors */
 int snac_env_sizes(int kind, int dynamic, snac_sizes* out);
+
+/* values per observation row for this descriptor: obs_dim of the kind plus its obs_tail (8 for the 1D L-Net class,
+ * 451 for the PPO 2D / 3D dataset classes); negative snac_status on a bad descriptor */
+int snac_obs_dim(const snac_env_desc* desc);
 
 /* reset(): Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:34-66 and the five sibling reset()s;
  * VectorizedEnvWrapper.reset / reset_at (multiprocess.py:20-23).
@@ -150,6 +176,16 @@ int snac_reset(const snac_env_desc* desc, const snac_state* st, const uint8_t* m
  * {1,2,3} -- the only values the reference's randint(1, 4) produces -- so that no input can move an agent off the plan area. */
 int snac_step(const snac_env_desc* desc, const snac_state* st, uint32_t t, const int8_t* actions,
               const int8_t* step_size, int auto_reset, void* obs, float* reward, uint8_t* done, void* stream);
+
+/* snac_step with ONE action and ONE step size for every env, passed by value -- the call of a single-env caller
+ * (the drop-in classes: env.step(action) with the step size the host drew from np.random, N = 1): no host-to-device
+ * copy precedes the launch; with SNAC_TAIL_RECORD the whole result comes back in one row.  action: any int (values outside
+ * [0, num_actions) only advance count_step); step_size is clamped into {1,2,3}. */
+int snac_step_scalar(const snac_env_desc* desc, const snac_state* st, uint32_t t, int32_t action, int32_t step_size,
+                     int auto_reset, void* obs, float* reward, uint8_t* done, void* stream);
+
+/* snac_reset of every env onto plan row `plan_idx`, passed by value (the single-env caller's reset()) */
+int snac_reset_scalar(const snac_env_desc* desc, const snac_state* st, int32_t plan_idx, void* obs, void* stream);
 
 /* the driver loop of multiprocess.py:78-84 -- T vector steps with auto-reset, fused in one launch with the
  * env state held on chip.

@@ -449,6 +449,8 @@ void orc_batch_destroy(orc_batch* b) {
     free(b);
 }
 
+/* plan_idx_in >= 0: that row; -1: counter RNG (dynamic) / row 0 (static); -2 (auto-reset): counter RNG (dynamic) / the
+ * env keeps its own row (static: per-env static plans survive an episode end) */
 static void batch_reset_one(orc_batch* b, int i, int plan_idx_in, double* obs) {
     int idx;
     b->episode[i] += 1;
@@ -456,7 +458,7 @@ static void batch_reset_one(orc_batch* b, int i, int plan_idx_in, double* obs) {
     else if (b->dynamic) {
         uint32_t w = orc_rng_word(b->seed, 1u, (uint64_t)(b->env_id_base + i), (uint32_t)b->episode[i]);
         idx = (int)(((uint64_t)w * (uint64_t)b->num_plans) >> 32);
-    } else idx = 0;
+    } else idx = (plan_idx_in == -2) ? b->envs[i].plan_idx : 0;
     orc_reset(&b->envs[i], b->plans + (size_t)idx * (size_t)b->cells, idx, obs);
     b->ep_return[i] = 0;
     b->need_reset[i] = 0;
@@ -476,7 +478,7 @@ static int batch_step_one(orc_batch* b, int i, uint32_t t, int a_in, int k_in, i
     orc_env* e = &b->envs[i];
     double r = 0.0;
     int d = 0, a = a_in, k = k_in, rc;
-    if (auto_reset && b->need_reset[i]) batch_reset_one(b, i, -1, NULL);
+    if (auto_reset && b->need_reset[i]) batch_reset_one(b, i, -2, NULL);
     if (a_in < 0 || k_in < 0) {
         uint32_t w = orc_rng_word(b->seed, 0u, (uint64_t)(b->env_id_base + i), t);
         if (a_in < 0) a = (int)(((w >> 16) * (uint32_t)b->num_actions) >> 16);

@@ -88,6 +88,15 @@ struct KArgs {
     const uint8_t* mask;
     const int16_t* plan_idx_in;
     double* out_f64;
+    int32_t plan_scalar;       // snac_reset_scalar: plan row of every env (-1: unused)
+    // observation-layout variants (snac_env_desc.frame_value / obs_scalars / obs_tail); variant != 0 selects the VAR kernels
+    int32_t variant;
+    int32_t ld;                // values per observation row: K::D + tail
+    int32_t frame_val;         // value shown for frame cells
+    int32_t sc_norm;           // 1: count_brick / total_brick, count_step / total_step; 0: raw counters
+    int32_t tail;              // SNAC_TAIL_* bits
+    // snac_step_scalar: one action / step size for every env, by value
+    int32_t use_scalar, act_scalar, k_scalar;
 };
 enum { AUX_RESET = 0, AUX_OBSERVE = 1, AUX_IOU = 2 };
 
@@ -102,6 +111,14 @@ __device__ __forceinline__ size_t row_of(const int32_t* idx, int pool, int i) {
 __device__ __forceinline__ size_t tile_row(const int* rows, int env0, int e) {
     return rows ? (size_t)rows[e] : (size_t)(env0 + e);
 }
+
+// The header packs its counters as int16.  The reference never resets by itself and "keeps mutating" when stepped past
+// done (Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:86: count_step is unbounded); here count_step,
+// count_brick and the heights SATURATE at 32767 and the running return in [-32768, 32767] instead of wrapping.  Termination
+// is unaffected (total_step <= 3000 and total_brick <= 32767 are reached long before), only the counters an observation
+// shows stop growing.
+constexpr int CNT_MAX = 32767;
+__device__ __forceinline__ int clamp16(int v) { return min(max(v, -32768), 32767); }
 
 // per-lane env scalars (one env per lane in phase 1)
 struct Lane {
@@ -211,9 +228,9 @@ struct K2D {
         const bool was = ((w >> off) & 1ull) != 0ull;
         const bool planned = ((lds[P_OFF + (s.r - 3) * RS + lane] >> (s.c - 3)) & 1u) != 0u;
         const bool drop = act == 4;
-        s.cs += 1;
+        s.cs = min(s.cs + 1, CNT_MAX);
         if (drop) {
-            s.cb += 1;
+            s.cb = min(s.cb + 1, CNT_MAX);
             *cw = w | (1ull << off);                                 // += 1 then clamp to 1 (:115, :134-135)
         }
         if (act == 0) s.c = max(s.c - k, 3);                         // clip_position :74-83
@@ -238,6 +255,12 @@ struct K2D {
     // phase-2 keys of the lane's env: byte offset of the window's first row, bit offset of its first column
     __device__ static int key0(const Lane& s) { return (s.r - 3) * RS * 8; }
     __device__ static int key1(const Lane& s) { return 2 * (s.c - 3); }
+    // SNAC_TAIL_PLAN: input_plan cell (row-major 20x20) of plan row pidx, from the L2-resident table
+    static constexpr int PLAN_CELLS = 400;
+    __device__ static int plan_value(const KArgs& a, int pidx, int cell) {
+        const int row = cell / 20, col = cell - row * 20;
+        return (int)((((const uint32_t*)a.plans)[pidx * GE + row] >> col) & 1u);
+    }
 };
 
 // ================================================================================================
@@ -290,7 +313,7 @@ struct K3D {
     // step: DMP_simulator_3d_static_circle.py:153-230, DMP_simulator_3d_dynamic_triangle_usedata.py:142-231
     __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r * 26 + s.c;         // the agent's cell
-        s.cs += 1;
+        s.cs = min(s.cs + 1, CNT_MAX);
         reward = 0;
         // check_sur (:88-102 / :77-91): left, right, "up" (row + 1), "down" (row - 1)
         const int n0 = h[-1], n1 = h[1], n2 = h[26], n3 = h[-26];
@@ -311,10 +334,10 @@ struct K3D {
             }
         } else if (valid) {
             const bool built = nd != -1;                             // check[act] == 0 for act in 4..7
-            const int newh = nd + 1;
+            const int newh = min(nd + 1, CNT_MAX);
             int pl = 0;
             if (built) {
-                s.cb += 1;
+                s.cb = min(s.cb + 1, CNT_MAX);
                 h[dl] = (int16_t)newh;
                 pl = ((const int16_t*)a.plans)[(size_t)s.pidx * GE + (s.r + dr - 3) * 20 + (s.c + dc - 3)];
                 s.cross += newh <= pl ? 1 : 0;                       // running sum of min(height, plan) for iou()
@@ -341,6 +364,8 @@ struct K3D {
     }
     __device__ static int key0(const Lane& s) { return ((s.r - 3) * 26 + (s.c - 3)) * 2; }   // byte offset of the window corner
     __device__ static int key1(const Lane&) { return 0; }
+    static constexpr int PLAN_CELLS = 400;
+    __device__ static int plan_value(const KArgs& a, int pidx, int cell) { return (int)((const int16_t*)a.plans)[(size_t)pidx * GE + cell]; }
 };
 
 // ================================================================================================
@@ -399,11 +424,11 @@ struct K1D {
     // step: DMP_Env_1D_static.py:85-136
     __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r;
-        const int hnew = (int)*h + 1;
+        const int hnew = min((int)*h + 1, CNT_MAX);
         const int pl = plan(lds)[lane * ES + s.r - 2];
         const bool drop = act == 2;
-        s.cs += 1;
-        if (drop) { s.cb += 1; *h = (int16_t)hnew; }
+        s.cs = min(s.cs + 1, CNT_MAX);
+        if (drop) { s.cb = min(s.cb + 1, CNT_MAX); *h = (int16_t)hnew; }
         if (act == 0) s.r = max(s.r - k, 2);                         // clip_position :57-64
         if (act == 1) s.r = min(s.r + k, 31);
         const bool term = drop && s.cb >= s.tb + bg;                 // :107-114, before the time limit
@@ -424,6 +449,8 @@ struct K1D {
     }
     __device__ static int key0(const Lane& s) { return s.r; }
     __device__ static int key1(const Lane&) { return 0; }
+    static constexpr int PLAN_CELLS = 30;
+    __device__ static int plan_value(const KArgs& a, int pidx, int cell) { return (int)((const int16_t*)a.plans)[(size_t)pidx * GE + cell]; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -433,8 +460,19 @@ struct K1D {
 // write_scalars), and the 51 values leave as ONE contiguous store.  (Writing the scalar slots with a separate
 // per-lane store was measured: the partial-line writes cost 55 % -- 4.5 vs 2.9 ms per pass.)
 // 1D: 7 values per env, flat, one element per lane.
-template <class K, typename OT, bool FULL>
-__device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int k0, int k1, int lane) {
+// VAR: the layout variants of snac_env_desc (frame value, row length a.ld = K::D + tail, the tail itself); the canonical
+// instantiation (VAR = false) carries none of it.
+struct StepOut { int reward; int done; };                        // per lane: what SNAC_TAIL_RECORD reports besides the header
+
+// one SNAC_TAIL_RECORD value: 0 reward, 1 done, 2 pos_r, 3 pos_c, 4 count_brick, 5 count_step, 6 total_brick, 7 plan_idx
+__device__ __forceinline__ int record_value(int j, int reward, int done, int r, int c, int cb, int cs, int tb, int pidx) {
+    return j == 0 ? reward : j == 1 ? done : j == 2 ? r : j == 3 ? c : j == 4 ? cb : j == 5 ? cs : j == 6 ? tb : pidx;
+}
+
+template <class K, typename OT, bool FULL, bool VAR>
+__device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int k0, int k1, int lane, const KArgs& a,
+                                          const Lane& s, const StepOut& so) {
+    const int LD = VAR ? a.ld : K::D;
     if constexpr (K::D == 51) {
         constexpr int U = 8;                                         // envs per batch (K::E is a multiple of U)
         const int wl = lane < K::W ? lane : 0;
@@ -461,6 +499,7 @@ __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int
                     const uint64_t w = *(const uint64_t*)(base + (e * 8 + s0) + lane_off);
                     v[u] = ((int)((uint32_t)(w >> off) << 30)) >> 30;    // signed 2-bit field: 0 / 1 / -1
                 }
+                if constexpr (VAR) v[u] = v[u] < 0 ? a.frame_val : v[u];
             }
             // one fence per batch: every LDS read is in flight before the first store is built (otherwise the
             // compiler sinks each scalar read into its store's exec-masked block and serialises them)
@@ -468,31 +507,68 @@ __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const double val = is_win ? (double)v[u] : sv[u];
-                if (lane < K::D && (FULL || e0 + u < nenv)) p[(e0 + u) * K::D] = (OT)val;
+                if (lane < K::D && (FULL || e0 + u < nenv)) p[(size_t)(e0 + u) * LD] = (OT)val;
+            }
+        }
+        if constexpr (VAR) {
+            if (a.tail) {
+                for (int e = 0; e < nenv; ++e) {                     // e is wave-uniform: readlane broadcasts env e's scalars
+                    OT* q = orow + (size_t)e * LD + K::D;
+                    const int r = __builtin_amdgcn_readlane(s.r, e), c = __builtin_amdgcn_readlane(s.c, e);
+                    const int pidx = __builtin_amdgcn_readlane(s.pidx, e);
+                    if (a.tail & SNAC_TAIL_POSITION) {
+                        if (lane < 2) q[lane] = (OT)(double)(lane == 0 ? r : c);
+                        q += 2;
+                    }
+                    if (a.tail & SNAC_TAIL_PLAN) {
+                        for (int cell = lane; cell < K::PLAN_CELLS; cell += 64) q[cell] = (OT)(double)K::plan_value(a, pidx, cell);
+                        q += K::PLAN_CELLS;
+                    }
+                    if (a.tail & SNAC_TAIL_RECORD) {
+                        const int val = record_value(lane, __builtin_amdgcn_readlane(so.reward, e), __builtin_amdgcn_readlane(so.done, e),
+                                                     r, c, __builtin_amdgcn_readlane(s.cb, e), __builtin_amdgcn_readlane(s.cs, e),
+                                                     __builtin_amdgcn_readlane(s.tb, e), pidx);
+                        if (lane < 8) q[lane] = (OT)(double)val;
+                    }
+                }
             }
         }
     } else {
-        // 1D: q = e * 7 + el
+        // 1D: q = e * LD + el
         const int16_t* h = K::hmap(lds);
         const double* scp = K::sc(lds);
         const int* posp = K::pos(lds);
-        const int total = nenv * K::D;
+        const int total = nenv * LD;
         for (int q = lane; q < total; q += 64) {
-            const int e = q / K::D, el = q - e * K::D;
-            const int v = h[e * K::ES + posp[e] - 2 + min(el, K::W - 1)];
-            const double s = scp[2 * e + (el >= K::W ? el - K::W : 0)];
-            orow[q] = (OT)(el < K::W ? (double)v : s);
+            const int e = q / LD, el = q - e * LD;
+            int v = h[e * K::ES + posp[e] - 2 + min(el, K::W - 1)];
+            if constexpr (VAR) v = v < 0 ? a.frame_val : v;
+            double val = el < K::W ? (double)v : scp[2 * e + (el >= K::W + 1 ? 1 : 0)];
+            if constexpr (VAR) {
+                if (el >= K::D) {                                    // the tail: e differs per lane -> lane e's scalars by bpermute
+                    int ti = el - K::D, out = 0;
+                    const int pos = posp[e], pidx = __shfl(s.pidx, e);
+                    if (a.tail & SNAC_TAIL_POSITION) { if (ti == 0) out = pos; ti -= 1; }
+                    if (a.tail & SNAC_TAIL_PLAN) { if (ti >= 0 && ti < K::PLAN_CELLS) out = K::plan_value(a, pidx, ti); ti -= K::PLAN_CELLS; }
+                    const int rec = record_value(ti, __shfl(so.reward, e), __shfl(so.done, e), pos, 0, __shfl(s.cb, e), __shfl(s.cs, e),
+                                                 __shfl(s.tb, e), pidx);
+                    if ((a.tail & SNAC_TAIL_RECORD) && ti >= 0) out = rec;
+                    val = (double)out;
+                }
+            }
+            orow[q] = (OT)val;
         }
     }
 }
 
 // the two scalar observation slots (count_brick, count_step or their normalised forms): one IEEE float64 division per
 // lane (no fast-math), staged in LDS for phase 2.
-template <class K, typename OT>
-__device__ __forceinline__ void write_scalars(uint32_t* lds, const Lane& s, int ts, int lane) {
+template <class K, typename OT, bool VAR>
+__device__ __forceinline__ void write_scalars(uint32_t* lds, const Lane& s, int ts, int lane, const KArgs& a) {
     const double num0 = (double)s.cb, num1 = (double)s.cs;
-    const double v0 = K::DYN ? num0 / (double)s.tb : num0;
-    const double v1 = K::DYN ? num1 / (double)ts : num1;
+    const bool norm = VAR ? (a.sc_norm != 0) : K::DYN;
+    const double v0 = norm ? num0 / (double)s.tb : num0;
+    const double v1 = norm ? num1 / (double)ts : num1;
     if (lane < K::E) {
         double2 v; v.x = v0; v.y = v1;
         *(double2*)(K::sc(lds) + 2 * lane) = v;
@@ -500,10 +576,12 @@ __device__ __forceinline__ void write_scalars(uint32_t* lds, const Lane& s, int 
     }
 }
 
+// plan row of a new episode: counter RNG stream 1 for the dataset classes; a static-plan env keeps `keep` -- its own row
+// on auto-reset (per-env static plans, hindsight relabelling), desc->static_plan on an explicit reset without indices
 template <class K>
-__device__ __forceinline__ int pick_plan(const KArgs& a, EnvKeys pk, int episode) {
+__device__ __forceinline__ int pick_plan(const KArgs& a, EnvKeys pk, int episode, int keep) {
     if (K::DYN) return (int)__umulhi(rng_word(pk, (uint32_t)episode), (uint32_t)a.num_plans);
-    return a.static_plan;
+    return keep;
 }
 
 template <class K, int WPB>
@@ -512,11 +590,11 @@ __device__ __forceinline__ uint32_t* wave_lds() {
     return lds + (threadIdx.x >> 6) * K::LDS_WORDS;
 }
 
-template <class K, typename OT>
-__device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, const Lane& s, int ts, int lane) {
-    write_scalars<K, OT>(lds, s, ts, lane);
-    if (nenv == K::E) write_obs<K, OT, true>(lds, orow, nenv, K::key0(s), K::key1(s), lane);
-    else write_obs<K, OT, false>(lds, orow, nenv, K::key0(s), K::key1(s), lane);
+template <class K, typename OT, bool VAR>
+__device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, const Lane& s, const KArgs& a, int lane, const StepOut& so) {
+    write_scalars<K, OT, VAR>(lds, s, a.total_step, lane, a);
+    if (nenv == K::E) write_obs<K, OT, true, VAR>(lds, orow, nenv, K::key0(s), K::key1(s), lane, a, s, so);
+    else write_obs<K, OT, false, VAR>(lds, orow, nenv, K::key0(s), K::key1(s), lane, a, s, so);
 }
 
 // T fused vector steps (T = 1: one step() call) for one tile of E envs per wave.
@@ -555,7 +633,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
             const int old_pidx = s.pidx, old_tb = s.tb;
             if (nr) {
                 episode += 1;
-                const int pidx = pick_plan<K>(a, pk, episode);
+                const int pidx = pick_plan<K>(a, pk, episode, old_pidx);
                 K::reset(a, s, pidx == old_pidx ? -1 : pidx);   // -1: same plan again (static tables): keep tb, no load
                 if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
             }
@@ -576,7 +654,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
                 if (a.step_size) k = min(max((int)a.step_size[row + lane], 1), 3);
             }
             K::step(lds, a, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
-            s.ep_ret += reward;
+            s.ep_ret = clamp16(s.ep_ret + reward);
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
             if (a.reward) a.reward[row + lane] = (float)reward;
             if (a.done) a.done[row + lane] = done ? 1 : 0;
@@ -586,7 +664,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
             if (a.first_out) a.first_out[row + lane] = s.cs == 1 ? 1 : 0;   // first step of its episode
         }
         if (__any(done)) {
-            const double v = K::iou(lds, s, lane);
+            const double v = K::iou(lds, s, active ? lane : 0);      // idle lanes stay inside the wave's LDS slice
             if (done) { d_eps += 1; d_ret += s.ep_ret; d_iou += __double2ll_rn(v * FX40); }
         }
         if (a.obs_mode == SNAC_OBS_ALL || (a.obs_mode == SNAC_OBS_LAST && t == a.T - 1)) {
@@ -634,7 +712,7 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
     if (nr) {
         const int old_pidx = s.pidx, old_tb = s.tb;
         episode += 1;
-        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode);
+        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
         K::reset(a, s, pidx == old_pidx ? -1 : pidx);
         if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
     }
@@ -652,7 +730,7 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
         const int act = a.actions ? (int)a.actions[edge] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
         const int k = a.step_size ? min(max((int)a.step_size[edge], 1), 3) : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
         K::step(lds, a, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
-        s.ep_ret += reward;
+        s.ep_ret = clamp16(s.ep_ret + reward);
         s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
         if (a.reward) a.reward[edge] = (float)reward;
         if (a.done) a.done[edge] = done ? 1 : 0;
@@ -663,7 +741,7 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
                 const int e = __ffsll(m) - 1;
                 K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane);
             }
-        const double v = K::iou(lds, s, lane);
+        const double v = K::iou(lds, s, active ? lane : 0);
         if (done) {
             a.stat_episodes[drow] += 1;
             a.stat_return[drow] += s.ep_ret;
@@ -702,7 +780,7 @@ __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
             const int episode = a.episode[env] + 1;
             int pidx;
             if (a.plan_idx_in) pidx = a.plan_idx_in[env];
-            else pidx = pick_plan<K>(a, env_keys(a.key_plan, (uint64_t)(a.env_id_base + env)), episode);
+            else pidx = pick_plan<K>(a, env_keys(a.key_plan, (uint64_t)(a.env_id_base + env)), episode, a.static_plan);
             pidx = min(max(pidx, 0), a.num_plans - 1);
             K::reset(a, s, pidx);
             a.hdr[env] = s.pack();
@@ -711,7 +789,7 @@ __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
         K::store_grid(lds, a, env0, nenv, lane);
     }
     if (a.aux_op == AUX_IOU) {
-        const double v = K::iou(lds, s, lane);                   // 3D: from the running sum kept in the header
+        const double v = K::iou(lds, s, active ? lane : 0);      // 3D: from the running sum kept in the header
         if (active) a.out_f64[env] = v;
         return;
     }
@@ -1057,7 +1135,8 @@ int snac_transition(const snac_env_desc* d, const snac_state* st, int32_t m, con
                     void* stream) {
     if (int rc = check_common(d, st)) return rc;
     if (m < 0) return fail(SNAC_ERR_ARG, "m must be >= 0");
-    if (!src_index && !dst_index && m > d->num_envs) return fail(SNAC_ERR_ARG, "m exceeds the pool (num_envs)");
+    // an absent index array means "row i": with either one absent, edge i touches pool row i, so m is bounded by the pool
+    if ((!src_index || !dst_index) && m > d->num_envs) return fail(SNAC_ERR_ARG, "m exceeds the pool (num_envs)");
     if (m == 0) return SNAC_OK;
     KArgs a = make_args(d, st);
     a.pool = d->num_envs; a.n = m; a.src_index = src_index; a.dst_index = dst_index;

@@ -137,3 +137,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_bench_gpus_flag_must_match_the_world_size():
+    """bench.py --gpus N under a torch.distributed environment of another size exits non-zero before touching torch."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr and not r.stdout.strip()

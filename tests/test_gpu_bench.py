@@ -49,6 +49,31 @@ def test_bench_line_and_two_rank_path():
     assert two["n_gpus"] == 2 and two["config"]["env_steps_per_pass"] == 2 * 4096 * 120
     # 2 ranks x 4096 envs (ids 0..8191) == 1 rank x 8192 envs: same global episodic sums after the same 3 passes
     assert two["episodic"] == one["episodic"]
+    assert two["ranks"] == 2 and len(two["kernel_ms_per_rank"]) == 2 and min(two["kernel_ms_per_rank"]) > 0
+    cb = one["cpu_baseline"]
+    assert cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0 and cb["python_loop_n1024"]["value"] > 0
+    assert r["peak_measured_write"] is None or 1000 < r["peak_measured_write"] < 8000
+
+
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no torch.distributed environment: the process becomes a launcher, starts two ranks
+    (sharing this box's one GPU, hence gloo for the three int64 sums) and forwards rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SNAC_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--T", "120", "--no-cpu"]
+    out = subprocess.run(cmd + ["--gpus", "2", "--envs", "4096"], cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    two = json.loads(lines[0])
+    one = _run(cmd + ["--envs", "8192"])
+    assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["backend"] == "gloo"
+    assert two["episodic"] == one["episodic"]
+    # RCCL needs one GPU per rank: two RCCL ranks on a one-GPU box must fail loudly, not report a 1-GPU number
+    if __import__("torch").cuda.device_count() == 1:
+        env["SNAC_BENCH_BACKEND"] = "nccl"
+        bad = subprocess.run(cmd + ["--gpus", "2", "--envs", "4096"], cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_rccl_int64_all_reduce_single_rank():
