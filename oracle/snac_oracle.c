@@ -59,6 +59,14 @@ int orc_set_rules(orc_env* e, int brick_gt, int time_gt) {
     return 0;
 }
 
+int orc_set_tail(orc_env* e, int tail) {
+    int base = (e->dim == 1) ? 7 : 51;
+    e->tail = tail;
+    e->obs_dim = base + ((tail & ORC_TAIL_POSITION) ? (e->dim == 1 ? 1 : 2) : 0) + ((tail & ORC_TAIL_PLAN) ? (e->dim == 1 ? 30 : 400) : 0) +
+                 ((tail & ORC_TAIL_RECORD) ? 8 : 0);
+    return e->obs_dim;
+}
+
 #define G(e, r, c) ((e)->grid[(r) * (e)->W + (c)])
 #define P(e, r, c) ((e)->plan[(r) * (e)->W + (c)])
 
@@ -78,6 +86,21 @@ void orc_observe(const orc_env* e, double* obs) {
     } else {
         obs[n++] = (double)e->cb;
         obs[n++] = (double)e->cs;
+    }
+    /* tails of the env copies: Env/1D/DMP_Env_1D_static_Lnet.py:83 appends the position; the script/PPO dataset classes append the
+     * plan (1D: 30 heights, 2D / 3D: input_plan = plan[3:23, 3:23] flattened) */
+    if (e->tail & ORC_TAIL_POSITION) {
+        obs[n++] = (double)e->pos[0];
+        if (e->dim != 1) obs[n++] = (double)e->pos[1];
+    }
+    if (e->tail & ORC_TAIL_PLAN) {
+        if (e->dim == 1) for (int i = 0; i < 30; ++i) obs[n++] = (double)e->plan[i];
+        else for (int r = 3; r < 23; ++r) for (int c = 3; c < 23; ++c) obs[n++] = (double)P(e, r, c);
+    }
+    if (e->tail & ORC_TAIL_RECORD) {
+        obs[n++] = (double)e->last_reward; obs[n++] = (double)e->last_done;
+        obs[n++] = (double)e->pos[0]; obs[n++] = (double)e->pos[1];
+        obs[n++] = (double)e->cb; obs[n++] = (double)e->cs; obs[n++] = (double)e->tb; obs[n++] = (double)e->plan_idx;
     }
 }
 
@@ -101,6 +124,7 @@ int orc_reset(orc_env* e, const int32_t* plan, int plan_idx, double* obs) {
     e->pos[0] = e->hw;                               /* S1:77, D2:60 */
     e->pos[1] = (e->dim == 1) ? 0 : e->hw;
     if (e->dim == 3) e->step_size = 1;               /* S3:78, D3:66 */
+    e->last_reward = 0; e->last_done = 0;
     if (obs) orc_observe(e, obs);
     return 0;
 }
@@ -259,6 +283,7 @@ int orc_step(orc_env* e, int action, int k, double* obs, double* reward, int* do
     else if (e->dim == 2) rc = step2(e, action, k, &r, &d);
     else rc = step3(e, action, k, &r, &d);
     if (rc) return rc;
+    e->last_reward = (int32_t)r; e->last_done = d;
     if (obs) orc_observe(e, obs);
     if (reward) *reward = r;
     if (done) *done = d;
@@ -440,6 +465,11 @@ orc_batch* orc_batch_create(int dim, int dynamic, int n, const int32_t* plans, i
 
 void orc_batch_set_rules(orc_batch* b, int brick_gt, int time_gt) {
     for (int i = 0; i < b->n; ++i) orc_set_rules(&b->envs[i], brick_gt, time_gt);
+}
+
+void orc_batch_configure(orc_batch* b, int obs_norm, int rules_dyn, int total_step, int frame, int tail) {
+    for (int i = 0; i < b->n; ++i) { orc_configure(&b->envs[i], obs_norm, rules_dyn, total_step, frame); orc_set_tail(&b->envs[i], tail); }
+    b->obs_dim = b->envs[0].obs_dim; b->total_step = b->envs[0].total_step;
 }
 
 void orc_batch_destroy(orc_batch* b) {

@@ -46,12 +46,18 @@ typedef struct orc_env {
     int32_t frame;       /* value of the frame cells: -1, or 2 in the 2D L-Net variant */
     int32_t brick_gt;    /* 1: done when cb > tb (script/PPO copies), 0: cb >= tb */
     int32_t time_gt;     /* 1: done when cs > T (script/PPO/3d_static), 0: cs >= T */
+    int32_t tail;        /* ORC_TAIL_* bits appended to the observation row (layout variants, see orc_set_tail) */
+    int32_t last_reward, last_done;   /* of the last step (0, 0 after reset): what ORC_TAIL_RECORD reports */
 } orc_env;
+enum { ORC_TAIL_POSITION = 1, ORC_TAIL_PLAN = 2, ORC_TAIL_RECORD = 4 };
 
 /* ---- single env ---- */
 int  orc_init(orc_env* e, int dim, int dynamic);
 int  orc_configure(orc_env* e, int obs_norm, int rules_dyn, int total_step, int frame);
 int  orc_set_rules(orc_env* e, int brick_gt, int time_gt);   /* the `>` termination tests of the script/PPO env copies */
+/* observation-row tails of the reference's env copies (include/snac_hip.h obs_tail): position (Env/1D/DMP_Env_1D_static_Lnet.py:83),
+ * the plan (script/PPO/2d_dynamic/DMP_Env_2d_dynamic_usedata_plan.py:70-71), and the build's own 8-value record; updates obs_dim */
+int  orc_set_tail(orc_env* e, int tail);
 /* plan: 30 (1D) or 676 (2D/3D) ints; obs: obs_dim doubles (may be NULL) */
 int  orc_reset(orc_env* e, const int32_t* plan, int plan_idx, double* obs);
 /* returns 0, or -1 for an action outside [0, num_actions) (the reference raises after cs += 1) */
@@ -95,6 +101,8 @@ orc_batch* orc_batch_create(int dim, int dynamic, int n, const int32_t* plans, i
                             uint64_t seed, int64_t env_id_base);
 void orc_batch_destroy(orc_batch* b);
 void orc_batch_set_rules(orc_batch* b, int brick_gt, int time_gt);
+/* layout / rule switches of every env (orc_configure + orc_set_tail); updates the batch's obs_dim and total_step */
+void orc_batch_configure(orc_batch* b, int obs_norm, int rules_dyn, int total_step, int frame, int tail);
 /* mask NULL = all; plan_idx_in NULL = counter RNG (dynamic) / plan 0 (static); obs [n][obs_dim] or NULL */
 int  orc_batch_reset(orc_batch* b, const uint8_t* mask, const int32_t* plan_idx_in, double* obs);
 /* one vector step at tick t.  actions/step_size NULL = counter RNG.  auto_reset: envs whose previous

@@ -25,7 +25,8 @@ class _Env(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "dynamic", "hw", "H", "W", "total_step", "num_actions", "obs_dim")] + [
         ("grid", C.c_int32 * MAX_CELLS), ("plan", C.c_int32 * MAX_CELLS), ("pos", C.c_int32 * 2),
         ("cb", C.c_int32), ("cs", C.c_int32), ("tb", C.c_int32), ("step_size", C.c_int32), ("plan_idx", C.c_int32),
-        ("obs_norm", C.c_int32), ("rules_dyn", C.c_int32), ("frame", C.c_int32), ("brick_gt", C.c_int32), ("time_gt", C.c_int32)]
+        ("obs_norm", C.c_int32), ("rules_dyn", C.c_int32), ("frame", C.c_int32), ("brick_gt", C.c_int32), ("time_gt", C.c_int32),
+        ("tail", C.c_int32), ("last_reward", C.c_int32), ("last_done", C.c_int32)]
 
 
 class _Batch(C.Structure):
@@ -74,6 +75,8 @@ def lib():
         L.orc_batch_iou.argtypes = [C.POINTER(_Batch), C.c_void_p]
         L.orc_set_rules.argtypes = [C.POINTER(_Env), C.c_int, C.c_int]
         L.orc_batch_set_rules.argtypes = [C.POINTER(_Batch), C.c_int, C.c_int]
+        L.orc_set_tail.argtypes = [C.POINTER(_Env), C.c_int]
+        L.orc_batch_configure.argtypes = [C.POINTER(_Batch), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_transition.argtypes = [C.POINTER(_Env), C.POINTER(_Env), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.orc_set_state.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -121,6 +124,11 @@ class OracleEnv:
 
     def set_rules(self, brick_gt=False, time_gt=False):
         lib().orc_set_rules(C.byref(self.e), int(brick_gt), int(time_gt))
+        return self
+
+    def set_tail(self, tail):
+        """ORC_TAIL_* bits (1 position, 2 plan, 4 record) appended to every observation row."""
+        self.obs_dim = lib().orc_set_tail(C.byref(self.e), int(tail))
         return self
 
     def reset(self, plan, plan_idx=0):
@@ -186,6 +194,15 @@ class OracleBatch:
 
     def set_rules(self, brick_gt=False, time_gt=False):
         lib().orc_batch_set_rules(self.b, int(brick_gt), int(time_gt))
+        return self
+
+    def configure(self, obs_norm=None, rules_dyn=None, total_step=0, frame=-1, tail=0):
+        """Layout / rule switches of every env: obs_norm (None: = dynamic), rules_dyn (None: = dynamic), total_step (0: keep),
+        frame value, tail bits (1 position, 2 plan, 4 record)."""
+        on = self.dynamic if obs_norm is None else obs_norm
+        rd = self.dynamic if rules_dyn is None else rules_dyn
+        lib().orc_batch_configure(self.b, int(on), int(rd), int(total_step), int(frame), int(tail))
+        self.obs_dim, self.total_step = self.b.contents.obs_dim, self.b.contents.total_step
         return self
 
     def set_total_step(self, total_step):

@@ -10,14 +10,17 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SNAC_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 ENV_1D, ENV_2D, ENV_3D = 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 OBS_NONE, OBS_ALL, OBS_LAST = 0, 1, 2
 FLAG_NEED_RESET = 1
 RULE_BRICK_GT, RULE_TIME_GT = 1, 2
+SCALARS_DEFAULT, SCALARS_RAW, SCALARS_NORM = 0, 1, 2
+TAIL_POSITION, TAIL_PLAN, TAIL_RECORD = 1, 2, 4
 
-EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_reset", "snac_step", "snac_rollout",
+EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_obs_dim", "snac_reset", "snac_reset_scalar", "snac_step",
+           "snac_step_scalar", "snac_rollout",
            "snac_rollout_rec", "snac_replay_gather", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
            "snac_import_state", "snac_obs_equal")
 
@@ -31,7 +34,8 @@ class Sizes(C.Structure):
 class EnvDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dynamic", C.c_int32), ("num_envs", C.c_int32), ("num_plans", C.c_int32),
                 ("obs_dtype", C.c_int32), ("static_plan", C.c_int32), ("seed", C.c_uint64), ("env_id_base", C.c_int64),
-                ("total_step", C.c_int32), ("rules", C.c_int32)]
+                ("total_step", C.c_int32), ("rules", C.c_int32), ("frame_value", C.c_int32), ("obs_scalars", C.c_int32),
+                ("obs_tail", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RolloutRecord(C.Structure):
@@ -74,7 +78,10 @@ def lib():
         L.snac_version.restype = C.c_int
         L.snac_last_error.restype = C.c_char_p
         L.snac_env_sizes.argtypes = [C.c_int, C.c_int, C.POINTER(Sizes)]
+        L.snac_obs_dim.argtypes = [C.POINTER(EnvDesc)]
         L.snac_reset.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp, vp, vp]
+        L.snac_reset_scalar.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, vp, vp]
+        L.snac_step_scalar.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_uint32, C.c_int32, C.c_int32, C.c_int, vp, vp, vp, vp]
         L.snac_step.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_uint32, vp, vp, C.c_int, vp, vp, vp, vp]
         L.snac_rollout.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, C.c_uint32, vp, vp, C.c_int, vp, vp, vp, vp]
         L.snac_rollout_rec.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, C.c_uint32, vp, vp, C.c_int, vp, vp, vp,

@@ -32,11 +32,21 @@ class BatchedDMPEnv:
     seed      counter-RNG seed (include/snac_hip.h); env_id_base: global id of local env 0 (multi-GPU shards)
     brick_gt / time_gt   the strict termination tests of the env copies under script/PPO (SNAC_RULE_* in snac_hip.h):
               done when count_brick > total_brick / count_step > total_step instead of >=
+    layout    observation layout of the reference's env copies, produced by the same kernels (snac_env_desc.frame_value /
+              obs_scalars / obs_tail): None = the canonical classes; "lnet1d" (Env/1D/DMP_Env_1D_static_Lnet.py: position
+              appended, 8 values), "lnet2d" (Env/2D/DMP_Env_2D_static_Lnet.py: frame cells 2, normalised scalars), "ppo"
+              (script/PPO/*: raw counters; the dataset classes append the plan: 37 / 451 values).  Or set the three fields
+              directly: frame_value (-1 | 2), obs_scalars ("raw" | "norm" | None), obs_tail (iterable of "position", "plan",
+              "record", or the bit set).
     """
+
+    LAYOUTS = {None: {}, "lnet1d": dict(obs_tail=("position",)), "lnet2d": dict(frame_value=2, obs_scalars="norm"),
+               "ppo": dict(obs_scalars="raw"), "ppo_plan": dict(obs_scalars="raw", obs_tail=("plan",))}
+    _TAILS = {"position": _lib.TAIL_POSITION, "plan": _lib.TAIL_PLAN, "record": _lib.TAIL_RECORD}
 
     def __init__(self, kind, dynamic, num_envs, plans=None, plan_choose=0, density="dense", split="train",
                  device="cuda", seed=1, obs_dtype=torch.float64, env_id_base=0, total_step=None, plan_tb=None,
-                 brick_gt=False, time_gt=False):
+                 brick_gt=False, time_gt=False, layout=None, frame_value=None, obs_scalars=None, obs_tail=None, static_plan=0):
         if not torch.cuda.is_available():
             raise _lib.SnacError("BatchedDMPEnv needs a ROCm GPU: there is no CPU fallback")
         self.kind = _KINDS[kind]
@@ -55,7 +65,19 @@ class BatchedDMPEnv:
         self._lib = _lib.lib()
         sz = _lib.env_sizes(self.kind, self.dynamic)
         self.sizes = sz
-        self.obs_dim, self.num_actions = sz.obs_dim, sz.num_actions
+        self.num_actions = sz.num_actions
+        if layout == "ppo" and dynamic:
+            layout = "ppo_plan"                                  # the dataset copies under script/PPO append the plan
+        lay = dict(self.LAYOUTS[layout])
+        for key, val in (("frame_value", frame_value), ("obs_scalars", obs_scalars), ("obs_tail", obs_tail)):
+            if val is not None:
+                lay[key] = val
+        self.frame_value = int(lay.get("frame_value", -1))
+        self.obs_scalars = lay.get("obs_scalars")
+        tail = lay.get("obs_tail", 0)
+        if not isinstance(tail, int):
+            tail = sum(self._TAILS[t] for t in set(tail))
+        self.obs_tail = int(tail)
         self.total_step = int(total_step) if total_step else sz.total_step   # override: the 3D L-Net variant (1300)
         if plans is None:
             if self.dynamic:
@@ -77,10 +99,18 @@ class BatchedDMPEnv:
         self._grid = torch.zeros((N, sz.grid_elems), dtype=_GRID_DTYPE[self.kind], device=dev)
         self._stats = torch.zeros((3, N), dtype=torch.int64, device=dev)
         self._desc = _lib.EnvDesc(self.kind, int(self.dynamic), N, self.num_plans,
-                                  _lib.OBS_F64 if obs_dtype == torch.float64 else _lib.OBS_F32, 0,
+                                  _lib.OBS_F64 if obs_dtype == torch.float64 else _lib.OBS_F32, int(static_plan),
                                   self.seed & 0xFFFFFFFFFFFFFFFF, self.env_id_base, self.total_step,
-                                  (_lib.RULE_BRICK_GT if brick_gt else 0) | (_lib.RULE_TIME_GT if time_gt else 0))
+                                  (_lib.RULE_BRICK_GT if brick_gt else 0) | (_lib.RULE_TIME_GT if time_gt else 0),
+                                  self.frame_value,
+                                  {None: _lib.SCALARS_DEFAULT, "raw": _lib.SCALARS_RAW, "norm": _lib.SCALARS_NORM}[self.obs_scalars],
+                                  self.obs_tail, 0)
+        self.obs_dim = self._lib.snac_obs_dim(C.byref(self._desc))   # values per observation row, tail included
+        if self.obs_dim < 0:
+            _lib.check(self.obs_dim)
+        self.base_obs_dim = sz.obs_dim
         self.brick_gt, self.time_gt = bool(brick_gt), bool(time_gt)
+        self.static_plan = int(static_plan)
         self._state = _lib.State(self._hdr.data_ptr(), self._episode.data_ptr(), self._grid.data_ptr(),
                                  self._plans.data_ptr(), self._plan_tb.data_ptr(), self._stats[0].data_ptr(),
                                  self._stats[1].data_ptr(), self._stats[2].data_ptr())
@@ -163,6 +193,31 @@ class BatchedDMPEnv:
                 _lib.check(self._lib.snac_step(*args, self._stream()))
         self.t += 1
         return obs, reward, done.view(torch.bool)
+
+    def step_scalar(self, action, step_size, auto_reset=False, out=None):
+        """step() with ONE action and ONE step size for every env, passed by value (snac_step_scalar): no host-to-device copy
+        precedes the launch.  With obs_tail "record" the row also carries reward, done and the header, so a single-env caller
+        reads everything back with one copy.  out: preallocated obs [N, obs_dim].  Returns obs."""
+        if not self._was_reset:
+            raise _lib.SnacError("step() before reset()")
+        obs = self._new_obs() if out is None else self._buf(out, (self.num_envs, self.obs_dim), self.obs_dtype, "out")
+        args = (C.byref(self._desc), C.byref(self._state), self.t & 0xFFFFFFFF, int(action), int(step_size), int(bool(auto_reset)),
+                _ptr(obs), None, None)
+        if torch.cuda.current_device() == self.device.index:
+            _lib.check(self._lib.snac_step_scalar(*args, self._stream()))
+        else:
+            with torch.cuda.device(self.device):
+                _lib.check(self._lib.snac_step_scalar(*args, self._stream()))
+        self.t += 1
+        return obs
+
+    def reset_scalar(self, plan_idx, out=None):
+        """reset() of every env onto plan row `plan_idx`, passed by value (snac_reset_scalar).  Returns obs [N, obs_dim]."""
+        obs = self._new_obs() if out is None else self._buf(out, (self.num_envs, self.obs_dim), self.obs_dtype, "out")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_reset_scalar(C.byref(self._desc), C.byref(self._state), int(plan_idx), _ptr(obs), self._stream()))
+        self._was_reset = True
+        return obs
 
     def _buf(self, t, shape, dtype, what):
         if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != self.device or not t.is_contiguous():
@@ -251,7 +306,9 @@ class BatchedDMPEnv:
         index = torch.as_tensor(index, device=self.device, dtype=torch.long)
         child = BatchedDMPEnv(self.kind, self.dynamic, int(index.numel()), plans=self.plans_full, device=self.device, seed=self.seed,
                               obs_dtype=self.obs_dtype, env_id_base=self.env_id_base, total_step=self.total_step,
-                              brick_gt=self.brick_gt, time_gt=self.time_gt)
+                              brick_gt=self.brick_gt, time_gt=self.time_gt, frame_value=self.frame_value,
+                              obs_scalars=self.obs_scalars, obs_tail=self.obs_tail, static_plan=self.static_plan)
+        child._plan_tb.copy_(self._plan_tb)                          # caller-supplied total_brick rows travel with the fork
         child._hdr.copy_(self._hdr[index]); child._episode.copy_(self._episode[index]); child._grid.copy_(self._grid[index])
         child.t = self.t
         child._was_reset = self._was_reset

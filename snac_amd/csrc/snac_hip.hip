@@ -539,24 +539,26 @@ __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int
         const double* scp = K::sc(lds);
         const int* posp = K::pos(lds);
         const int total = nenv * LD;
-        for (int q = lane; q < total; q += 64) {
+        for (int q0 = 0; q0 < total; q0 += 64) {                     // uniform trip count: the tail's bpermutes need every lane
+            const int q = min(q0 + lane, total - 1);
             const int e = q / LD, el = q - e * LD;
             int v = h[e * K::ES + posp[e] - 2 + min(el, K::W - 1)];
             if constexpr (VAR) v = v < 0 ? a.frame_val : v;
             double val = el < K::W ? (double)v : scp[2 * e + (el >= K::W + 1 ? 1 : 0)];
             if constexpr (VAR) {
-                if (el >= K::D) {                                    // the tail: e differs per lane -> lane e's scalars by bpermute
-                    int ti = el - K::D, out = 0;
+                if (a.tail) {                                        // wave-uniform; e differs per lane -> lane e's scalars by bpermute
                     const int pos = posp[e], pidx = __shfl(s.pidx, e);
-                    if (a.tail & SNAC_TAIL_POSITION) { if (ti == 0) out = pos; ti -= 1; }
-                    if (a.tail & SNAC_TAIL_PLAN) { if (ti >= 0 && ti < K::PLAN_CELLS) out = K::plan_value(a, pidx, ti); ti -= K::PLAN_CELLS; }
-                    const int rec = record_value(ti, __shfl(so.reward, e), __shfl(so.done, e), pos, 0, __shfl(s.cb, e), __shfl(s.cs, e),
-                                                 __shfl(s.tb, e), pidx);
-                    if ((a.tail & SNAC_TAIL_RECORD) && ti >= 0) out = rec;
-                    val = (double)out;
+                    const int rw = __shfl(so.reward, e), dn = __shfl(so.done, e), cb = __shfl(s.cb, e), cs = __shfl(s.cs, e), tb = __shfl(s.tb, e);
+                    if (el >= K::D) {
+                        int ti = el - K::D, out = 0;
+                        if (a.tail & SNAC_TAIL_POSITION) { if (ti == 0) out = pos; ti -= 1; }
+                        if (a.tail & SNAC_TAIL_PLAN) { if (ti >= 0 && ti < K::PLAN_CELLS) out = K::plan_value(a, pidx, ti); ti -= K::PLAN_CELLS; }
+                        if ((a.tail & SNAC_TAIL_RECORD) && ti >= 0) out = record_value(ti, rw, dn, pos, 0, cb, cs, tb, pidx);
+                        val = (double)out;
+                    }
                 }
             }
-            orow[q] = (OT)val;
+            if (q0 + lane < total) orow[q] = (OT)val;
         }
     }
 }
@@ -601,9 +603,10 @@ __device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, cons
 // EXPL: actions and / or step sizes come from the caller's arrays.  The counter-RNG instantiation (EXPL = false) has no
 // global load in its loop at all: with the null tests at run time the compiler joins both paths behind one
 // `s_waitcnt vmcnt(0)`, and vmcnt counts the observation stores too -- every tick would wait for the previous tick's rows.
-template <class K, typename OT, int WPB, bool EXPL>
+template <class K, typename OT, int WPB, bool EXPL, bool VAR>
 __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
     constexpr int E = K::E;
+    const int LD = VAR ? a.ld : K::D;
     const int lane = threadIdx.x & 63;
     const int tile = (int)blockIdx.x * WPB + (int)(threadIdx.x >> 6);
     const int env0 = __builtin_amdgcn_readfirstlane(tile * E);
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
         }
         if (a.obs_mode == SNAC_OBS_ALL || (a.obs_mode == SNAC_OBS_LAST && t == a.T - 1)) {
             const size_t orow = a.obs_mode == SNAC_OBS_ALL ? row : (size_t)env0;
-            emit_obs<K, OT>(lds, obs + orow * K::D, nenv, s, a.total_step, lane);
+            emit_obs<K, OT, VAR>(lds, obs + orow * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
         }
     }
     K::store_grid(lds, a, env0, nenv, lane);
@@ -689,9 +692,10 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
 // a.n tree edges.  The state arrays are a node pool; edge i reads row src_index[i] and writes row dst_index[i] (out of
 // place), the observation / reward / done rows are per edge.  snac_transition: no auto-reset, no episodic sums (a search
 // is not an episode).  snac_step is the same kernel on the identity rows with both switched on.
-template <class K, typename OT, int WPB>
+template <class K, typename OT, int WPB, bool VAR>
 __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
     constexpr int E = K::E;
+    const int LD = VAR ? a.ld : K::D;
     const int lane = threadIdx.x & 63;
     const int tile = (int)blockIdx.x * WPB + (int)(threadIdx.x >> 6);
     const int env0 = __builtin_amdgcn_readfirstlane(tile * E);
@@ -727,8 +731,11 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
     bool done = false;
     if (active) {
         const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
-        const int act = a.actions ? (int)a.actions[edge] : (int)(((w >> 16) * (uint32_t)K::A) >> 16);
-        const int k = a.step_size ? min(max((int)a.step_size[edge], 1), 3) : 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+        int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+        if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }   // snac_step_scalar: by value, no input arrays
+        if (a.actions) act = (int)a.actions[edge];
+        if (a.step_size) k = (int)a.step_size[edge];
+        k = min(max(k, 1), 3);
         K::step(lds, a, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
         s.ep_ret = clamp16(s.ep_ret + reward);
         s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
@@ -748,16 +755,17 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
             a.stat_iou_fx[drow] += __double2ll_rn(v * FX40);
         }
     }
-    if (a.obs) emit_obs<K, OT>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s, a.total_step, lane);
+    if (a.obs) emit_obs<K, OT, VAR>(lds, (OT*)a.obs + (size_t)env0 * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
     if (a.dst_index && active) rows[lane] = (int)drow;           // the scalar slots have been written out by now
     K::store_grid(lds, a, env0, nenv, lane, a.dst_index ? rows : nullptr);
     if (active) { a.hdr[drow] = s.pack(); a.episode[drow] = episode; }
 }
 
 // reset(mask, plan_idx_in) / observe / iou on the same tile machinery
-template <class K, typename OT, int WPB>
+template <class K, typename OT, int WPB, bool VAR>
 __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
     constexpr int E = K::E;
+    const int LD = VAR ? a.ld : K::D;
     const int lane = threadIdx.x & 63;
     const int tile = (int)blockIdx.x * WPB + (int)(threadIdx.x >> 6);
     const int env0 = __builtin_amdgcn_readfirstlane(tile * E);
@@ -780,6 +788,7 @@ __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
             const int episode = a.episode[env] + 1;
             int pidx;
             if (a.plan_idx_in) pidx = a.plan_idx_in[env];
+            else if (a.plan_scalar >= 0) pidx = a.plan_scalar;
             else pidx = pick_plan<K>(a, env_keys(a.key_plan, (uint64_t)(a.env_id_base + env)), episode, a.static_plan);
             pidx = min(max(pidx, 0), a.num_plans - 1);
             K::reset(a, s, pidx);
@@ -793,7 +802,8 @@ __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
         if (active) a.out_f64[env] = v;
         return;
     }
-    if (a.obs) emit_obs<K, OT>(lds, (OT*)a.obs + (size_t)env0 * K::D, nenv, s, a.total_step, lane);
+    // SNAC_TAIL_RECORD outside a step: reward 0, done = the env's pending-reset flag
+    if (a.obs) emit_obs<K, OT, VAR>(lds, (OT*)a.obs + (size_t)env0 * LD, nenv, s, a, lane, StepOut{0, (s.flags & SNAC_FLAG_NEED_RESET) ? 1 : 0});
 }
 
 // environment_memory with its -1 frame, float64 [N][H][W]; one thread per cell
@@ -804,7 +814,7 @@ __global__ void k_export(const KArgs a, long long total) {
         const long long env = i / (H * Wd);
         const int cellidx = (int)(i - env * (H * Wd));
         const int r = cellidx / Wd, c = cellidx - r * Wd;
-        int v = -1;
+        int v = a.frame_val;
         if (KIND == 1) {
             if (c >= HW && c < Wd - HW) v = ((const int16_t*)a.grid)[env * 32 + (c - HW)];
         } else if (r >= HW && r < H - HW && c >= HW && c < Wd - HW) {
@@ -890,7 +900,8 @@ __global__ __launch_bounds__(256) void k_equal(const OT* a, const int32_t* ia, i
     if (i >= m) return;
     const OT* pa = a + row_of(ia, rows_a, i) * D;
     const OT* pb = b + row_of(ib, rows_b, i) * D;
-    const bool differ = lane < D && !(pa[lane] == pb[lane]);
+    bool differ = false;
+    for (int j = lane; j < D; j += 64) differ = differ || !(pa[j] == pb[j]);
     const unsigned long long any = __ballot(differ);
     if (lane == 0) out[i] = any ? 0 : 1;
 }
@@ -902,6 +913,7 @@ __global__ __launch_bounds__(256) void k_equal(const OT* a, const int32_t* ia, i
 // the step opened an episode -- so sampling is a gather: one wave per sample, float32 out, plan expanded from the table.
 struct GArgs {
     int32_t n, cap, batch, num_plans;
+    int32_t ld, frame_val;     // row length (K::D, + the position tail) and frame value of the ring's layout
     const void* obs;
     const uint8_t* first;
     const int16_t* plan_idx;
@@ -923,17 +935,19 @@ __global__ __launch_bounds__(256) void k_gather(const GArgs g) {
     const size_t cur = (size_t)t * g.n + i, prev = (size_t)(t == 0 ? g.cap - 1 : t - 1) * g.n + i;
     const bool first = g.first[cur] != 0;
     const OT* o = (const OT*)g.obs;
-    if (lane < D) {
-        g.s_next[(size_t)b * D + lane] = (float)o[cur * D + lane];
+    const int LD = g.ld;                                         // D, or D + the position tail (1 / 2 values)
+    if (lane < LD) {
+        g.s_next[(size_t)b * LD + lane] = (float)o[cur * LD + lane];
         float sv;
         if (first) {   // reset observation: window at the start position over an empty grid, both scalar slots 0
             const int wi = lane / 7, wj = lane - 7 * wi;
             const bool frame = KIND == 1 ? lane < 2 : (wi < 3 || wj < 3);
-            sv = (lane < W && frame) ? -1.0f : 0.0f;
+            sv = (lane < W && frame) ? (float)g.frame_val : 0.0f;
+            if (lane >= D) sv = KIND == 1 ? 2.0f : 3.0f;         // position tail: the start position
         } else {
-            sv = (float)o[prev * D + lane];
+            sv = (float)o[prev * LD + lane];
         }
-        g.s[(size_t)b * D + lane] = sv;
+        g.s[(size_t)b * LD + lane] = sv;
     }
     if (g.plan_out) {
         const int p = min(max((int)g.plan_idx[cur], 0), g.num_plans - 1);
@@ -949,6 +963,20 @@ __global__ __launch_bounds__(256) void k_gather(const GArgs g) {
 
 // ------------------------------------------------------------------------------------------------
 // host side
+// the layout flags of the descriptor (include/snac_hip.h "Observation-layout variants")
+int check_layout(const snac_env_desc* d) {
+    if (d->frame_value != 0 && d->frame_value != -1 && d->frame_value != 2) return fail(SNAC_ERR_ARG, "frame_value must be -1 (or 0) or 2");
+    if (d->frame_value == 2 && d->kind == SNAC_ENV_3D) return fail(SNAC_ERR_UNSUPPORTED, "frame_value 2 is a 1D / 2D layout (the 3D rules test the frame for -1)");
+    if (d->obs_scalars < SNAC_SCALARS_DEFAULT || d->obs_scalars > SNAC_SCALARS_NORM) return fail(SNAC_ERR_ARG, "unknown obs_scalars");
+    if (d->obs_tail & ~(SNAC_TAIL_POSITION | SNAC_TAIL_PLAN | SNAC_TAIL_RECORD)) return fail(SNAC_ERR_ARG, "unknown bits in obs_tail");
+    return SNAC_OK;
+}
+int base_obs_dim(int kind) { return kind == SNAC_ENV_1D ? 7 : 51; }
+int tail_len(int kind, int tail) {
+    return ((tail & SNAC_TAIL_POSITION) ? (kind == SNAC_ENV_1D ? 1 : 2) : 0) + ((tail & SNAC_TAIL_PLAN) ? (kind == SNAC_ENV_1D ? 30 : 400) : 0) +
+           ((tail & SNAC_TAIL_RECORD) ? 8 : 0);
+}
+
 int check_common(const snac_env_desc* d, const snac_state* st) {
     if (!d || !st) return fail(SNAC_ERR_ARG, "null desc/state");
     if (d->kind < SNAC_ENV_1D || d->kind > SNAC_ENV_3D) return fail(SNAC_ERR_ARG, "unknown env kind");
@@ -959,6 +987,7 @@ int check_common(const snac_env_desc* d, const snac_state* st) {
     // the running return is an int16 and a step pays at most 10: 3000 steps cannot overflow it (the reference: <= 1300)
     if (d->total_step < 0 || d->total_step > 3000) return fail(SNAC_ERR_ARG, "total_step out of range (0..3000)");
     if (d->rules & ~(SNAC_RULE_BRICK_GT | SNAC_RULE_TIME_GT)) return fail(SNAC_ERR_ARG, "unknown bits in rules");
+    if (int rc = check_layout(d)) return rc;
     if (!st->hdr || !st->episode || !st->grid || !st->plans || !st->plan_tb || !st->stat_episodes || !st->stat_return ||
         !st->stat_iou_fx)
         return fail(SNAC_ERR_ARG, "null pointer in snac_state");
@@ -977,6 +1006,12 @@ KArgs make_args(const snac_env_desc* d, const snac_state* st) {
     a.env_id_base = d->env_id_base;
     a.hdr = (int4*)st->hdr; a.episode = st->episode; a.grid = st->grid; a.plans = st->plans; a.plan_tb = st->plan_tb;
     a.stat_episodes = st->stat_episodes; a.stat_return = st->stat_return; a.stat_iou_fx = st->stat_iou_fx;
+    a.plan_scalar = -1;
+    a.frame_val = d->frame_value == 2 ? 2 : -1;
+    a.sc_norm = d->obs_scalars == SNAC_SCALARS_DEFAULT ? (d->dynamic ? 1 : 0) : (d->obs_scalars == SNAC_SCALARS_NORM ? 1 : 0);
+    a.tail = d->obs_tail;
+    a.ld = base_obs_dim(d->kind) + tail_len(d->kind, d->obs_tail);
+    a.variant = (a.frame_val != -1 || a.sc_norm != (d->dynamic ? 1 : 0) || a.tail != 0) ? 1 : 0;
     return a;
 }
 
@@ -986,12 +1021,18 @@ template <class K, typename OT, int WPB>
 void launch_k(Op op, const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + K::E - 1) / K::E;
     const dim3 grid((unsigned)((tiles + WPB - 1) / WPB)), block(WPB * 64);
-    if (op == OP_ROLLOUT) {
-        if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout<K, OT, WPB, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_rollout<K, OT, WPB, false>), grid, block, 0, s, a);
+    if (a.variant) {                                             // layout variants: their own instantiations, the canonical ones stay lean
+        if (op == OP_ROLLOUT) hipLaunchKernelGGL((k_rollout<K, OT, WPB, true, true>), grid, block, 0, s, a);
+        else if (op == OP_TRANSITION) hipLaunchKernelGGL((k_transition<K, OT, WPB, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_aux<K, OT, WPB, true>), grid, block, 0, s, a);
+        return;
     }
-    else if (op == OP_TRANSITION) hipLaunchKernelGGL((k_transition<K, OT, WPB>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_aux<K, OT, WPB>), grid, block, 0, s, a);
+    if (op == OP_ROLLOUT) {
+        if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout<K, OT, WPB, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_rollout<K, OT, WPB, false, false>), grid, block, 0, s, a);
+    }
+    else if (op == OP_TRANSITION) hipLaunchKernelGGL((k_transition<K, OT, WPB, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_aux<K, OT, WPB, false>), grid, block, 0, s, a);
 }
 
 template <template <bool, int> class KT, bool DYN, int E, int WPB>
@@ -1064,6 +1105,32 @@ int snac_env_sizes(int kind, int dynamic, snac_sizes* o) {
     return SNAC_OK;
 }
 
+int snac_obs_dim(const snac_env_desc* d) {
+    if (!d) return fail(SNAC_ERR_ARG, "null desc");
+    if (d->kind < SNAC_ENV_1D || d->kind > SNAC_ENV_3D) return fail(SNAC_ERR_ARG, "unknown env kind");
+    if (int rc = check_layout(d)) return rc;
+    return base_obs_dim(d->kind) + tail_len(d->kind, d->obs_tail);
+}
+
+int snac_reset_scalar(const snac_env_desc* d, const snac_state* st, int32_t plan_idx, void* obs, void* stream) {
+    if (int rc = check_common(d, st)) return rc;
+    if (plan_idx < 0 || plan_idx >= d->num_plans) return fail(SNAC_ERR_ARG, "plan_idx out of range");
+    KArgs a = make_args(d, st);
+    a.aux_op = AUX_RESET; a.plan_scalar = plan_idx; a.obs = obs;
+    return launch(OP_AUX, d, a, stream);
+}
+
+int snac_step_scalar(const snac_env_desc* d, const snac_state* st, uint32_t t, int32_t action, int32_t step_size, int auto_reset,
+                     void* obs, float* reward, uint8_t* done, void* stream) {
+    if (int rc = check_common(d, st)) return rc;
+    KArgs a = make_args(d, st);
+    a.pool = d->num_envs; a.stats_on = 1;
+    a.T = 1; a.t0 = t; a.auto_reset = auto_reset ? 1 : 0; a.obs_mode = obs ? SNAC_OBS_ALL : SNAC_OBS_NONE;
+    a.use_scalar = 1; a.act_scalar = action; a.k_scalar = step_size;
+    a.obs = obs; a.reward = reward; a.done = done;
+    return launch(OP_TRANSITION, d, a, stream);
+}
+
 int snac_reset(const snac_env_desc* d, const snac_state* st, const uint8_t* mask, const int16_t* plan_idx_in, void* obs,
                void* stream) {
     if (int rc = check_common(d, st)) return rc;
@@ -1102,8 +1169,10 @@ int snac_replay_gather(const snac_env_desc* d, const snac_state* st, int32_t cap
     if (cap < 2 || batch < 0) return fail(SNAC_ERR_ARG, "cap must be >= 2 and batch >= 0");
     if (!obs_ring || !first_ring || !tick_idx || !env_idx || !s_out || !s_next_out) return fail(SNAC_ERR_ARG, "null pointer");
     if (plan_out && !plan_idx_ring) return fail(SNAC_ERR_ARG, "plan_out needs plan_idx_ring");
+    if (d->obs_tail & ~SNAC_TAIL_POSITION) return fail(SNAC_ERR_UNSUPPORTED, "replay gather supports the position tail only");
     if (batch == 0) return SNAC_OK;
     GArgs g;
+    g.ld = base_obs_dim(d->kind) + tail_len(d->kind, d->obs_tail); g.frame_val = d->frame_value == 2 ? 2 : -1;
     g.n = d->num_envs; g.cap = cap; g.batch = batch; g.num_plans = d->num_plans;
     g.obs = obs_ring; g.first = first_ring; g.plan_idx = plan_idx_ring; g.tick = tick_idx; g.env = env_idx;
     g.plans = st->plans; g.s = s_out; g.s_next = s_next_out; g.plan_out = plan_out;
@@ -1176,7 +1245,8 @@ int snac_obs_equal(const snac_env_desc* d, const void* obs_a, const int32_t* idx
     if (!obs_a || !obs_b || !out) return fail(SNAC_ERR_ARG, "null pointer");
     if (m == 0) return SNAC_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int D = d->kind == SNAC_ENV_1D ? 7 : 51;
+    if (int rc = check_layout(d)) return rc;
+    const int D = base_obs_dim(d->kind) + tail_len(d->kind, d->obs_tail);   // <= 459 values: the wave strides over the row
     const dim3 grid((unsigned)((m + 3) / 4)), block(256);
     if (d->obs_dtype == SNAC_OBS_F32)
         hipLaunchKernelGGL((k_equal<float>), grid, block, 0, s, (const float*)obs_a, idx_a, rows_a, (const float*)obs_b, idx_b, rows_b, m, D, out);

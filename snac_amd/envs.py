@@ -47,27 +47,38 @@ class _Facade(_Base):
     _dim = 0
     _dynamic = False
 
+    _layout = {}                # extra BatchedDMPEnv layout arguments of a variant class (frame_value / obs_scalars / obs_tail)
+
     def _setup(self, plans_full, total_step=None):
         from .batched import BatchedDMPEnv  # imports torch; raises without a ROCm GPU
 
+        lay = dict(self._layout)
+        tail = tuple(lay.pop("obs_tail", ())) + ("record",)
+        # obs_tail "record": every reset() / step() is ONE launch and ONE device-to-host copy -- the row carries the
+        # observation, reward, done, position and counters (SNAC_TAIL_RECORD); action / step size / plan index travel by value
         self._env = BatchedDMPEnv(self._dim, self._dynamic, 1, plans=plans_full, total_step=total_step,
-                                  brick_gt=getattr(self, "_brick_gt", False), time_gt=getattr(self, "_time_gt", False))
+                                  brick_gt=getattr(self, "_brick_gt", False), time_gt=getattr(self, "_time_gt", False),
+                                  obs_tail=tail, **lay)
         self._table = np.asarray(plans_full, np.float64)
+        self._row = self._env._new_obs()                       # reused device row
+        self._nobs = self._env.obs_dim - 8                     # the observation proper (with the variant's own tail)
 
     # ---- shared plumbing ---------------------------------------------------------------------------
-    def _hdr(self):
-        h8 = self._env._hdr.cpu().numpy().view(np.int8).reshape(-1)
-        h16 = h8.view(np.int16)
-        return int(h8[0]), int(h8[1]), int(h16[2]), int(h16[3]), int(h16[4])
+    def _read(self):
+        """The one device-to-host copy of a reset() / step(): -> (obs [1, n], reward, done, r, c, cb, cs, tb)."""
+        row = self._row.cpu().numpy()
+        rec = row[0, self._nobs:]
+        return row[:, :self._nobs], float(rec[0]), bool(rec[1]), int(rec[2]), int(rec[3]), int(rec[4]), int(rec[5]), int(rec[6])
 
     def _do_reset(self, plan_idx):
         if getattr(self, "_plan_dirty", False):                # a hindsight relabel changed the device row: restore it
             self._env.set_plan_row(self._dirty_row, self._table[self._dirty_row])
             self._plan_dirty = False
-        obs = self._env.reset(plan_idx=np.asarray([plan_idx], np.int16)).cpu().numpy()
+        self._env.reset_scalar(plan_idx, out=self._row)
+        obs, _, _, r, c, cb, cs, tb = self._read()
         self.plan = self._table[plan_idx].copy()               # a fresh array per reset, like create_plan()
         self._sent_plan = self.plan.copy()
-        r, c, cb, cs, tb = self._hdr()
+        self._cur_plan_idx = int(plan_idx)
         self.total_brick = float(tb)
         self.count_step = 0
         self.observation = None
@@ -75,23 +86,20 @@ class _Facade(_Base):
         return obs, (r, c)
 
     def _do_step(self, action, step_size=None):
-        import torch
-
         if step_size is None:
             self.step_size = int(np.random.randint(1, 4))      # drawn on EVERY step, like the reference
         else:
             self.step_size = int(step_size)                    # hindsight variants: injected by the caller
         a = int(action)
         bad = not (0 <= a < self.action_dim) and self._dim != 3
-        send = a if -128 <= a <= 127 else 127
-        obs, reward, done = self._env.step(torch.tensor([send], dtype=torch.int8), torch.tensor([self.step_size], dtype=torch.int8))
+        self._env.step_scalar(a if -2 ** 31 <= a < 2 ** 31 else -1, self.step_size, out=self._row)
         if bad:  # the reference leaves `position` unbound here, after count_step and the RNG have advanced
             self.count_step += 1
             raise UnboundLocalError("local variable 'position' referenced before assignment")
-        r, c, cb, cs, tb = self._hdr()
+        obs, reward, done, r, c, cb, cs, tb = self._read()
         self.count_step = cs
         self._set_cb(cb)
-        return obs.cpu().numpy(), float(reward.item()), bool(done.item()), (r, c)
+        return obs, reward, done, (r, c)
 
     def _set_cb(self, cb):
         self.count_brick = cb
@@ -102,7 +110,7 @@ class _Facade(_Base):
         Push such a change to the device plan row; total_brick keeps the value computed by reset(), as in the reference."""
         cur = np.asarray(self.plan, np.float64)
         if not np.array_equal(cur, self._sent_plan):
-            self._dirty_row = int(self._env.plan_idx[0])
+            self._dirty_row = self._cur_plan_idx
             self._env.set_plan_row(self._dirty_row, cur)
             self._sent_plan = cur.copy()
             self._plan_dirty = True
@@ -162,10 +170,10 @@ class _Env1D(_Facade):
     def iou(self):
         return float(self._env.iou().item())
 
-    def _after_step(self, action, pos):
+    def _after_step(self, action, pos, obs):
         self.position_memory.append(pos)
         if action == 2:
-            self.brick_memory.append([pos, float(self.environment_memory[0, pos])])
+            self.brick_memory.append([pos, float(obs[0, 2])])    # environment_memory[0, pos] = the window centre
         else:
             self.brick_memory.append([-1, -1])
 
@@ -212,12 +220,12 @@ class deep_mobile_printing_1d1r_static(_Env1D):
         self.total_brick = float(self.total_brick)
         self.brick_memory = [[-1, -1]]
         self.position_memory = [r]
-        return obs.reshape(1, 7)
+        return obs
 
     def step(self, action, _step_size=None):
         obs, reward, done, (r, _) = self._do_step(action, _step_size)
-        self._after_step(action, r)
-        return obs.reshape(1, 7), reward, done
+        self._after_step(action, r, obs)
+        return obs, reward, done
 
 
 class deep_mobile_printing_1d1r_hindsight(deep_mobile_printing_1d1r_static):
@@ -251,13 +259,13 @@ class deep_mobile_printing_1d1r_hindsight_dynamic(_Env1D):
         self.total_brick = area
         self.brick_memory = [[-1, -1]]
         self.position_memory = [r]
-        return [obs.reshape(1, 7), self.plan]
+        return [obs, self.plan]
 
     def step(self, action, step_size):
         self._sync_plan()
         obs, reward, done, (r, _) = self._do_step(action, step_size)
-        self._after_step(action, r)
-        return [obs.reshape(1, 7), self.plan], reward, done
+        self._after_step(action, r, obs)
+        return [obs, self.plan], reward, done
 
 
 class deep_mobile_printing_1d1r_dynamic(_Env1D):
@@ -273,7 +281,7 @@ class deep_mobile_printing_1d1r_dynamic(_Env1D):
         self._setup(np.asarray(self.plan_dataset))
 
     def _lists(self, obs):
-        norm = obs.reshape(1, 7)
+        norm = obs
         raw = norm.copy()
         raw[0, 5] = self.conut_brick
         raw[0, 6] = self.count_step
@@ -294,7 +302,7 @@ class deep_mobile_printing_1d1r_dynamic(_Env1D):
 
     def step(self, action):
         obs, reward, done, (r, _) = self._do_step(action)
-        self._after_step(action, r)
+        self._after_step(action, r, obs)
         raw, norm = self._lists(obs)
         return [raw, norm, self.plan], reward, done
 
@@ -335,12 +343,12 @@ class _EnvGrid(_Facade):
         h = self.HALF_WINDOW_SIZE
         self.input_plan = self.plan[h:h + self.plan_height, h:h + self.plan_width]
         self.position_memory = [[r, c]]
-        return obs.reshape(1, 51), [r, c]
+        return obs, [r, c]
 
     def _grid_step(self, action, step_size=None):
         obs, reward, done, (r, c) = self._do_step(action, step_size)
         self.position_memory.append([r, c])
-        return obs.reshape(1, 51), reward, done, self.position_memory[-1]
+        return obs, reward, done, self.position_memory[-1]
 
     def iou(self):
         """3D: the class method of the reference; 2D: the caller-side boolean IoU (script/DQN/2d/DQN_2d_dynamic.py:63-71)."""
@@ -548,13 +556,13 @@ class deep_mobile_printing_2d1r_hindsight_dynamic(deep_mobile_printing_2d1r_dyna
     of np.random draws that throw-away plan costs depends on the rasteriser.  This class skips it: the dynamics are the
     pinned 2D dataset dynamics, but a seeded script sees a different np.random stream than with the reference."""
 
+    _layout = dict(obs_scalars="raw")
+
     def create_plan(self):
         raise NotImplementedError("the reference's random-triangle rasteriser needs cv2 (and its result is discarded by reset())")
 
     def _raw(self, obs):
-        o = np.array(obs, np.float64)
-        o[0, -2], o[0, -1] = self.count_brick, self.count_step
-        return o
+        return obs                                               # obs_scalars "raw": the kernel writes the counters
 
     def reset(self):
         obs, plan, pos = deep_mobile_printing_2d1r_dynamic.reset(self)

@@ -1,5 +1,6 @@
 """L-Net env variants of the reference (used by script/Representation_learning/*): static plans with a different
-observation layout per dimension.  Same HIP path as snac_amd.envs; the layout differences are host-side.
+observation layout per dimension.  Same HIP path as snac_amd.envs; the layouts are flags of the kernels
+(snac_env_desc.frame_value / obs_scalars / obs_tail, BatchedDMPEnv(layout="lnet1d" | "lnet2d")), nothing is rearranged on the host.
 
   Env/1D/DMP_Env_1D_static_Lnet.py                 position appended to the observation, shape (1, 8)
   Env/2D/DMP_Env_2D_static_Lnet.py                 frame cells hold 2 instead of -1, normalised scalars, [obs, position]
@@ -14,20 +15,17 @@ from .envs import (_Env3D, _EnvGrid, _Facade, deep_mobile_printing_1d1r_static, 
 
 
 class deep_mobile_printing_1d1r_lnet(deep_mobile_printing_1d1r_static):
-    """Env/1D/DMP_Env_1D_static_Lnet.py :: deep_mobile_printing_1d1r (:83, :112, :127, :133)"""
-
-    def reset(self):
-        obs = deep_mobile_printing_1d1r_static.reset(self)
-        return np.hstack((obs, np.array([[self.position_memory[-1]]])))
+    """Env/1D/DMP_Env_1D_static_Lnet.py :: deep_mobile_printing_1d1r (:83, :112, :127, :133): observation (1, 8)"""
+    _layout = dict(obs_tail=("position",))
 
     def step(self, action):
-        obs, reward, done = deep_mobile_printing_1d1r_static.step(self, action)
-        return np.hstack((obs, np.array([[self.position_memory[-1]]]))), reward, done
+        return deep_mobile_printing_1d1r_static.step(self, action)
 
 
 class deep_mobile_printing_2d1r_lnet(_EnvGrid):
     """Env/2D/DMP_Env_2D_static_Lnet.py :: deep_mobile_printing_2d1r (:61-64 frame value 2, :75-76 return layout)"""
-    _dim, _dynamic = 2, True            # "dynamic" selects the normalised scalars; the plan table has one row
+    _dim, _dynamic = 2, False
+    _layout = dict(frame_value=2, obs_scalars="norm")
 
     def __init__(self, plan_choose=0):
         self._init_grid()
@@ -42,22 +40,14 @@ class deep_mobile_printing_2d1r_lnet(_EnvGrid):
 
     create_plan = deep_mobile_printing_2d1r_static.create_plan
 
-    @staticmethod
-    def _frame2(a):
-        return np.where(a == -1, 2.0, a)
-
-    @property
-    def environment_memory(self):
-        return self._frame2(_Facade.environment_memory.fget(self))
-
     def reset(self):
         self.create_plan()
         obs, pos = self._grid_reset(0)
-        return [self._frame2(obs), pos]
+        return [obs, pos]
 
     def step(self, action):
         obs, reward, done, pos = self._grid_step(action)
-        return [self._frame2(obs), pos], reward, done
+        return [obs, pos], reward, done
 
 
 class deep_mobile_printing_3d1r_lnet(_Env3D):

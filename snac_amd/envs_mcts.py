@@ -124,7 +124,7 @@ class _Static1DMCTS(_MCTS, deep_mobile_printing_1d1r_static):
 
     def step(self, action):
         state, obs, reward, done, (r, _) = self._mcts_step(action)
-        self._after_step(action, r)
+        self._after_step(action, r, obs)
         return state, obs, reward, done
 
 
@@ -160,7 +160,7 @@ class deep_mobile_printing_1d1r_MCTS_obs(_MCTS, deep_mobile_printing_1d1r_dynami
 
     def step(self, action):
         state, obs, reward, done, (r, _) = self._mcts_step(action)
-        self._after_step(action, r)
+        self._after_step(action, r, obs)
         return state, obs, reward, done
 
 

@@ -1,5 +1,6 @@
 """The env copies under script/PPO of the reference (stable-baselines PPO2 wants gym spaces, flat observations and a
-4-tuple step): same HIP path as snac_amd.envs, the layout differences are host-side, the two `>` termination tests are
+4-tuple step): same HIP path as snac_amd.envs; the flat layout (raw counters, the plan appended by the dataset classes) is
+written by the kernels (snac_env_desc.obs_scalars / obs_tail, BatchedDMPEnv(layout="ppo")), the two `>` termination tests are
 rule bits of the kernel (SNAC_RULE_BRICK_GT / SNAC_RULE_TIME_GT in include/snac_hip.h).
 
   script/PPO/1d_static/DMP_Env_1D_static.py                            obs (7,)
@@ -40,7 +41,7 @@ except Exception:  # pragma: no cover - gym is optional
 
 class _PPO(object):
     """Mixin: flat observation [window, count_brick, count_step (, plan)], 4-tuple step."""
-    _plan_tail = False
+    _layout = dict(obs_scalars="raw")
 
     def _spaces(self, window, plan_cells=0, plan_high=1):
         self.action_space = Discrete(self.action_dim)
@@ -49,12 +50,7 @@ class _PPO(object):
         self.observation_space = Box(low=np.array(low), high=np.array(high), dtype=int)
 
     def _flat(self, obs):
-        o = np.array(obs, np.float64).reshape(-1)
-        o[-2], o[-1] = (self.conut_brick if self._dim == 1 else self.count_brick), self.count_step   # raw, also for dataset plans
-        if self._plan_tail:
-            tail = self.plan if self._dim == 1 else self.input_plan
-            o = np.hstack((o, np.asarray(tail, np.float64).reshape(-1)))
-        return o
+        return np.asarray(obs, np.float64).reshape(-1)           # the row as the kernel wrote it
 
 
 class deep_mobile_printing_1d1r_ppo_static(_PPO, deep_mobile_printing_1d1r_static):
@@ -77,7 +73,7 @@ class deep_mobile_printing_1d1r_ppo_static(_PPO, deep_mobile_printing_1d1r_stati
 
 class deep_mobile_printing_1d1r_ppo_dynamic(_PPO, deep_mobile_printing_1d1r_dynamic):
     """script/PPO/1d_dynamic/DMP_Env_1D_dynamic_usedata_plan.py :: deep_mobile_printing_1d1r(data_path, random_choose_paln=True)"""
-    _plan_tail = True
+    _layout = dict(obs_scalars="raw", obs_tail=("plan",))
     _brick_gt = True
 
     def __init__(self, data_path, random_choose_paln=True):
@@ -117,7 +113,7 @@ class deep_mobile_printing_2d1r_ppo_static(_PPO, deep_mobile_printing_2d1r_stati
 
 class deep_mobile_printing_2d1r_ppo_dynamic(_PPO, deep_mobile_printing_2d1r_dynamic):
     """script/PPO/2d_dynamic/DMP_Env_2d_dynamic_usedata_plan.py :: deep_mobile_printing_2d1r(data_path, random_choose_paln=True)"""
-    _plan_tail = True
+    _layout = dict(obs_scalars="raw", obs_tail=("plan",))
 
     def __init__(self, data_path, random_choose_paln=True):
         deep_mobile_printing_2d1r_dynamic.__init__(self, data_path, random_choose_paln)
@@ -150,7 +146,7 @@ class deep_mobile_printing_3d1r_ppo_static(_PPO, deep_mobile_printing_3d1r_stati
 
 class deep_mobile_printing_3d1r_ppo_dynamic(_PPO, deep_mobile_printing_3d1r_dynamic):
     """script/PPO/3d_dynamic/DMP_simulator_3d_dynamic_triangle_usedata.py :: deep_mobile_printing_3d1r(data_path, random_choose_paln=True)"""
-    _plan_tail = True
+    _layout = dict(obs_scalars="raw", obs_tail=("plan",))
 
     def __init__(self, data_path, random_choose_paln=True):
         deep_mobile_printing_3d1r_dynamic.__init__(self, data_path, random_choose_paln)

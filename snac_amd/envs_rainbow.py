@@ -106,7 +106,7 @@ class Env1DDynamic(_Rainbow, deep_mobile_printing_1d1r_dynamic):
 
     def step(self, action):
         obs, reward, done, (r, _) = self._do_step(action, self._k())
-        self._after_step(action, r)
+        self._after_step(action, r, obs)
         return self._raw(obs), reward, done
 
 

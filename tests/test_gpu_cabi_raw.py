@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 class EnvDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dynamic", C.c_int32), ("num_envs", C.c_int32), ("num_plans", C.c_int32),
                 ("obs_dtype", C.c_int32), ("static_plan", C.c_int32), ("seed", C.c_uint64), ("env_id_base", C.c_int64),
-                ("total_step", C.c_int32), ("rules", C.c_int32)]
+                ("total_step", C.c_int32), ("rules", C.c_int32), ("frame_value", C.c_int32), ("obs_scalars", C.c_int32),
+                ("obs_tail", C.c_int32), ("reserved", C.c_int32)]
 
 
 class State(C.Structure):
@@ -34,7 +35,7 @@ def test_raw_c_abi_reset_step_rollout_iou():
 
     L = C.CDLL(os.path.join(helpers.ROOT, "snac_amd", "libsnac_hip.so"))
     L.snac_last_error.restype = C.c_char_p
-    assert L.snac_version() == 3
+    assert L.snac_version() == 4
     sz = Sizes()
     assert L.snac_env_sizes(2, 1, C.byref(sz)) == 0 and (sz.obs_dim, sz.grid_elems, sz.grid_elem_bytes) == (51, 20, 4)
 
