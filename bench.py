@@ -29,6 +29,8 @@ if ROOT not in sys.path:
 
 # algorithmic bytes per env-step (DESIGN.md "Roofline"); f32 = the same with 4-byte observations
 ALG_BYTES = {(2, "f64"): 481, (2, "f32"): 277, (1, "f64"): 88, (1, "f32"): 60, (3, "f64"): 574, (3, "f32"): 370}
+# bytes the fused rollout really writes per env-step: the observation row + reward (4) + done (1); state stays on chip
+WRITTEN_BYTES = {(2, "f64"): 413, (2, "f32"): 209, (1, "f64"): 61, (1, "f32"): 33, (3, "f64"): 413, (3, "f32"): 209}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 HEADLINE = "env-steps/sec at N=65536 envs (2D dynamic dense); bit-exact vs CPU"
 
@@ -341,6 +343,7 @@ def main():
             with open(tfile) as fh:
                 traffic = json.load(fh)["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
         wpeak = measured_write_peak(torch, dev)
+        written = WRITTEN_BYTES[(args.kind, dkey)] * n * T / (kern_ms * 1e-3) / 1e9
         what = "%dD %s dense" % (args.kind, "dynamic" if dynamic else "static")
         out = {
             "metric": HEADLINE if headline else "env-steps/sec at N=%d envs (%s, %s obs); bit-exact vs CPU" % (n, what, dkey),
@@ -363,7 +366,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "frac_traffic": (traffic / HBM_PEAK_GBS) if traffic else None,
                          "peak_measured_write": wpeak,
-                         "frac_of_measured_write": ((traffic or achieved) / wpeak) if wpeak else None,
+                         "written": written,                      # output bytes of the launch / its duration, GB/s
+                         "frac_of_measured_write": ((traffic or written) / wpeak) if wpeak else None,
                          "kernel": "k_rollout", "kernel_ms": kern_ms, "alg_bytes_per_env_step": alg},
             "backend": backend if world > 1 else None,
             "rccl_ranks": ranks_seen if (world > 1 and backend == "nccl") else None,

@@ -1,4 +1,4 @@
-"""A/B timing of snac_rollout through the raw C ABI: python tools/ab_time.py <libsnac_hip.so> [kind] [N] [T] [reps]
+"""A/B timing of snac_rollout through the raw C ABI: python tools/ab_time.py <libsnac_hip.so> [kind] [N] [T] [reps] [obs_mode]
 (works with any ABI version whose snac_env_desc / snac_state layouts match; used to compare builds on one box)."""
 import ctypes as C
 import os
@@ -16,7 +16,8 @@ from snac_amd import plans  # noqa: E402
 class Desc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dynamic", C.c_int32), ("num_envs", C.c_int32), ("num_plans", C.c_int32),
                 ("obs_dtype", C.c_int32), ("static_plan", C.c_int32), ("seed", C.c_uint64), ("env_id_base", C.c_int64),
-                ("total_step", C.c_int32), ("rules", C.c_int32)]
+                ("total_step", C.c_int32), ("rules", C.c_int32), ("frame_value", C.c_int32), ("obs_scalars", C.c_int32),
+                ("obs_tail", C.c_int32), ("reserved", C.c_int32)]
 
 
 class State(C.Structure):
@@ -29,6 +30,8 @@ def main():
     N = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
     T = int(sys.argv[4]) if len(sys.argv) > 4 else 600
     reps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+    obs_mode = int(sys.argv[6]) if len(sys.argv) > 6 else 1      # 1: every observation written, 0: none (phase 1 alone)
+    want_rd = int(sys.argv[7]) if len(sys.argv) > 7 else 3       # bit 0: reward written, bit 1: done written
     L = C.CDLL(lib)
     table = plans.dataset(kind, "dense", "train")
     packed, tb = plans.pack_plans(kind, table)
@@ -52,7 +55,8 @@ def main():
     assert L.snac_reset(C.byref(desc), C.byref(st), None, None, None, stream) == 0
 
     def call(t0):
-        assert L.snac_rollout(C.byref(desc), C.byref(st), T, C.c_uint32(t0), None, None, 1, vp(obs), vp(rew), vp(done), stream) == 0
+        assert L.snac_rollout(C.byref(desc), C.byref(st), T, C.c_uint32(t0), None, None, obs_mode, vp(obs), vp(rew) if want_rd & 1 else None,
+                              vp(done) if want_rd & 2 else None, stream) == 0
 
     call(0); call(T)
     torch.cuda.synchronize()

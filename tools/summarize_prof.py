@@ -30,7 +30,7 @@ for f in find("trace/**/*kernel_trace.csv"):
     for name, d in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
         short = name[:90]
         print("%-90s n=%d avg=%.1f us min=%.1f max=%.1f total=%.3f ms %s" % (short, len(d), sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3, sum(d) / 1e6, meta[name]))
-for f in find("pmc_*/**/*counter_collection.csv"):
+for f in find("pmc_*/**/*counter_collection.csv") + find("p[0-9]*/**/*counter_collection.csv"):
     acc = defaultdict(lambda: defaultdict(list))
     with open(f) as fh:
         for row in csv.DictReader(fh):
