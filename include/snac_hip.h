@@ -223,6 +223,31 @@ int snac_replay_gather(const snac_env_desc* desc, const snac_state* st, int32_t 
                        const int32_t* env_idx, int32_t batch, float* s_out, float* s_next_out, float* plan_out,
                        void* stream);
 
+/* ---- plan generators: the hindsight classes of the reference draw a fresh random plan per reset --
+ * random triangles in 2D / 3D (create_plan, Env/2D/DMP_Env_2D_dynamic_hindsight_replay_usedata.py:37-59: three vertices from
+ * np.random.randint(0, 20, size=3) twice, cv2.polylines (+ cv2.fillPoly when dense), redrawn until more than 50 (dense) / 20
+ * (sparse) cells are set; the datasets of 400 / 50 / 50 plans were made this way) and random sine curves in 1D (create_plan,
+ * Env/1D/DMP_Env_1D_dynamic_hindsight_replay.py:29-42: k1 = uniform(3, 12), k2 = randint(1, 4), phase = uniform(-1, 1) pi,
+ * y = round(k1 sin(2 pi / 30 (k2 x + phase)) + 20)).  snac_make_plans writes rows [first, first + count) of st->plans and
+ * st->plan_tb (the caller's tables, in the layout of desc->kind) on the device, one wavefront per plan:
+ *   vertices NULL   counter RNG stream 2 keyed by (seed, plan_id_base + row): attempt a uses words 4a, 4a+1, 4a+2 (vertex v:
+ *                   x = ((word & 0xffff) * 20) >> 16, y = ((word >> 16) * 20) >> 16), redrawn (at most 64 times) until the
+ *                   area threshold is passed; 1D: words 0, 1, 2 -> k1 = 3 + 9 u, k2 = 1 + (word * 3 >> 32), phase = (2 u - 1) pi
+ *                   with u = word * 2^-32, y = rint(fma(k1, sin(..), 20)) with the sine specified in snac_hip.hip (spec_sin)
+ *   vertices        int8[count][6] = x0 y0 x1 y1 x2 y2 (2D / 3D): ONE rasterisation per row, no redraw -- the caller draws the
+ *                   vertices (the drop-in classes take them from np.random like the reference) and loops on area_out
+ *   sparse          0: outline + interior, threshold 50; 1: outline only, threshold 20; 3D plans also need fewer than 110 cells
+ *                   (script/HumanPlayerGUI/env/Env3D.py:360-364, how the 3D datasets were drawn)
+ *   area_out        int32[count] or NULL: number of cells set (1D: total_brick)
+ * Rasteriser: cv2's own rules for this call restated (LineIterator with leftToRight for the outline, the 16.16 fixed-point
+ * scanline fill of FillEdgeCollection for dense plans; snac_hip.hip tri_row).  cv2 itself is not available where this was
+ * built, but its OUTPUT is: all 1000 2D dataset plans the reference ships, drawn by its authors with this code, are
+ * reproduced bit for bit from their vertices (tests/test_plan_generators.py, tests/golden/dataset_triangles.npz).  What stays
+ * unpinned is the np.random stream a seeded script sees (the counter RNG draws the vertices here; the drop-in class passes
+ * np.random's vertices in).  2D total_brick = max(area, 30); 3D plan = mask * 6, total_brick = 6 area. */
+int snac_make_plans(const snac_env_desc* desc, const snac_state* st, int32_t first, int32_t count, int32_t sparse,
+                    uint64_t seed, int64_t plan_id_base, const int8_t* vertices, int32_t* area_out, void* stream);
+
 /* current observation of every env without stepping: observation_() + the hstack of
  * Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:64-72 */
 int snac_observe(const snac_env_desc* desc, const snac_state* st, void* obs, void* stream);

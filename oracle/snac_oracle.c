@@ -608,3 +608,122 @@ int orc_batch_transition(orc_batch* b, int m, const int32_t* src_index, const in
     free(tmp); free(ep); free(ret); free(nr);
     return bad ? -1 : 0;
 }
+
+
+/* ------------------------------------------------------------------------------------------- */
+/* plan generators (include/snac_hip.h "plan generators"): CPU restatement of the build's own specification of the
+ * reference's create_plan()s -- random triangles (Env/2D/DMP_Env_2D_dynamic_hindsight_replay_usedata.py:37-59, the 3D
+ * bound of script/HumanPlayerGUI/env/Env3D.py:360-364) and random sine curves
+ * (Env/1D/DMP_Env_1D_dynamic_hindsight_replay.py:29-42).  cv2 is absent here: the rasteriser is the specification's
+ * (8-connected Bresenham outline, centre-inside fill), not cv2's -- parity with cv2 is UNPINNED. */
+static void plot(int img[20][20], int x, int y) { if (x >= 0 && x < 20 && y >= 0 && y < 20) img[y][x] = 1; }
+
+/* one edge as cv2 draws it (cv2.polylines / the boundary pass of cv2.fillPoly with thickness 1, LINE_8, shift 0 both end
+ * in LineIterator(pt1, pt2, 8, leftToRight = true)): start at the LEFT end point, one pixel per step along the longer
+ * axis, a diagonal step whenever the running error dx - 2 dy has gone negative -- so an exact tie stays on the row */
+static void cv_line(int img[20][20], int x1, int y1, int x2, int y2) {
+    if (x2 < x1) { int t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+    int dx = x2 - x1, dy = y2 - y1, sy = dy < 0 ? -1 : 1;
+    int majx = 1, majy = 0, minx = 0, miny = sy;
+    if (dy < 0) dy = -dy;
+    if (dy > dx) { int t = dx; dx = dy; dy = t; majx = 0; majy = sy; minx = 1; miny = 0; }
+    int err = dx - 2 * dy, x = x1, y = y1;
+    for (int i = 0; i <= dx; ++i) {
+        plot(img, x, y);
+        if (err < 0) { err += 2 * dx; x += minx; y += miny; }
+        err -= 2 * dy;
+        x += majx; y += majy;
+    }
+}
+
+/* the interior as cv2.fillPoly fills it (FillEdgeCollection): every non-horizontal edge runs from its upper end (x0, y0) in
+ * 16.16 fixed point with slope ((x1 - x0) << 16) / (y1 - y0) (C division: towards zero); scanline y in [y_min, y_max) takes
+ * the two edges with y0 <= y < y1 and fills ceil(left) .. floor(right) */
+static void cv_fill(int img[20][20], const int* vx, const int* vy) {
+    long ex[3], edx[3];
+    int ey0[3], ey1[3], ne = 0, ymin = 99, ymax = -99;
+    for (int e = 0; e < 3; ++e) {
+        int ax = vx[(e + 2) % 3], ay = vy[(e + 2) % 3], bx = vx[e], by = vy[e];   /* previous vertex -> this vertex */
+        if (ay == by) continue;
+        if (ay > by) { int t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; }
+        ex[ne] = (long)ax << 16; edx[ne] = (((long)(bx - ax)) * 65536) / (by - ay); ey0[ne] = ay; ey1[ne] = by; ++ne;
+        if (ay < ymin) ymin = ay;
+        if (by > ymax) ymax = by;
+    }
+    for (int y = ymin; y < ymax && ne >= 2; ++y) {
+        long xs[3];
+        int k = 0;
+        for (int e = 0; e < ne; ++e)
+            if (ey0[e] <= y && y < ey1[e]) xs[k++] = ex[e] + (long)(y - ey0[e]) * edx[e];
+        if (k < 2) continue;
+        long lo = xs[0] < xs[1] ? xs[0] : xs[1], hi = xs[0] < xs[1] ? xs[1] : xs[0];
+        for (long x = (lo + 65535) >> 16; x <= (hi >> 16); ++x) plot(img, (int)x, y);
+    }
+}
+
+/* one rasterisation: vertices (x, y) = (column, row) as cv2 takes them; returns the number of cells set */
+int orc_raster_triangle(const int* vx, const int* vy, int sparse, int32_t* img400) {
+    int img[20][20];
+    int area = 0;
+    memset(img, 0, sizeof(img));
+    for (int e = 0; e < 3; ++e) cv_line(img, vx[(e + 2) % 3], vy[(e + 2) % 3], vx[e], vy[e]);
+    if (!sparse) cv_fill(img, vx, vy);
+    for (int y = 0; y < 20; ++y)
+        for (int x = 0; x < 20; ++x) { img400[y * 20 + x] = img[y][x]; area += img[y][x]; }
+    return area;
+}
+
+/* the specified sine (snac_hip.hip spec_sin): quadrant reduction with a two-part pi/2, fdlibm kernel polynomials, fused
+ * multiply-adds throughout -- compile with -ffp-contract=off so that nothing else is fused */
+static double spec_sin(double x) {
+    static const double S[6] = { -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+                                 2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10 };
+    static const double Cc[6] = { 4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+                                  -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11 };
+    double n = rint(x * 0.63661977236758134308);
+    double r = fma(-n, 6.07710050650619224932e-11, fma(-n, 1.57079632673412561417e+00, x));
+    double z = r * r, ps = S[5], pc = Cc[5];
+    for (int i = 4; i >= 0; --i) { ps = fma(z, ps, S[i]); pc = fma(z, pc, Cc[i]); }
+    double sn = fma(z * r, ps, r), cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+    int q = (int)n & 3;
+    double v = (q & 1) ? cs : sn;
+    return (q & 2) ? -v : v;
+}
+
+/* plan row `plan_id` of the generator: out = 30 heights (1D) or the bordered 26x26 plan (2D: 0/1, 3D: 0/6) as the
+ * reference holds it; *tb = total_brick as reset() would compute it (2D: floored at 30); returns the cells set / sum */
+int orc_make_plan(int dim, int sparse, uint64_t seed, int64_t plan_id, int32_t* out, int32_t* tb) {
+    if (dim == 1) {
+        double u1 = (double)orc_rng_word(seed, 2u, (uint64_t)plan_id, 0u) * 2.3283064365386963e-10;
+        double u2 = (double)orc_rng_word(seed, 2u, (uint64_t)plan_id, 2u) * 2.3283064365386963e-10;
+        int k2 = 1 + (int)(((uint64_t)orc_rng_word(seed, 2u, (uint64_t)plan_id, 1u) * 3u) >> 32);
+        double k1 = fma(9.0, u1, 3.0), phase = fma(2.0, u2, -1.0) * 3.14159265358979311600;
+        int sum = 0;
+        for (int x = 0; x < 30; ++x) {
+            double arg = 0.20943951023931953 * fma((double)k2, (double)x, phase);
+            out[x] = (int32_t)rint(fma(k1, spec_sin(arg), 20.0));
+            sum += out[x];
+        }
+        *tb = sum;
+        return sum;
+    }
+    {
+        int32_t img[400];
+        int area = 0, thr = sparse ? 20 : 50, amax = dim == 3 ? 110 : 401;
+        for (int attempt = 0; attempt < 64; ++attempt) {
+            int vx[3], vy[3];
+            for (int v = 0; v < 3; ++v) {
+                uint32_t w = orc_rng_word(seed, 2u, (uint64_t)plan_id, (uint32_t)(attempt * 4 + v));
+                vx[v] = (int)(((w & 0xffffu) * 20u) >> 16);
+                vy[v] = (int)(((w >> 16) * 20u) >> 16);
+            }
+            area = orc_raster_triangle(vx, vy, sparse, img);
+            if (area > thr && area < amax) break;
+        }
+        for (int i = 0; i < 676; ++i) out[i] = 0;
+        for (int y = 0; y < 20; ++y)
+            for (int x = 0; x < 20; ++x) out[(y + 3) * 26 + x + 3] = img[y * 20 + x] * (dim == 3 ? 6 : 1);
+        *tb = dim == 3 ? area * 6 : (area < 30 ? 30 : area);
+        return area;
+    }
+}

@@ -118,6 +118,10 @@ void orc_batch_iou(const orc_batch* b, double* out);
 int  orc_batch_transition(orc_batch* b, int m, const int32_t* src_index, const int32_t* dst_index, uint32_t t,
                           const int8_t* actions, const int8_t* step_size, double* obs, float* reward, uint8_t* done);
 
+/* ---- plan generators (the build's specification of the reference's random-triangle / random-sine create_plan()s) ---- */
+int  orc_raster_triangle(const int* vx, const int* vy, int sparse, int32_t* img400);
+int  orc_make_plan(int dim, int sparse, uint64_t seed, int64_t plan_id, int32_t* out, int32_t* tb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,8 @@ def lib():
         L.orc_set_state.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_batch_transition.argtypes = [C.POINTER(_Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_raster_triangle.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_make_plan.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -96,6 +98,25 @@ def static_plan(dim, plan_choose):
     if n < 0:
         raise ValueError("no such static plan")
     return out[:n].copy()
+
+
+def make_plans(dim, sparse, seed, first_id, count):
+    """Plans first_id .. first_id + count - 1 of the generator specification -> (table [count, 30 | 676] int32, total_brick [count])."""
+    cells = 30 if dim == 1 else 676
+    table = np.zeros((count, cells), np.int32)
+    tb = np.zeros(count, np.int32)
+    for i in range(count):
+        lib().orc_make_plan(dim, int(sparse), seed, first_id + i, _ptr(table[i]), C.c_void_p(tb[i:].ctypes.data))
+    return table, tb
+
+
+def raster_triangle(vx, vy, sparse):
+    """One rasterisation of the specification's triangle rasteriser -> (mask [20, 20] int32, area)."""
+    x = np.ascontiguousarray(vx, np.int32)
+    y = np.ascontiguousarray(vy, np.int32)
+    img = np.zeros(400, np.int32)
+    area = lib().orc_raster_triangle(_ptr(x), _ptr(y), int(sparse), _ptr(img))
+    return img.reshape(20, 20), int(area)
 
 
 class MT19937:

@@ -285,6 +285,47 @@ class BatchedDMPEnv:
         if update_tb:
             self._plan_tb[index] = int(tb[0])
 
+    # ---- plan generators on the device ---------------------------------------------------------------
+    def generate_plans(self, first=0, count=None, sparse=False, seed=None, id_base=0, vertices=None):
+        """Rewrite rows [first, first + count) of the device plan table with freshly generated plans (snac_make_plans): the
+        random triangles of the reference's 2D / 3D create_plan() (Env/2D/DMP_Env_2D_dynamic_hindsight_replay_usedata.py:37-59)
+        or, 1D, its random sine curves (Env/1D/DMP_Env_1D_dynamic_hindsight_replay.py:29-42) -- one wavefront per plan, so a
+        65 536-env batch gets 65 536 plans of its own instead of the 400 stored ones.  Plan row r is keyed by
+        (seed, id_base + r) on counter-RNG stream 2; vertices: optional int8 [count, 6] = x0 y0 x1 y1 x2 y2 rasterised as
+        given (no redraw).  Envs keep stepping on their current row: reset them to pick the new plans up.
+        Returns the number of cells set per plan (int32 [count]; 1D: total_brick)."""
+        count = self.num_plans - first if count is None else int(count)
+        v = None
+        if vertices is not None:
+            v = torch.as_tensor(np.asarray(vertices), device=self.device).to(torch.int8).contiguous()
+            if tuple(v.shape) != (count, 6):
+                raise ValueError("vertices must have shape (count, 6)")
+        area = torch.empty((count,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_make_plans(C.byref(self._desc), C.byref(self._state), int(first), count, int(bool(sparse)),
+                                                 int(self.seed if seed is None else seed) & 0xFFFFFFFFFFFFFFFF, int(id_base),
+                                                 _ptr(v), _ptr(area), self._stream()))
+        self._plans_stale = True                               # the host copy (plans_full) no longer mirrors the device table
+        return area
+
+    def _sync_plans_full(self):
+        """Decode the device plan table back into the reference's host format after generate_plans()."""
+        if not getattr(self, "_plans_stale", False):
+            return
+        t = self._plans.cpu().numpy()
+        P = self.num_plans
+        if self.kind == 1:
+            self.plans_full = t[:, :30].astype(np.float64)
+        else:
+            full = np.zeros((P, 26, 26), np.float64)
+            if self.kind == 2:
+                bits = (t.view(np.uint32)[:, :, None] >> np.arange(20, dtype=np.uint32)[None, None, :]) & 1
+                full[:, 3:23, 3:23] = bits
+            else:
+                full[:, 3:23, 3:23] = t.reshape(P, 20, 20)
+            self.plans_full = full
+        self._plans_stale = False
+
     # ---- snapshots (MCTS-style branching, checkpoints) ---------------------------------------------
     def state_dict(self):
         """Everything that defines the envs' future (tensors are cloned): the MCTS variants of the reference snapshot
@@ -304,6 +345,7 @@ class BatchedDMPEnv:
         children and step each child with its own action -- the batched form of the MCTS variants' functional
         transition(state, action).  Episodic sums start at zero; counter-RNG streams are keyed by the NEW local index."""
         index = torch.as_tensor(index, device=self.device, dtype=torch.long)
+        self._sync_plans_full()
         child = BatchedDMPEnv(self.kind, self.dynamic, int(index.numel()), plans=self.plans_full, device=self.device, seed=self.seed,
                               obs_dtype=self.obs_dtype, env_id_base=self.env_id_base, total_step=self.total_step,
                               brick_gt=self.brick_gt, time_gt=self.time_gt, frame_value=self.frame_value,
@@ -511,6 +553,7 @@ class BatchedDMPEnv:
 
     def plan(self):
         """float64 [N, ...]: the full plan of every env (reference attribute `plan`)."""
+        self._sync_plans_full()
         table = torch.from_numpy(self.plans_full).to(self.device)
         return table[self.plan_idx]
 

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
 // (0 or -100) and neither does done, so the deferred part is only reward_check and min(height, plan).
 // LDS operations of one wave execute in order: A's reads see step t-1's map and scalar slots although B overwrites them
 // later in the same iteration.  Semantics are K3D::step's (k_rollout, k_transition and k_aux keep using it; the tests
-// compare both paths with the oracle).  Layout variants, OBS_LAST / OBS_NONE, more than TB_MAX plans: generic kernel.
+// compare both paths with the CPU restatement).  Layout variants, OBS_LAST / OBS_NONE, more than TB_MAX plans: generic kernel.
 constexpr int TB_MAX = 2048;   // plan_tb rows staged in LDS per block
 
 template <bool DYN, typename OT, int WPB, bool EXPL, bool FULL>
@@ -1199,6 +1199,150 @@ __global__ __launch_bounds__(256) void k_equal(const OT* a, const int32_t* ia, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// plan generators on the device (include/snac_hip.h "Plan generators"): the reference draws a fresh random plan per reset in
+// its hindsight classes -- random triangles (Env/2D/DMP_Env_2D_dynamic_hindsight_replay_usedata.py:37-59, cv2.polylines /
+// cv2.fillPoly, redraw until the area exceeds 50 dense / 20 sparse) and random sine curves
+// (Env/1D/DMP_Env_1D_dynamic_hindsight_replay.py:29-42) -- and ships 400 + 50 + 50 of them per dataset.  Here a launch
+// writes `count` rows of the plan table, one wave per plan, from counter-RNG stream 2 or from explicit vertices.
+struct PArgs {
+    int32_t first, count, sparse, use_vertices;
+    uint32_t key;
+    int64_t id_base;
+    const int8_t* vertices;   // [count][6] x0 y0 x1 y1 x2 y2 (clamped into 0..19) or NULL
+    void* plans;
+    int16_t* plan_tb;
+    int32_t* area_out;        // [count] or NULL: cells set by the (last) attempt
+};
+
+// the triangle rasteriser, restating what cv2 does for the reference's call (thickness 1, LINE_8, shift 0); lane = plan row
+// (y), result = the 20-bit mask of its columns (x).
+//   outline  cv2.polylines -> LineIterator(leftToRight): start at the LEFT end point, one pixel per step along the longer
+//            axis, a diagonal step whenever the running error dx - 2 dy has gone negative (an exact tie stays on the row).
+//            Every lane walks the same pixels and keeps those of its row.
+//   fill     cv2.fillPoly -> FillEdgeCollection: each non-horizontal edge runs from its upper end in 16.16 fixed point with
+//            slope ((x1 - x0) << 16) / (y1 - y0) truncated towards zero; scanline y in [y_min, y_max) fills
+//            ceil(left) .. floor(right) between its two active edges (plus the outline above).
+// With these two rules every one of the 1000 2D plans the reference ships (drawn by its authors with cv2) is reproduced
+// bit for bit from its three vertices (tests/test_plan_generators.py).
+__device__ __forceinline__ uint32_t tri_row(int row, const int* vx, const int* vy, bool fill) {
+    uint32_t m = 0;
+    for (int e = 0; e < 3; ++e) {
+        int x1 = vx[(e + 2) % 3], y1 = vy[(e + 2) % 3], x2 = vx[e], y2 = vy[e];
+        if (x2 < x1) { int t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+        int dx = x2 - x1, dy = y2 - y1;
+        const int sy = dy < 0 ? -1 : 1;
+        dy = abs(dy);
+        const bool steep = dy > dx;
+        if (steep) { const int t = dx; dx = dy; dy = t; }
+        int err = dx - 2 * dy, x = x1, y = y1;
+        for (int i = 0; i <= dx; ++i) {                              // at most 20 pixels per edge
+            if (y == row) m |= 1u << x;
+            if (err < 0) { err += 2 * dx; if (steep) x += 1; else y += sy; }
+            err -= 2 * dy;
+            if (steep) y += sy; else x += 1;
+        }
+    }
+    if (fill) {
+        long long xs[2];
+        int k = 0, ymin = 99, ymax = -99;
+        for (int e = 0; e < 3; ++e) {
+            int ax = vx[(e + 2) % 3], ay = vy[(e + 2) % 3], bx = vx[e], by = vy[e];
+            if (ay == by) continue;
+            if (ay > by) { int t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; }
+            ymin = min(ymin, ay); ymax = max(ymax, by);
+            if (ay <= row && row < by && k < 2) xs[k++] = ((long long)ax << 16) + (long long)(row - ay) * (((long long)(bx - ax) * 65536) / (by - ay));
+        }
+        if (k == 2 && row >= ymin && row < ymax) {
+            const long long lo = xs[0] < xs[1] ? xs[0] : xs[1], hi = xs[0] < xs[1] ? xs[1] : xs[0];
+            const int c0 = max((int)((lo + 65535) >> 16), 0), c1 = min((int)(hi >> 16), 19);
+            if (c1 >= c0) m |= ((2u << c1) - 1u) & ~((1u << c0) - 1u);
+        }
+    }
+    return m;
+}
+
+// sin(x) for the sine-curve plans, specified operation by operation so that the CPU restatement gives the same bits (device
+// and host libm sines differ in the last place, and a plan height is a ROUNDED multiple of it): n = rint(x * 2/pi); two-step
+// Cody-Waite reduction r = x - n * pi/2; the fdlibm kernel polynomials on |r| <= pi/4, every multiply-add a fused one.
+__device__ __forceinline__ double spec_sin(double x) {
+    const double n = __builtin_rint(x * 0.63661977236758134308);
+    double r = __builtin_fma(-n, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-n, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = __builtin_fma(z * r, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double cs = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+    const int q = (int)n & 3;
+    const double v = (q & 1) ? cs : sn;
+    return (q & 2) ? -v : v;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_make_plans(const PArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (i >= g.count) return;
+    const size_t rowi = (size_t)(g.first + i);
+    const EnvKeys pk = env_keys(g.key, (uint64_t)(g.id_base + (int64_t)rowi));
+    if (KIND == 1) {
+        // y[x] = rint(k1 * sin(2 pi / 30 * (k2 x + phase)) + 20), k1 in [3, 12), k2 in {1, 2, 3}, phase in [-pi, pi)
+        const double u1 = (double)rng_word(pk, 0) * 2.3283064365386963e-10, u2 = (double)rng_word(pk, 2) * 2.3283064365386963e-10;
+        const double k1 = __builtin_fma(9.0, u1, 3.0), phase = __builtin_fma(2.0, u2, -1.0) * 3.14159265358979311600;
+        const int k2 = 1 + (int)__umulhi(rng_word(pk, 1), 3u);
+        const double arg = 0.20943951023931953 * __builtin_fma((double)k2, (double)min(lane, 29), phase);
+        const int y = (int)__builtin_rint(__builtin_fma(k1, spec_sin(arg), 20.0));
+        int sum = lane < 30 ? y : 0;
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if (lane < 32) ((int16_t*)g.plans)[rowi * 32 + lane] = lane < 30 ? (int16_t)y : (int16_t)0;
+        if (lane == 0) { g.plan_tb[rowi] = (int16_t)sum; if (g.area_out) g.area_out[i] = sum; }
+        return;
+    }
+    // 3D plans also have an upper bound: script/HumanPlayerGUI/env/Env3D.py:360-364 redraws while area <= min or area >= 110
+    // (the 3D datasets hold 6 x [51, 109] bricks)
+    const int thr = g.sparse ? 20 : 50, amax = KIND == 3 ? 110 : 401;
+    uint32_t m = 0;
+    int area = 0;
+    for (int attempt = 0; attempt < 64; ++attempt) {                // the reference redraws without bound; P(64 rejections) ~ 0
+        int vx[3], vy[3];
+        for (int v = 0; v < 3; ++v) {
+            if (g.use_vertices) {
+                vx[v] = min(max((int)g.vertices[(size_t)i * 6 + 2 * v], 0), 19);
+                vy[v] = min(max((int)g.vertices[(size_t)i * 6 + 2 * v + 1], 0), 19);
+            } else {
+                const uint32_t w = rng_word(pk, (uint32_t)(attempt * 4 + v));
+                vx[v] = (int)(((w & 0xffffu) * 20u) >> 16);
+                vy[v] = (int)(((w >> 16) * 20u) >> 16);
+            }
+        }
+        m = lane < 20 ? tri_row(lane, vx, vy, !g.sparse) : 0u;
+        area = __popc(m);
+        for (int off = 32; off > 0; off >>= 1) area += __shfl_xor(area, off);
+        if ((area > thr && area < amax) || g.use_vertices) break;
+    }
+    if (KIND == 2) {
+        if (lane < 20) ((uint32_t*)g.plans)[rowi * 20 + lane] = m;
+        if (lane == 0) g.plan_tb[rowi] = (int16_t)max(area, 30);     // the 2D total_brick floor (:45-46)
+    } else {
+        int16_t* dst = (int16_t*)g.plans + rowi * 400;
+        for (int r = 0; r < 20; ++r) {
+            const uint32_t mr = (uint32_t)__shfl((int)m, r);
+            if (lane < 20) dst[r * 20 + lane] = (int16_t)(((mr >> lane) & 1u) * 6);   // plan * z
+        }
+        if (lane == 0) g.plan_tb[rowi] = (int16_t)(area * 6);
+    }
+    if (lane == 0 && g.area_out) g.area_out[i] = area;
+}
+
+// ------------------------------------------------------------------------------------------------
 // replay sampling (the step after the env path: script/DQN/2d/DQN_2d_dynamic.py:122-124,145-166 keeps
 // (s, a, r, s', plan) tuples in a python deque and re-assembles float32 minibatches on the host).  The rollout output
 // ring obs[cap][N][D] already holds every s' -- and s is the previous tick's row, or the constant reset observation when
@@ -1574,6 +1718,26 @@ int snac_obs_equal(const snac_env_desc* d, const void* obs_a, const int32_t* idx
         hipLaunchKernelGGL((k_equal<double>), grid, block, 0, s, (const double*)obs_a, idx_a, rows_a, (const double*)obs_b, idx_b, rows_b, m, D, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "equal launch");
+    return SNAC_OK;
+}
+
+int snac_make_plans(const snac_env_desc* d, const snac_state* st, int32_t first, int32_t count, int32_t sparse, uint64_t seed,
+                    int64_t plan_id_base, const int8_t* vertices, int32_t* area_out, void* stream) {
+    if (int rc = check_common(d, st)) return rc;
+    if (first < 0 || count < 0 || (int64_t)first + count > d->num_plans) return fail(SNAC_ERR_ARG, "plan rows out of range");
+    if (vertices && d->kind == SNAC_ENV_1D) return fail(SNAC_ERR_ARG, "vertices are a 2D / 3D input");
+    if (count == 0) return SNAC_OK;
+    PArgs g;
+    g.first = first; g.count = count; g.sparse = sparse ? 1 : 0; g.use_vertices = vertices ? 1 : 0;
+    g.key = stream_key(seed, 2); g.id_base = plan_id_base; g.vertices = vertices;
+    g.plans = const_cast<void*>(st->plans); g.plan_tb = const_cast<int16_t*>(st->plan_tb); g.area_out = area_out;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((count + 3) / 4)), block(256);
+    if (d->kind == SNAC_ENV_1D) hipLaunchKernelGGL((k_make_plans<1>), grid, block, 0, s, g);
+    else if (d->kind == SNAC_ENV_2D) hipLaunchKernelGGL((k_make_plans<2>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((k_make_plans<3>), grid, block, 0, s, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "make_plans launch");
     return SNAC_OK;
 }
 

@@ -551,22 +551,43 @@ class deep_mobile_printing_2d1r_hindsight_dynamic(deep_mobile_printing_2d1r_dyna
     """Env/2D/DMP_Env_2D_dynamic_hindsight_replay_usedata.py :: deep_mobile_printing_2d1r_hindsight(data_path,
     random_choose_paln=True) -- the dataset class with raw counters in every observation and step(action, step_size).
 
-    PARITY UNPINNED for this class: the reference's reset() first rasterises a random triangle with cv2 (create_plan, :37-59)
-    and throws it away (:61-64); cv2 is not available where the goldens are recorded, so no golden exists, and the number
-    of np.random draws that throw-away plan costs depends on the rasteriser.  This class skips it: the dynamics are the
-    pinned 2D dataset dynamics, but a seeded script sees a different np.random stream than with the reference."""
+    reset() first draws a throw-away random triangle (create_plan, :37-59, :61-64) and then takes the dataset plan.  The
+    triangle's vertices come from np.random exactly as in the reference (two randint(0, 20, size=3) per attempt, redrawn until
+    the area exceeds 50 dense / 20 sparse); the rasterisation runs on the device (snac_make_plans with explicit vertices),
+    whose rules reproduce every cv2-drawn plan of the reference's datasets bit for bit -- so a seeded script sees the
+    reference's np.random stream.  (cv2 itself is absent where the goldens are recorded, hence no recorded trajectory of
+    this class: the dynamics are the pinned 2D dataset dynamics with raw counters and caller-supplied step sizes.)"""
 
     _layout = dict(obs_scalars="raw")
 
+    def __init__(self, data_path, random_choose_paln=True):
+        deep_mobile_printing_2d1r_dynamic.__init__(self, data_path, random_choose_paln)
+        self.plan_choose = 1 if "sparse" in data_path else 0     # :31-32
+        self._gen = None
+
     def create_plan(self):
-        raise NotImplementedError("the reference's random-triangle rasteriser needs cv2 (and its result is discarded by reset())")
+        if self.plan_choose not in (0, 1):
+            raise ValueError(' 0: Dense triangle, 1: Sparse triangle')
+        from .batched import BatchedDMPEnv
+
+        if self._gen is None:                                    # a one-row scratch table for the rasteriser
+            self._gen = BatchedDMPEnv(2, False, 1, plans=np.zeros((1, 26, 26)))
+        area = [50, 20]
+        total_area = 0
+        while total_area <= area[self.plan_choose]:
+            x = np.random.randint(0, self.plan_width, size=3)
+            y = np.random.randint(0, self.plan_height, size=3)
+            v = np.array([[x[0], y[0], x[1], y[1], x[2], y[2]]], np.int8)
+            total_area = int(self._gen.generate_plans(0, 1, sparse=bool(self.plan_choose), vertices=v).item())
+        self._gen._sync_plans_full()
+        return self._gen.plans_full[0].copy(), float(total_area)
 
     def _raw(self, obs):
         return obs                                               # obs_scalars "raw": the kernel writes the counters
 
     def reset(self):
+        self.plan, self.total_brick = self.create_plan()         # the reference's throw-away draw (:61)
         obs, plan, pos = deep_mobile_printing_2d1r_dynamic.reset(self)
-        self.plan_choose = 0
         return [self._raw(obs), plan, pos]
 
     def step(self, action, step_size):

@@ -123,7 +123,9 @@ def test_misc_facades_on_hip(name):
 @pytest.mark.gpu
 def test_2d_dynamic_hindsight_class_against_the_oracle():
     """Env/2D/DMP_Env_2D_dynamic_hindsight_replay_usedata.py cannot run where goldens are recorded (cv2): its drop-in is
-    checked against the oracle only -- the pinned 2D dataset dynamics with raw counters and caller-supplied step sizes."""
+    checked against the oracle -- the pinned 2D dataset dynamics with raw counters and caller-supplied step sizes -- and its
+    create_plan() against the oracle's restatement of cv2's rasteriser (itself pinned by the reference's datasets,
+    tests/test_plan_generators.py)."""
     path = os.path.join(helpers.ROOT, "snac_amd", "Env", "2D")
     if path not in sys.path:
         sys.path.append(path)
@@ -146,5 +148,15 @@ def test_2d_dynamic_hindsight_class_against_the_oracle():
             obs = env.reset()
             o = ref.reset(table[env.index_random], env.index_random)
             assert obs[0].tobytes() == o.reshape(1, -1).tobytes()
-    with pytest.raises(NotImplementedError):
-        env.create_plan()
+    # create_plan(): np.random is consumed as the reference consumes it (two randint(0, 20, size=3) per attempt, redrawn
+    # while the area is <= 20 for this sparse dataset); the rasterisation is the oracle's restatement of cv2
+    np.random.seed(11)
+    plan, area = env.create_plan()
+    st = np.random.RandomState(11)
+    while True:
+        x, y = st.randint(0, 20, size=3), st.randint(0, 20, size=3)
+        img, a = orc.raster_triangle(x, y, 1)
+        if a > 20:
+            break
+    assert area == a and plan.shape == (26, 26) and np.array_equal(plan[3:23, 3:23], img) and plan.sum() == a
+    assert np.random.randint(0, 1 << 30) == st.randint(0, 1 << 30)          # the global stream stands where the reference's would
