@@ -73,3 +73,64 @@ def test_step_into_preallocated_outputs():
         b.step(out=(bufs[0][:10], bufs[1], bufs[2]))
     with pytest.raises(ValueError):
         b.step(out=(bufs[0].float(), bufs[1], bufs[2]))
+
+
+@pytest.mark.parametrize("kind", [1, 2, 3])
+def test_counters_saturate_when_stepped_past_done_without_reset(kind):
+    """The reference never resets by itself and "keeps mutating" when stepped past done (count_step is unbounded,
+    Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:86).  The packed header holds int16 counters: count_step, count_brick and the
+    heights saturate at 32767 instead of wrapping; rewards and done flags stay the reference's.  33 400 un-reset steps of a
+    static batch (every env repeats one action) against the unbounded CPU restatement, clamped at 32767."""
+    import numpy as np
+    import torch
+
+    import helpers
+    from snac_amd import BatchedDMPEnv
+
+    N, T, CAP = 16, 33400, 32767
+    env = BatchedDMPEnv(kind, False, N, seed=1)
+    table = helpers.plan_table(kind, False, "p0")
+    orc = helpers.oracle().OracleBatch(kind, False, N, table, seed=1)
+    assert env.reset().cpu().numpy().tobytes() == orc.reset().tobytes()
+    A = env.num_actions
+    acts = torch.tensor([(i * 3 + 2) % A for i in range(N)], dtype=torch.int8, device="cuda")
+    ks = torch.tensor([1 + i % 3 for i in range(N)], dtype=torch.int8, device="cuda")
+    an, kn = acts.cpu().numpy(), ks.cpu().numpy()
+    bufs = (torch.empty((N, env.obs_dim), dtype=torch.float64, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda"),
+            torch.empty(N, dtype=torch.uint8, device="cuda"))
+    check = set(range(0, 2000, 7)) | set(range(32700, T))                   # around the first episodes and around the clamp
+    saturated = False
+    for t in range(T):
+        env.step(acts, ks, out=bufs)
+        oc, rc, dc = orc.step(t, an, kn)
+        if t in check:
+            og = bufs[0].cpu().numpy()
+            want = np.minimum(oc, float(CAP))
+            if kind == 1:                                                   # reward of an over-built cell is -1 either way
+                assert np.array_equal(bufs[1].cpu().numpy(), rc)
+            assert np.array_equal(og, want), t
+            assert np.array_equal(bufs[2].cpu().numpy(), dc)
+            saturated = saturated or bool((oc > CAP).any())
+    assert saturated and int(env.count_step.max()) == CAP and int(env.count_step.min()) == CAP
+    assert int(env.count_brick.max()) <= CAP and int(env.episode_return.abs().max()) <= 32768
+
+
+def test_transition_with_one_index_array_is_bounded_by_the_pool():
+    """C ABI: an absent index array means "row i", so with either one absent m may not exceed the pool."""
+    import ctypes as C
+
+    import torch
+
+    from snac_amd import BatchedDMPEnv, _lib
+
+    env = BatchedDMPEnv(2, True, 64, seed=1)
+    env.reset()
+    m = 200
+    idx = torch.zeros(m, dtype=torch.int32, device="cuda")
+    a = torch.zeros(m, dtype=torch.int8, device="cuda")
+    L = _lib.lib()
+    for src, dst in ((idx, None), (None, idx), (None, None)):
+        rc = L.snac_transition(C.byref(env._desc), C.byref(env._state), m, None if src is None else C.c_void_p(src.data_ptr()),
+                               None if dst is None else C.c_void_p(dst.data_ptr()), 0, C.c_void_p(a.data_ptr()), None, None, None, None, None)
+        assert rc == -1 and b"pool" in L.snac_last_error()
+    torch.cuda.synchronize()

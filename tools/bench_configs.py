@@ -58,6 +58,27 @@ def main():
     for name, kind, dyn, n, T in rows:
         ms = rollout_time(kind, dyn, n, T)
         print("rollout f64 %s  %8.3f ms  %.3e env-steps/s  alg %.0f GB/s" % (name, ms, n * T / ms * 1e3, ALG[kind] * n * T / ms / 1e6))
+    # 3D with the reference's own action mix [0.2 x 4 moves, 0.05 x 4 builds] (Env/3D/DMP_simulator_3d_static_circle.py:361-362):
+    # explicit int8 actions drawn with that distribution on the device, step sizes from the counter RNG
+    for dyn, T in ((True, 1000), (False, 1300)):
+        n = 16384
+        env = BatchedDMPEnv(3, dyn, n, seed=1)
+        env.reset()
+        g = torch.Generator(device=env.device).manual_seed(1)
+        probs = torch.tensor([0.2] * 4 + [0.05] * 4, device=env.device)
+        acts = torch.multinomial(probs, T * n, replacement=True, generator=g).to(torch.int8).reshape(T, n)
+        buf = torch.empty((T, n, env.obs_dim), dtype=torch.float64, device=env.device)
+        env.rollout(T, actions=acts, out=buf)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(5):
+            a.record(); env.rollout(T, actions=acts, out=buf); b.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b))
+        st = env.episodic_stats()
+        print("rollout f64 3D %s reference action mix [0.2x4, 0.05x4] N=16384 T=%d  %8.3f ms  %.3e env-steps/s  (%d episodes, mean IoU %.4f)" % (
+            "dynamic" if dyn else "static ", T, best, n * T / best * 1e3, st["episodes"], st["iou_fx_sum"] / 2.0 ** 40 / max(st["episodes"], 1)))
     ms = rollout_time(2, True, 65536, 600, obs_dtype=torch.float32)
     print("rollout f32 2D dynamic     N=65536  T=600   %8.3f ms  %.3e env-steps/s  alg(277 B) %.0f GB/s" % (ms, 65536 * 600 / ms * 1e3, 277 * 65536 * 600 / ms / 1e6))
     ms = rollout_time(2, True, 65536, 600, obs="last")

@@ -46,20 +46,26 @@ for f in find("pmc_*/**/*counter_collection.csv") + find("p[0-9]*/**/*counter_co
 # separate --pmc passes, are in KiB, and FETCH_SIZE under-reports wide reads by 2x on gfx950.
 import json
 
-vals = {}
+vals = defaultdict(dict)                                     # kernel family -> counter -> per-launch average
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in find("pmc_%s/**/*counter_collection.csv" % c):
-        v = []
+        per = defaultdict(list)
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if "k_rollout" in row["Kernel_Name"] and row["Counter_Name"] == c:
-                    v.append(float(row["Counter_Value"]))
-        if v:
-            vals[c] = sum(v) / len(v)
-if len(vals) == 2:
-    t = dict(fetch_kib=vals["FETCH_SIZE"], write_kib=vals["WRITE_SIZE"],
-             hbm_bytes_per_launch=(2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
-             note="2*FETCH_SIZE + WRITE_SIZE (KiB) per k_rollout launch; separate --pmc passes; gfx950 read correction x2")
-    with open(os.path.join(out, "traffic.json"), "w") as fh:
-        json.dump(t, fh, indent=1)
-    print("== traffic:", t)
+                if row["Counter_Name"] != c:
+                    continue
+                for fam in ("k_rollout", "k_transition"):
+                    if fam in row["Kernel_Name"]:
+                        dim = "K3D" if "K3D" in row["Kernel_Name"] or "rollout3d" in row["Kernel_Name"] else ("K2D" if "K2D" in row["Kernel_Name"] else "K1D")
+                        per[fam + ":" + dim].append(float(row["Counter_Value"]))
+        for fam, v in per.items():
+            vals[fam][c] = sum(v) / len(v)
+for fam, v in sorted(vals.items()):
+    if len(v) == 2:
+        t = dict(kernel=fam, fetch_kib=v["FETCH_SIZE"], write_kib=v["WRITE_SIZE"],
+                 hbm_bytes_per_launch=(2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0,
+                 note="2*FETCH_SIZE + WRITE_SIZE (KiB) per launch; separate --pmc passes; gfx950 read correction x2")
+        if fam.startswith("k_rollout"):
+            with open(os.path.join(out, "traffic.json"), "w") as fh:
+                json.dump(t, fh, indent=1)
+        print("== traffic:", t)
