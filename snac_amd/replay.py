@@ -39,6 +39,10 @@ class ReplayRing:
         self.head = 0          # next slot to write
         self.ticks = 0         # ticks collected so far
         self.plan_cells = 30 if env.kind == 1 else 400
+        # the predecessor of slot 0 is slot cap - 1: seed it with the envs' CURRENT observation, so that the very first
+        # transitions have their `s` also when the ring is attached to envs in mid-episode (first[0, i] == 0)
+        self.obs[self.cap - 1].copy_(env.observe())
+        self._env_t = env.t    # the env may only advance through the ring: s' / s are paired by slot
 
     def __len__(self):
         """Number of addressable transitions."""
@@ -54,6 +58,9 @@ class ReplayRing:
         T = int(T)
         if T > self.cap:
             raise ValueError("T exceeds the ring capacity")
+        if self.env.t != self._env_t:
+            raise _lib.SnacError("the envs were stepped outside the ring since the last collect(): the predecessor rows no longer "
+                                 "match (attach a new ReplayRing)")
         done_ticks = 0
         while done_ticks < T:
             n = min(T - done_ticks, self.cap - self.head)
@@ -66,6 +73,7 @@ class ReplayRing:
             self.head = (self.head + n) % self.cap
             self.ticks += n
             done_ticks += n
+        self._env_t = self.env.t
 
     def append(self, actions, step_size=None):
         """One vector step with the caller's actions ([N], e.g. an epsilon-greedy policy's), appended to the ring."""

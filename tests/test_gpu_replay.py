@@ -154,3 +154,26 @@ def test_sequence_sampling_stays_inside_one_episode(kind):
     assert bool((((slots - oldest) % cap) < ring.valid_ticks()).all())          # only addressable slots
     with pytest.raises(ValueError):
         ring.sample_sequences(8, cap + 1)
+
+
+def test_ring_attached_in_mid_episode_and_guard_against_outside_steps():
+    """slot 0's predecessor is slot cap - 1 of the ring; it is seeded with the envs' current observation, so a
+    ring attached to envs in mid-episode returns a real `s` for its first transitions; stepping the envs outside the ring
+    between collect() calls is refused."""
+    import torch
+
+    from snac_amd import BatchedDMPEnv, ReplayRing, SnacError
+
+    env = BatchedDMPEnv(2, True, 64, seed=8)
+    env.reset()
+    env.rollout(37)                                              # mid-episode
+    before = env.observe().clone()
+    ring = ReplayRing(env, 16)
+    ring.collect(5)
+    assert int(ring.first[0].sum()) < 64                         # most envs did not start an episode at slot 0
+    b = ring.gather(torch.zeros(64, dtype=torch.int32), torch.arange(64, dtype=torch.int32), with_plan=False)
+    cont = ring.first[0] == 0
+    assert torch.equal(b["s"][cont], before[cont].float()) and torch.equal(b["s_next"], ring.obs[0].float())
+    env.step(auto_reset=True)                                    # behind the ring's back
+    with pytest.raises(SnacError, match="outside the ring"):
+        ring.collect(1)
