@@ -739,10 +739,17 @@ struct Roll3D {
     // per launch.  total_brick <= 0 (only a hand-made header) takes the plain division.
     double rtb = 0.0, dtb = 1.0, rT = 0.0, dT = 1.0;
     uint32_t wq = 0;                                                 // counter-RNG words of 8 ticks: lane e + 8 j holds (env e, tick + j)
+    // EXPL: the caller's actions / step sizes, 16 steps at a time.  A load consumed in the middle of a tick would wait for the
+    // burst just issued, so a window's bytes are loaded a window ahead (into pa / pz), put into this wave's LDS slice
+    // (sin: [2 halves][16 steps][8 envs] actions, then the same for step sizes) right behind the W wait of the window's last
+    // step, and a step reads its byte from LDS.
+    int8_t* sin = nullptr;
+    int pa[2] = {0, 0}, pz[2] = {0, 0};
 
-    __device__ __forceinline__ Roll3D(const KArgs& a_, uint32_t* lds_, const int16_t* tbtab_, float* srew_, uint8_t* sdone_, int lane_,
-                                      int env0_, int nenv_, int wv_)
-        : a(a_), lds(lds_), tbtab(tbtab_), srew(srew_), sdone(sdone_), lane(lane_), env0(env0_), nenv(nenv_), wv(wv_), active(lane_ < nenv_) {}
+    __device__ __forceinline__ Roll3D(const KArgs& a_, uint32_t* lds_, const int16_t* tbtab_, float* srew_, uint8_t* sdone_, int8_t* sin_,
+                                      int lane_, int env0_, int nenv_, int wv_)
+        : a(a_), lds(lds_), tbtab(tbtab_), srew(srew_), sdone(sdone_), lane(lane_), env0(env0_), nenv(nenv_), wv(wv_), active(lane_ < nenv_),
+          sin(sin_) {}
 
     __device__ __forceinline__ void issue_reads() {                 // A
         const int wl = lane < K::W ? lane : 0;
@@ -771,6 +778,25 @@ struct Roll3D {
             for (unsigned long long m = __ballot(nr); m; m &= m - 1) K::clear(lds, __ffsll(m) - 1, lane);
         }
     }
+    __device__ __forceinline__ void issue_inputs(int w) {            // global -> registers: steps 16 w .. 16 w + 15 of this wave's envs
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int tt = 16 * w + 8 * h + (lane >> 3), e = lane & 7;
+            const bool ok = tt < a.T && e < nenv;
+            const size_t at = (size_t)tt * (size_t)a.n + (size_t)(env0 + e);
+            pa[h] = (ok && a.actions) ? (int)a.actions[at] : 0;
+            pz[h] = (ok && a.step_size) ? (int)a.step_size[at] : 1;
+        }
+    }
+    __device__ __forceinline__ void commit_inputs(int w) {           // registers -> LDS half w & 1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int idx = (w & 1) * 128 + 64 * h + lane;
+            sin[idx] = (int8_t)pa[h];
+            sin[256 + idx] = (int8_t)pz[h];
+        }
+    }
+
     // W + S: resolve and write everything of the previous step.  `live`: the env was not reset since (its header is still
     // that episode's).  prev = this lane's slot of the tile's row 0 of that step, prow = its [T][N] row index.
     __device__ __forceinline__ void finish_prev(OT* prev, size_t prow, bool was_reset, int tp) {
@@ -783,6 +809,9 @@ struct Roll3D {
         const int rc = q_newh > q_pl ? -1 : (q_newh == q_pl ? 10 : 1);   // reward_check on the built cell
         const int reward = q_sel ? rc : q_reward;
         const int inc = (q_built && le) ? 1 : 0;                     // min(height, plan) grows by one
+        if constexpr (EXPL) {
+            if ((tp & 15) == 14) commit_inputs((tp + 2) >> 4);       // behind the wait: the next window's bytes have long arrived
+        }
         if (!was_reset) { s.cross += inc; s.ep_ret = clamp16(s.ep_ret + (q_sel ? rc : 0)); }
         const bool fin_ep = active && q_done;
         if (__any(fin_ep)) {                                         // iou (:257-276) = sum(min(g, plan)) / (tb + cb - sum)
@@ -849,8 +878,9 @@ struct Roll3D {
         const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & 7) + 8 * (t & 7)) << 2, (int)wq);
         int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
         if constexpr (EXPL) {
-            if (a.actions) act = active ? (int)a.actions[row + lane] : 0;
-            if (a.step_size) k = active ? min(max((int)a.step_size[row + lane], 1), 3) : 1;
+            const int idx = ((t >> 4) & 1) * 128 + (t & 15) * 8 + (lane & 7);
+            if (a.actions) act = (int)sin[idx];
+            if (a.step_size) k = min(max((int)sin[256 + idx], 1), 3);
         }
         const int slot = lane & (E - 1);                             // idle lanes only READ some env's map
         int16_t* h = K::hmap(lds) + slot * K::ES + s.r * 26 + s.c;
@@ -914,6 +944,9 @@ struct Roll3D {
         q_pl = *plp;
         q_newh = newh; q_built = built; q_sel = sel; q_reward = reward0; q_done = done; q_act = act; q_k = k; q_pidx = s.pidx;
         q_first = first; q_cross = s.cross; q_cb = s.cb; q_tb = s.tb; q_ret = s.ep_ret;
+        if constexpr (EXPL) {
+            if ((t & 15) == 15) issue_inputs((t >> 4) + 2);
+        }
     }
 
     __device__ __forceinline__ void run() {
@@ -929,6 +962,7 @@ struct Roll3D {
         dT = (double)a.total_step; rT = 1.0 / dT;
         OT* const obs = (OT*)a.obs + (size_t)env0 * K::D + lane;      // this lane's slot of the tile's row 0 at step 0
         const size_t tstride = (size_t)a.n * K::D;
+        if constexpr (EXPL) { issue_inputs(0); commit_inputs(0); issue_inputs(1); }
         tick<false>(0, nullptr);
         for (int t = 1; t < a.T; ++t) tick<true>(t, obs + (size_t)(t - 1) * tstride);
         issue_reads();
@@ -950,7 +984,8 @@ template <bool DYN, typename OT, int WPB, bool EXPL>
 __global__ __launch_bounds__(WPB * 64) void k_rollout3d(const KArgs a) {
     using K = K3D<DYN, 8>;
     constexpr int STAGE_WORDS = WPB >= 4 ? (2 * 16 * WPB * 8 * 5 + 3) / 4 : 0;      // reward float + done byte, two halves of 16 steps
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * K::LDS_WORDS + TB_MAX / 2 + STAGE_WORDS];
+    constexpr int IN_WORDS = EXPL ? WPB * 128 : 0;                                  // 512 bytes of staged inputs per wave
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * K::LDS_WORDS + TB_MAX / 2 + STAGE_WORDS + IN_WORDS];
     const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
     // blocks are dealt round-robin over the 8 XCDs: give each XCD a contiguous eighth of the env range, so that the rows of
     // one tick that an XCD's L2 collects are neighbours in memory (+7 % at N = 65 536, nothing at 16 384)
@@ -975,8 +1010,9 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout3d(const KArgs a) {
     // no barrier with the block's other waves.
     int16_t* tbtab = (int16_t*)(lds_all + WPB * K::LDS_WORDS);
     for (int i = lane; i < a.num_plans; i += 64) tbtab[i] = a.plan_tb[i];
-    if (nenv == 8) { Roll3D<DYN, OT, WPB, EXPL, true> r(a, lds, tbtab, srew, sdone, lane, env0, nenv, wv); r.run(); }
-    else { Roll3D<DYN, OT, WPB, EXPL, false> r(a, lds, tbtab, srew, sdone, lane, env0, nenv, wv); r.run(); }
+    int8_t* sin = (int8_t*)(lds_all + WPB * K::LDS_WORDS + TB_MAX / 2 + STAGE_WORDS) + wv * 512;
+    if (nenv == 8) { Roll3D<DYN, OT, WPB, EXPL, true> r(a, lds, tbtab, srew, sdone, sin, lane, env0, nenv, wv); r.run(); }
+    else { Roll3D<DYN, OT, WPB, EXPL, false> r(a, lds, tbtab, srew, sdone, sin, lane, env0, nenv, wv); r.run(); }
 }
 
 // transition(state, action) of the MCTS variants (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175 and the eight sibling files;
