@@ -1089,6 +1089,148 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
     if (active) { a.hdr[drow] = s.pack(); a.episode[drow] = episode; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3D single step / tree edge without the LDS image.  k_transition stages every 800-byte height map into the bordered LDS
+// image and back with 2-byte accesses (profiles/r02_step_*: 524 288 edges in 468 us = 1.5 TB/s of HBM traffic, bound by
+// ~25 narrow memory instructions per edge, not by HBM).  But one step changes ONE cell.  Here a wave takes 32 edges:
+//   lane = edge   header, counter RNG or the caller's action, the six neighbour / path cells and the plan cell read straight
+//                 from the source record (frame cells are -1 by their coordinates), K3D::step by selects;
+//   per edge      the record is copied source -> destination in 16-byte lanes (50 lanes x 16 B), the built cell patched in
+//                 the lane that holds it; lanes 0..48 gather the 7x7 window from the source record (patched the same way),
+//                 lanes 49 / 50 take the scalar slots: one 408-byte row store.
+// Four wide memory instructions per edge instead of ~25 narrow ones.  Semantics are K3D::step's (tests compare with the CPU
+// restatement exactly as for k_transition); layout variants stay on the generic kernel.
+template <bool DYN, typename OT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_transition3d(const KArgs a) {
+    using K = K3D<DYN, 8>;
+    constexpr int E = 32;
+    __shared__ double sc_all[WPB][E][2];
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const int edge0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * WPB + wv) * E);
+    if (edge0 >= a.n) return;
+    const int nedge = min(E, a.n - edge0);
+    const bool active = lane < nedge;
+    const int edge = edge0 + (active ? lane : 0);
+    const int srow = (int)row_of(a.src_index, a.pool, edge), drow = (int)row_of(a.dst_index, a.pool, edge);
+    Lane s;
+    s.unpack(a.hdr[srow]);
+    int episode = a.episode[srow];
+    const uint64_t gid = (uint64_t)(a.env_id_base + edge);
+    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+    if (nr) {
+        const int old_pidx = s.pidx, old_tb = s.tb;
+        episode += 1;
+        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    }
+    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+    if (a.actions) act = (int)a.actions[edge];
+    if (a.step_size) k = (int)a.step_size[edge];
+    k = min(max(k, 1), 3);
+    const int16_t* const g16 = (const int16_t*)a.grid;
+    const int16_t* const src = g16 + (size_t)srow * K::GE;
+    // a cell of the source map in bordered coordinates: the frame is -1, a freshly reset env is empty
+    auto cell = [&](int R, int C) -> int {
+        const bool in = (unsigned)(R - 3) < 20u && (unsigned)(C - 3) < 20u;
+        const int v = (in && !nr) ? (int)src[(R - 3) * 20 + (C - 3)] : 0;
+        return in ? v : -1;
+    };
+    const int d = act & 3;
+    const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
+    const int n0 = cell(s.r, s.c - 1), n1 = cell(s.r, s.c + 1), n2 = cell(s.r + 1, s.c), n3 = cell(s.r - 1, s.c);
+    const int c2 = cell(s.r + 2 * dr, s.c + 2 * dc), c3 = cell(s.r + 3 * dr, s.c + 3 * dc);
+    const int tr = s.r + dr - 3, tc = s.c + dc - 3;
+    const bool inside = (unsigned)tr < 20u && (unsigned)tc < 20u;
+    const int tcell = inside ? tr * 20 + tc : 0;
+    const int pl = ((const int16_t*)a.plans)[(size_t)s.pidx * K::GE + tcell];
+    // K3D::step by selects (the same formulation as Roll3D::tick, without its deferral)
+    const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
+    const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
+    const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
+    s.cs = min(s.cs + 1, CNT_MAX);
+    const bool can_move = valid && act < 4 && nd == 0;
+    const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;
+    s.r += can_move ? dr * m : 0;
+    s.c += can_move ? dc * m : 0;
+    const bool built = active && is_build && nd != -1;
+    const int newh = min(nd + 1, CNT_MAX);
+    s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
+    s.cross += (built && newh <= pl) ? 1 : 0;
+    const bool limit = s.cb >= s.tb + a.brick_gt;
+    bool done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);
+    int reward = 0;
+    const int rcheck = newh > pl ? -1 : (newh == pl ? 10 : 1);
+    if (DYN) {
+        const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
+        const bool fin = is_build && (boxed_post || limit);
+        reward = is_build ? (boxed_post ? -100 : ((!limit && built) ? rcheck : 0)) : 0;
+        done = fin ? true : ((is_build && built) ? false : done);
+    } else {
+        const bool fin = is_build && (limit || boxed_pre);
+        reward = (is_build && !fin && built) ? rcheck : 0;
+        done = fin ? true : ((is_build && built) ? false : done);
+    }
+    s.ep_ret = clamp16(s.ep_ret + reward);
+    s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    if (active) {
+        if (a.reward) a.reward[edge] = (float)reward;
+        if (a.done) a.done[edge] = done ? 1 : 0;
+        if (a.stats_on && done) {                                // snac_step: episodic sums
+            const double v = K::iou(nullptr, s, 0);
+            a.stat_episodes[drow] += 1;
+            a.stat_return[drow] += s.ep_ret;
+            a.stat_iou_fx[drow] += __double2ll_rn(v * FX40);
+        }
+    }
+    // the two scalar observation slots of every edge -> LDS
+    {
+        const double c0 = (double)s.cb, c1 = (double)s.cs;
+        double (*sc)[2] = sc_all[wv];
+        if (lane < E) { sc[lane][0] = DYN ? c0 / (double)s.tb : c0; sc[lane][1] = DYN ? c1 / (double)a.total_step : c1; }
+    }
+    const int tpatch = built ? tcell : -1;                           // interior index of the cell this step changed
+    const int key_r = s.r, key_c = s.c;
+    const int wl = lane < K::W ? lane : 0, wi = wl / 7, wj = wl - 7 * wi;
+    const uint4* const g4 = (const uint4*)a.grid;
+    uint4* const g4w = (uint4*)a.grid;
+    OT* const orow = a.obs ? (OT*)a.obs + (size_t)edge0 * K::D + lane : nullptr;
+    for (int e = 0; e < nedge; ++e) {                                // wave-uniform: readlane broadcasts edge e's scalars
+        const int se = __builtin_amdgcn_readlane(srow, e), de = __builtin_amdgcn_readlane(drow, e);
+        const int tp = __builtin_amdgcn_readlane(tpatch, e), nh = __builtin_amdgcn_readlane(newh, e);
+        const bool fresh = __builtin_amdgcn_readlane((int)nr, e) != 0;
+        // the 7x7 window around the NEW position, read from the source record before the record is overwritten in place
+        int wv_cell = -1;
+        double scal = 0.0;
+        if (orow) {
+            const int R = __builtin_amdgcn_readlane(key_r, e) - 3 + wi, C = __builtin_amdgcn_readlane(key_c, e) - 3 + wj;
+            const bool in = (unsigned)(R - 3) < 20u && (unsigned)(C - 3) < 20u;
+            const int idx = in ? (R - 3) * 20 + (C - 3) : 0;
+            const int v = (in && !fresh && lane < K::W) ? (int)g16[(size_t)se * K::GE + idx] : 0;
+            wv_cell = in ? (idx == tp ? nh : v) : -1;
+            scal = sc_all[wv][e][lane >= K::W ? min(lane - K::W, 1) : 0];
+        }
+        if (lane < 50) {
+            uint4 v = fresh ? make_uint4(0u, 0u, 0u, 0u) : g4[(size_t)se * 50 + lane];
+            if (tp >= 0 && (tp >> 3) == lane) {                      // this lane's 8 cells hold the built one
+                const int hw = tp & 7, sh = (hw & 1) * 16;
+                const uint32_t keep = ~(0xFFFFu << sh), put = ((uint32_t)nh & 0xFFFFu) << sh;
+                uint32_t* pv = &v.x;
+                if ((hw >> 1) == 0) v.x = (v.x & keep) | put;
+                else if ((hw >> 1) == 1) v.y = (v.y & keep) | put;
+                else if ((hw >> 1) == 2) v.z = (v.z & keep) | put;
+                else v.w = (v.w & keep) | put;
+                (void)pv;
+            }
+            g4w[(size_t)de * 50 + lane] = v;
+        }
+        if (orow && lane < K::D) orow[(size_t)e * K::D] = (OT)(lane < K::W ? (double)wv_cell : scal);
+    }
+    if (active) { a.hdr[drow] = s.pack(); a.episode[drow] = episode; }
+}
+
 // reset(mask, plan_idx_in) / observe / iou on the same tile machinery
 template <class K, typename OT, int WPB, bool VAR>
 __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
@@ -1554,6 +1696,14 @@ void launch_roll3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     }
 }
 
+void launch_trans3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
+    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
+    const int tiles = (a.n + 31) / 32;
+    const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+    if (dyn) { if (f32) hipLaunchKernelGGL((k_transition3d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<true, double, 4>), grid, block, 0, s, a); }
+    else { if (f32) hipLaunchKernelGGL((k_transition3d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<false, double, 4>), grid, block, 0, s, a); }
+}
+
 template <template <bool, int> class KT, int WPB>
 void launch_tile(Op op, bool dyn, int E, int obs_dtype, const KArgs& a, hipStream_t s) {
     if (E == 64) dyn ? launch_dt<KT, true, 64, WPB>(op, obs_dtype, a, s) : launch_dt<KT, false, 64, WPB>(op, obs_dtype, a, s);
@@ -1571,6 +1721,7 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
         case SNAC_ENV_2D: launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
             if (op == OP_ROLLOUT && E == 8 && !a.variant && a.obs_mode == SNAC_OBS_ALL && a.num_plans <= TB_MAX && !pipeline_off()) { launch_roll3d(d, a, s); break; }
+            if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans3d(d, a, s); break; }
             if (E == 8 && a.n < 8192) dyn ? launch_dt<K3D, true, 8, 1>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 1>(op, d->obs_dtype, a, s);
             else if (E == 8) dyn ? launch_dt<K3D, true, 8, 4>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 4>(op, d->obs_dtype, a, s);
             else dyn ? launch_dt<K3D, true, 16, 2>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 16, 2>(op, d->obs_dtype, a, s);
