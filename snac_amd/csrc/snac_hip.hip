@@ -1231,6 +1231,155 @@ __global__ __launch_bounds__(WPB * 64) void k_transition3d(const KArgs a) {
     if (active) { a.hdr[drow] = s.pack(); a.episode[drow] = episode; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2D single step / tree edge without the LDS image.  k_transition expands every 80-byte bit-board into the bordered two-bit
+// LDS image and squeezes it back (20 rows per edge, for a window that shows 7 of them and a step that changes one bit).
+// Here a wave takes E edges and nothing is staged:
+//   lane = edge   header, counter RNG or the caller's action, K2D::step on the agent's row word and the plan's row word;
+//                 then the 7 row words around the NEW position, cut to the 7 window columns and re-coded as two-bit cells
+//                 (00 empty / 01 brick / 11 frame, as in the LDS image): the whole 7x7 window is 98 bits = 4 registers;
+//   per edge      four v_readlane broadcast those registers, lane l < 49 extracts the signed two-bit field at bit 2 l
+//                 (0 / 1 / -1), lanes 49 / 50 take the broadcast scalar slots: one 408-byte row store, no load, no LDS;
+//   the record    in place (snac_step): only the row word a brick changed is written back.  Gathered / scattered rows
+//                 (snac_transition): copied source -> destination three records per instruction (lane = row word), the
+//                 changed word patched on the way.
+// Semantics are K2D::step's (tests compare with the CPU restatement exactly as for k_transition); layout variants stay on
+// the generic kernel.
+template <bool DYN, typename OT, int WPB, int E>
+__global__ __launch_bounds__(WPB * 64) void k_transition2d(const KArgs a) {
+    using K = K2D<DYN, 64>;
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const int edge0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * WPB + wv) * E);
+    if (edge0 >= a.n) return;
+    const int nedge = min(E, a.n - edge0);
+    const bool active = lane < nedge;
+    const int edge = edge0 + (active ? lane : 0);
+    const int srow = (int)row_of(a.src_index, a.pool, edge), drow = (int)row_of(a.dst_index, a.pool, edge);
+    Lane s;
+    s.unpack(a.hdr[srow]);
+    int episode = a.episode[srow];
+    const uint64_t gid = (uint64_t)(a.env_id_base + edge);
+    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+    if (nr) {
+        const int old_pidx = s.pidx, old_tb = s.tb;
+        episode += 1;
+        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    }
+    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+    if (a.actions) act = (int)a.actions[edge];
+    if (a.step_size) k = (int)a.step_size[edge];
+    k = min(max(k, 1), 3);
+    const uint32_t* const g32 = (const uint32_t*)a.grid;
+    const uint32_t* const src = g32 + (size_t)srow * K::GE;
+    const uint32_t* const prow = (const uint32_t*)a.plans + (size_t)s.pidx * K::GE;
+    // ---- K2D::step (DMP_Env_2D_dynamic_usedata_plan.py:85-147) on the agent's row word; a freshly reset board is empty
+    const int q0 = min(max(s.r - 3, 0), K::GE - 1), bit = min(max(s.c - 3, 0), 19);
+    const uint32_t row0 = nr ? 0u : src[q0];
+    const bool was = ((row0 >> bit) & 1u) != 0u, planned = ((prow[q0] >> bit) & 1u) != 0u;
+    const bool drop = active && act == 4;
+    const uint32_t newrow = row0 | (1u << bit);                      // += 1 then clamp to 1 (:115, :134-135)
+    const int patch = drop ? q0 : -1;                                // the board row this step changed
+    s.cs = min(s.cs + 1, CNT_MAX);
+    if (drop) s.cb = min(s.cb + 1, CNT_MAX);
+    if (act == 0) s.c = max(s.c - k, 3);                             // clip_position :74-83
+    if (act == 1) s.c = min(s.c + k, 22);
+    if (act == 2) s.r = min(s.r + k, 22);                            // "up" is row + k (:100-103)
+    if (act == 3) s.r = max(s.r - k, 3);
+    const bool term = drop && s.cb >= s.tb + a.brick_gt;             // :117-126, tested before the time limit
+    const bool done = term || s.cs >= a.ts_done;
+    const int reward = (drop && !term && !was && planned) ? 5 : 0;   // un-clamped cell vs plan (:129-133)
+    s.ep_ret = clamp16(s.ep_ret + reward);
+    s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    if (active) {
+        if (a.reward) a.reward[edge] = (float)reward;
+        if (a.done) a.done[edge] = done ? 1 : 0;
+        if (a.stats_on && done) {                                    // snac_step: episodic sums; the boolean IoU needs board and plan
+            int inter = 0, uni = 0;
+            uint32_t gq[K::GE], pq[K::GE];
+#pragma unroll
+            for (int q = 0; q < K::GE; ++q) { gq[q] = nr ? 0u : src[q]; pq[q] = prow[q]; }   // all 40 loads in flight together
+#pragma unroll
+            for (int q = 0; q < K::GE; ++q) {
+                const uint32_t g = q == patch ? newrow : gq[q];
+                inter += __popc(g & pq[q]); uni += __popc(g | pq[q]);
+            }
+            const double v = (double)inter / (double)uni;
+            a.stat_episodes[drow] += 1;
+            a.stat_return[drow] += s.ep_ret;
+            a.stat_iou_fx[drow] += __double2ll_rn(v * FX40);
+        }
+    }
+    // ---- the 7x7 window around the new position as 49 two-bit cells: window cell l = 7 i + j is the field at bit 2 l
+    uint32_t win[4] = {0u, 0u, 0u, 0u};
+    double sc0 = 0.0, sc1 = 0.0;
+    if (a.obs) {
+        const int sh = s.c - 3;                                      // first window column, bordered: 0..19
+        constexpr uint32_t FRAME26 = 0x3800007u;                     // frame columns 0-2 and 23-25 of an interior row
+        const uint32_t frm = spread16((FRAME26 >> sh) & 0x7Fu) * 3u; // 11 in every frame cell of the 7 columns
+        uint32_t enc[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int q = s.r - 6 + i;                               // board row of window row i
+            const bool in = (unsigned)q < (unsigned)K::GE;
+            const int qc = in ? q : 0;
+            uint32_t g = (in && !nr) ? src[qc] : 0u;
+            g = qc == patch ? newrow : g;                            // a drop does not move: the changed row is window row 3
+            enc[i] = in ? (spread16(((g << 3) >> sh) & 0x7Fu) | frm) : 0x3FFFu;
+        }
+        const uint64_t lo = (uint64_t)enc[0] | ((uint64_t)enc[1] << 14) | ((uint64_t)enc[2] << 28) | ((uint64_t)enc[3] << 42) | ((uint64_t)enc[4] << 56);
+        const uint64_t hi = (uint64_t)(enc[4] >> 8) | ((uint64_t)enc[5] << 6) | ((uint64_t)enc[6] << 20);
+        win[0] = (uint32_t)lo; win[1] = (uint32_t)(lo >> 32); win[2] = (uint32_t)hi; win[3] = (uint32_t)(hi >> 32);
+        const double c0 = (double)s.cb, c1 = (double)s.cs;
+        sc0 = DYN ? c0 / (double)s.tb : c0;
+        sc1 = DYN ? c1 / (double)a.total_step : c1;
+    }
+    // ---- the record
+    uint32_t* const g32w = (uint32_t*)a.grid;
+    if (a.src_index || a.dst_index) {
+        // three records per instruction: lane = (edge of the trio, row word)
+        const int sub = lane / K::GE, q = lane - sub * K::GE;
+        for (int e0 = 0; e0 < nedge; e0 += 3) {
+            const int e = e0 + sub;
+            const bool ok = sub < 3 && e < nedge;
+            const int el = (ok ? e : e0) << 2;
+            const int se = __builtin_amdgcn_ds_bpermute(el, srow), de = __builtin_amdgcn_ds_bpermute(el, drow);
+            const int pe = __builtin_amdgcn_ds_bpermute(el, patch), fresh = __builtin_amdgcn_ds_bpermute(el, (int)nr);
+            const uint32_t ne = (uint32_t)__builtin_amdgcn_ds_bpermute(el, (int)newrow);
+            if (ok) {
+                uint32_t v = fresh ? 0u : g32[(size_t)se * K::GE + q];
+                v = q == pe ? ne : v;
+                g32w[(size_t)de * K::GE + q] = v;
+            }
+        }
+    } else if (active) {
+        if (nr) for (int q = 0; q < K::GE; ++q) g32w[(size_t)drow * K::GE + q] = q == patch ? newrow : 0u;
+        else if (drop) g32w[(size_t)drow * K::GE + q0] = newrow;
+    }
+    if (active) { a.hdr[drow] = s.pack(); a.episode[drow] = episode; }
+    // ---- the observation rows: broadcast, extract, one store per edge
+    if (a.obs) {
+        const int wsel = min(lane >> 4, 3), wsh = 2 * (lane & 15);
+        const int slo0 = (int)(uint32_t)__double_as_longlong(sc0), shi0 = (int)(uint32_t)(__double_as_longlong(sc0) >> 32);
+        const int slo1 = (int)(uint32_t)__double_as_longlong(sc1), shi1 = (int)(uint32_t)(__double_as_longlong(sc1) >> 32);
+        OT* const orow = (OT*)a.obs + (size_t)edge0 * K::D + lane;
+        const bool is_win = lane < K::W;
+        for (int e = 0; e < nedge; ++e) {                            // wave-uniform: readlane broadcasts edge e's registers
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)win[0], e), w1 = (uint32_t)__builtin_amdgcn_readlane((int)win[1], e);
+            const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)win[2], e), w3 = (uint32_t)__builtin_amdgcn_readlane((int)win[3], e);
+            const uint32_t ww = wsel == 0 ? w0 : (wsel == 1 ? w1 : (wsel == 2 ? w2 : w3));
+            const int cellv = ((int)((ww >> wsh) << 30)) >> 30;      // signed 2-bit field: 0 / 1 / -1
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane(slo0, e), a1 = (uint32_t)__builtin_amdgcn_readlane(shi0, e);
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane(slo1, e), b1 = (uint32_t)__builtin_amdgcn_readlane(shi1, e);
+            const double scal = __longlong_as_double((long long)(((uint64_t)(lane == K::W ? a1 : b1) << 32) | (lane == K::W ? a0 : b0)));
+            if (lane < K::D) orow[(size_t)e * K::D] = (OT)(is_win ? (double)cellv : scal);
+        }
+    }
+}
+
 // reset(mask, plan_idx_in) / observe / iou on the same tile machinery
 template <class K, typename OT, int WPB, bool VAR>
 __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
@@ -1669,7 +1818,7 @@ int pick_tile(int kind, int n) {
     return 8;                        // small batches: one-wave blocks of 8 envs, so that 4096 envs still reach every CU
 }
 
-// SNAC_3D_PIPELINE=0 keeps 3D rollouts on the generic kernel (A/B timing, tests of both paths)
+// SNAC_3D_PIPELINE=0 keeps 3D rollouts and 2D / 3D single steps on the generic kernels (A/B timing, tests of both paths)
 bool pipeline_off() {
     static const bool off = [] { const char* e = std::getenv("SNAC_3D_PIPELINE"); return e && e[0] == '0'; }();
     return off;
@@ -1704,6 +1853,25 @@ void launch_trans3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     else { if (f32) hipLaunchKernelGGL((k_transition3d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<false, double, 4>), grid, block, 0, s, a); }
 }
 
+// E edges per wave.  The kernel is bound by HBM traffic from N = 2^19 down to where the launch itself dominates; 32 edges per
+// wave were 4 % ahead of 64 there (two rounds of waves: the second round's loads run under the first round's row stores),
+// small batches take 16 so that a step() on 4096 envs is still 256 waves.  SNAC_T2D_E overrides (tuning).
+template <bool DYN, typename OT>
+void launch_trans2d_e(const KArgs& a, hipStream_t s) {
+    static const int forced = [] { const char* e = std::getenv("SNAC_T2D_E"); return e ? std::atoi(e) : 0; }();
+    const int E = (forced == 16 || forced == 32 || forced == 64) ? forced : (a.n >= 65536 ? 32 : 16);
+    const int tiles = (a.n + E - 1) / E;
+    const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+    if (E == 64) hipLaunchKernelGGL((k_transition2d<DYN, OT, 4, 64>), grid, block, 0, s, a);
+    else if (E == 32) hipLaunchKernelGGL((k_transition2d<DYN, OT, 4, 32>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_transition2d<DYN, OT, 4, 16>), grid, block, 0, s, a);
+}
+void launch_trans2d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
+    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
+    if (dyn) f32 ? launch_trans2d_e<true, float>(a, s) : launch_trans2d_e<true, double>(a, s);
+    else f32 ? launch_trans2d_e<false, float>(a, s) : launch_trans2d_e<false, double>(a, s);
+}
+
 template <template <bool, int> class KT, int WPB>
 void launch_tile(Op op, bool dyn, int E, int obs_dtype, const KArgs& a, hipStream_t s) {
     if (E == 64) dyn ? launch_dt<KT, true, 64, WPB>(op, obs_dtype, a, s) : launch_dt<KT, false, 64, WPB>(op, obs_dtype, a, s);
@@ -1718,7 +1886,9 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     const int E = pick_tile(d->kind, a.n);
     switch (d->kind) {
         case SNAC_ENV_1D: launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
-        case SNAC_ENV_2D: launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
+        case SNAC_ENV_2D:
+            if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans2d(d, a, s); break; }
+            launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
             if (op == OP_ROLLOUT && E == 8 && !a.variant && a.obs_mode == SNAC_OBS_ALL && a.num_plans <= TB_MAX && !pipeline_off()) { launch_roll3d(d, a, s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans3d(d, a, s); break; }
