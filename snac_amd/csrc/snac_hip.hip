@@ -710,6 +710,30 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
 // compare both paths with the CPU restatement).  Layout variants, OBS_LAST / OBS_NONE, more than TB_MAX plans: generic kernel.
 constexpr int TB_MAX = 2048;   // plan_tb rows staged in LDS per block
 
+// reward [T][N] float and done [T][N] uint8 of one wave's 8 envs are 32-byte and 8-byte pieces: written per tick they cost
+// 15 % of a whole 3D pass (sub-64-byte writes, tools/wr_shape3d.hip).  The pipelined rollouts (k_rollout3d, k_rollout1d: 8 envs
+// per wave) stage 16 steps per block in LDS and write whole runs (WPB = 8: 256 B and 64 B).  Two stage halves: ONE barrier per
+// 16 steps (a wave has flushed half A before it meets the barrier that releases half B's flush).  Called by every wave of the
+// block at the same steps, idle waves included.  benv: the block's first env.
+template <int WPB>
+__device__ void flush_stage(const KArgs& a, const float* srew, const uint8_t* sdone, int tp, int benv, int wv, int lane) {
+    constexpr int BE = WPB * 8;
+    __syncthreads();
+    const int t0 = tp & ~15, rows = tp - t0 + 1;
+    const int env = benv + lane;
+    for (int r = wv; r < rows; r += WPB) {
+        const int slot = ((t0 + r) & 31) * BE;
+        const size_t orow = (size_t)(t0 + r) * (size_t)a.n;
+        if (a.reward && lane < BE && env < a.n) a.reward[orow + env] = srew[slot + lane];
+        if (a.done) {
+            if ((a.n & 3) == 0) {                                    // dword runs (rows are 4-byte aligned)
+                if (lane < BE / 4 && benv + 4 * lane < a.n) ((uint32_t*)(a.done + orow + benv))[lane] = ((const uint32_t*)(sdone + slot))[lane];
+            } else if (lane < BE && env < a.n) a.done[orow + env] = sdone[slot + lane];
+        }
+    }
+}
+
+
 template <bool DYN, typename OT, int WPB, bool EXPL, bool FULL>
 struct Roll3D {
     using K = K3D<DYN, 8>;
@@ -841,29 +865,9 @@ struct Roll3D {
             if (a.first_out) a.first_out[prow + lane] = q_first ? 1 : 0;
         }
         if constexpr (STAGE) {
-            if ((tp & 15) == 15 || tp == a.T - 1) flush_stage(a, srew, sdone, tp, env0 - wv * E, wv, lane);
+            if ((tp & 15) == 15 || tp == a.T - 1) flush_stage<WPB>(a, srew, sdone, tp, env0 - wv * E, wv, lane);
         }
     }
-    // reward [T][N] float and done [T][N] uint8 of one wave's 8 envs are 32-byte and 8-byte pieces: written per tick they cost
-    // 15 % of the whole pass (sub-64-byte writes, tools/wr_shape3d.hip).  The block stages 16 steps in LDS and writes whole runs
-    // (WPB = 8: 256 B and 64 B).  Two stage halves: ONE barrier per 16 steps (a wave has flushed half A before it meets the
-    // barrier that releases half B's flush).  Called by every wave of the block at the same steps, idle waves included.
-    __device__ static void flush_stage(const KArgs& a, const float* srew, const uint8_t* sdone, int tp, int benv, int wv, int lane) {
-        __syncthreads();
-        const int t0 = tp & ~15, rows = tp - t0 + 1;
-        const int env = benv + lane;
-        for (int r = wv; r < rows; r += WPB) {
-            const int slot = ((t0 + r) & 31) * BE;
-            const size_t orow = (size_t)(t0 + r) * (size_t)a.n;
-            if (a.reward && lane < BE && env < a.n) a.reward[orow + env] = srew[slot + lane];
-            if (a.done) {
-                if ((a.n & 3) == 0) {                                // dword runs (rows are 4-byte aligned)
-                    if (lane < BE / 4 && benv + 4 * lane < a.n) ((uint32_t*)(a.done + orow + benv))[lane] = ((const uint32_t*)(sdone + slot))[lane];
-                } else if (lane < BE && env < a.n) a.done[orow + env] = sdone[slot + lane];
-            }
-        }
-    }
-
     // step t; EMIT: the outputs of step t-1 are resolved and written on the way
     template <bool EMIT>
     __device__ __forceinline__ void tick(int t, OT* prev) {
@@ -1000,7 +1004,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout3d(const KArgs a) {
         if constexpr (WPB >= 4) {
             if (blk * WPB * 8 < a.n)
                 for (int tp = 0; tp < a.T; ++tp)
-                    if ((tp & 15) == 15 || tp == a.T - 1) Roll3D<DYN, OT, WPB, EXPL, true>::flush_stage(a, srew, sdone, tp, blk * WPB * 8, wv, lane);
+                    if ((tp & 15) == 15 || tp == a.T - 1) flush_stage<WPB>(a, srew, sdone, tp, blk * WPB * 8, wv, lane);
         }
         return;
     }
@@ -1013,6 +1017,215 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout3d(const KArgs a) {
     int8_t* sin = (int8_t*)(lds_all + WPB * K::LDS_WORDS + TB_MAX / 2 + STAGE_WORDS) + wv * 512;
     if (nenv == 8) { Roll3D<DYN, OT, WPB, EXPL, true> r(a, lds, tbtab, srew, sdone, sin, lane, env0, nenv, wv); r.run(); }
     else { Roll3D<DYN, OT, WPB, EXPL, false> r(a, lds, tbtab, srew, sdone, sin, lane, env0, nenv, wv); r.run(); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1D fused rollout (counter RNG, every observation written), built round the dependency chain instead of the tile machinery.
+// BASELINE config 2 (1D static, N = 4096) is 512 waves walking 750 dependent ticks: with the generic kernel a tick costs
+// 0.59 us (hash, LDS round trips for the cell, the scalar slots and the 7-value rows, one after the other) while the whole
+// pass writes only 187 MB.  Two facts shorten the chain:
+//   * in 1D (DMP_Env_1D_static.py:85-136) position, count_brick, count_step, done and the auto-reset depend on the ACTIONS
+//     only, never on the heights: the control chain of a tick is a dozen VALU instructions; the heights enter the reward and
+//     the window, and both can be resolved a tick later;
+//   * a wave's 64 lanes are laid out as (env e, observation element el): lane 7 e + el, 8 envs = 56 lanes.  The 7 lanes of an
+//     env run the same control chain redundantly, so every lane already knows where ITS element lives -- window lanes read
+//     one height from LDS, lanes 5 / 6 compute their scalar slot -- and the tile's 8 rows leave as one 448-byte store with no
+//     cross-lane traffic at all.  Lane el = 2 (the window centre = the agent's cell) owns the env: it adds the brick
+//     (ds_add, no read-modify-write round trip; heights saturate on read), resolves the reward and keeps the episodic sums.
+// A tick issues its LDS reads and finishes the PREVIOUS tick (reward, row store, staged reward / done) while they fly; two
+// register sets alternate so that no copy waits for them.  The counter RNG hashes 8 ticks at once in all 64 lanes (lane
+// e + 8 j: env e, tick t + j), a tick fetches its word with one bpermute.  reward / done: whole runs per block (flush_stage).
+// Semantics are K1D::step's; explicit inputs, layout variants, OBS_LAST / OBS_NONE stay on the generic kernel.
+template <bool DYN, typename OT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_rollout1d(const KArgs a) {
+    using K = K1D<DYN, 8>;
+    constexpr int BE = WPB * 8;
+    constexpr bool STAGE = WPB >= 4;
+    constexpr int H_WORDS = 8 * 34, P_WORDS = 8 * 32;                // heights int32 [8][34] with the frame, plans int32 [8][32] (no
+                                                                     // conversion behind a read: its first use is a tick later)
+    constexpr int WAVE_WORDS = H_WORDS + P_WORDS;
+    constexpr int STAGE_WORDS = STAGE ? (2 * 16 * BE * 5 + 3) / 4 : 0;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * WAVE_WORDS + STAGE_WORDS + 1];
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const int chunk = ((int)gridDim.x + 7) >> 3;                     // an XCD owns a contiguous eighth of the env range
+    const int blk = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+    const int env0 = __builtin_amdgcn_readfirstlane((blk * WPB + wv) * 8);
+    float* srew = (float*)(lds_all + WPB * WAVE_WORDS);
+    uint8_t* sdone = (uint8_t*)(srew + (STAGE ? 2 * 16 * BE : 0));
+    if (env0 >= a.n) {                                               // a wave without envs keeps its block's flushes company
+        if constexpr (STAGE) {
+            if (blk * BE < a.n)
+                for (int tp = 0; tp < a.T; ++tp)
+                    if ((tp & 15) == 15 || tp == a.T - 1) flush_stage<WPB>(a, srew, sdone, tp, blk * BE, wv, lane);
+        }
+        return;
+    }
+    const int nenv = min(8, a.n - env0);
+    int* const H = (int*)(lds_all + wv * WAVE_WORDS);
+    int* const PL = H + H_WORDS;
+    const int e = min(lane / 7, 7), el = lane < 56 ? lane - 7 * e : 0;
+    const bool live = lane < 56 && e < nenv;                         // this lane has an observation element
+    const bool own = live && el == 2;                                // ... and owns its env
+    const int env = env0 + (e < nenv ? e : 0);
+    Lane s;
+    s.unpack(a.hdr[env]);
+    int episode = a.episode[env];
+    {   // records -> LDS: heights with their frame, the envs' plans
+        const int16_t* g16 = (const int16_t*)a.grid;
+        for (int i = lane; i < 8 * 34; i += 64) {
+            const int ee = i / 34, c = i - ee * 34;
+            int v = -1;
+            if (c >= 2 && c < 32) v = ee < nenv ? (int)g16[(size_t)(env0 + ee) * K::GE + (c - 2)] : 0;
+            H[i] = v;
+        }
+        for (int i = lane; i < 8 * 32; i += 64) {
+            const int ee = i >> 5, c = i & 31;
+            const int pe = __shfl(s.pidx, 7 * ee);                   // lane 7 ee holds env ee's header
+            PL[i] = (int)((const int16_t*)a.plans)[(size_t)pe * K::GE + c];
+        }
+    }
+    const EnvKeys pk = env_keys(a.key_plan, (uint64_t)(a.env_id_base + env));
+    const EnvKeys sk = env_keys(a.key_step, (uint64_t)(a.env_id_base + env0 + (lane & 7)));   // producer layout: env (lane & 7)
+    // cb / tb and cs / T without a division per tick (Roll3D: correctly rounded for 0 <= n <= 32767, 1 <= d <= 32767)
+    double dtb = (double)s.tb, rtb = 1.0 / dtb;
+    const double dT = (double)a.total_step, rT = 1.0 / dT;
+    int d_eps = 0, d_ret = 0;
+    long long d_iou = 0;
+    uint32_t wq = rng_word(sk, a.t0 + (uint32_t)(lane >> 3));        // the words of steps 0..7
+    uint32_t wnext = (uint32_t)__builtin_amdgcn_ds_bpermute(e << 2, (int)wq);   // step 0's, fetched a step ahead from now on
+    // what a tick leaves open for the next one to finish: two sets in rotation
+    struct Open { int v, pl, ret; double sc; long long iou_fx; bool drop, term, done, first; int act, k, pidx; };
+    Open o[2];
+    o[0] = Open{0, 0, 0, 0.0, 0, false, false, false, false, 0, 1, 0};
+    o[1] = o[0];
+    OT* const obs = (OT*)a.obs + (size_t)env0 * K::D + lane;
+    const size_t tstride = (size_t)a.n * K::D;
+    int* const hrow = H + e * 34;
+    const int* const prow = PL + e * 32;
+
+    const bool rec = a.actions_out || a.step_size_out || a.plan_idx_out || a.first_out;
+    // finish step tp: reward, episodic sums, the row, staged reward / done
+    auto finish = [&](const Open& q, int tp, bool was_reset) {
+        const int hv = min(q.v, CNT_MAX);                            // heights saturate (on read: LDS holds the raw count)
+        const int reward = (q.drop && !q.term) ? (hv > q.pl ? -1 : (hv == q.pl ? 10 : 1)) : 0;   // :117-123, the owner's hv is the agent's cell
+        const int tot = clamp16(q.ret + reward);
+        if (!was_reset) s.ep_ret = tot;
+        if (own && q.done) { d_eps += 1; d_ret += tot; d_iou += q.iou_fx; }
+        const double val = el < K::W ? (double)hv : q.sc;
+        if (live) obs[(size_t)tp * tstride] = (OT)val;
+        const size_t prw = (size_t)tp * (size_t)a.n + (size_t)env;
+        if constexpr (STAGE) {
+            if (lane < 56 && el == 2) {                              // idle envs of a ragged tile stage values nobody writes out
+                const int slot = (tp & 31) * BE + wv * 8 + e;
+                srew[slot] = (float)reward;
+                sdone[slot] = q.done ? 1 : 0;
+            }
+        }
+        if (own) {
+            if constexpr (!STAGE) {
+                if (a.reward) a.reward[prw] = (float)reward;
+                if (a.done) a.done[prw] = q.done ? 1 : 0;
+            }
+            if (__builtin_expect(rec, 0)) {                          // snac_rollout_rec only
+                if (a.actions_out) a.actions_out[prw] = (int8_t)q.act;
+                if (a.step_size_out) a.step_size_out[prw] = (int8_t)q.k;
+                if (a.plan_idx_out) a.plan_idx_out[prw] = (int16_t)q.pidx;
+                if (a.first_out) a.first_out[prw] = q.first ? 1 : 0;
+            }
+        }
+        if constexpr (STAGE) {
+            if ((tp & 15) == 15 || tp == a.T - 1) flush_stage<WPB>(a, srew, sdone, tp, env0 - wv * 8, wv, lane);
+        }
+    };
+    // step t into `cur`; the previous step (`prev`) is finished on the way
+    auto tick = [&](int t, Open& cur, const Open& prev) {
+        const bool was_reset = a.auto_reset && prev.done && t > 0;
+        const bool nr = lane < 56 && e < nenv && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+        if (__builtin_expect(__any(nr), 0)) {                        // rare: all 7 lanes of the env reset it together
+            if (nr) {
+                const int old_pidx = s.pidx, old_tb = s.tb;
+                episode += 1;
+                const int pidx = pick_plan<K>(a, pk, episode, old_pidx);
+                K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+                if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+                dtb = (double)s.tb; rtb = 1.0 / dtb;
+                for (int c = el; c < 30; c += 7) {
+                    hrow[2 + c] = 0;
+                    if (pidx != old_pidx) PL[e * 32 + c] = (int)((const int16_t*)a.plans)[(size_t)pidx * K::GE + c];
+                }
+            }
+        }
+        const uint32_t w = wnext;
+        const int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+        const int pos0 = s.r;
+        const bool drop = act == 2;
+        cur.first = s.cs == 0;
+        s.cs = min(s.cs + 1, CNT_MAX);
+        if (drop) s.cb = min(s.cb + 1, CNT_MAX);
+        if (drop && own) __hip_atomic_fetch_add(hrow + pos0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_add: the brick
+        if (act == 0) s.r = max(pos0 - k, 2);                        // clip_position :57-64
+        if (act == 1) s.r = min(pos0 + k, 31);
+        const bool term = drop && s.cb >= s.tb + a.brick_gt;         // :107-114, before the time limit
+        const bool done = term || s.cs >= a.ts_done;
+        s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+        // the next step's RNG word, asked for a whole step ahead (every 8th step all 64 lanes hash the next 8 words first)
+        if (((t + 1) & 7) == 0) wq = rng_word(sk, a.t0 + (uint32_t)(t + 1) + (uint32_t)(lane >> 3));
+        wnext = (uint32_t)__builtin_amdgcn_ds_bpermute((e + 8 * ((t + 1) & 7)) << 2, (int)wq);
+        // this step's LDS reads: the lane's window cell around the new position, the plan cell under the agent
+        cur.v = hrow[s.r - 2 + min(el, K::W - 1)];
+        cur.pl = prow[pos0 - 2];
+        {
+            const double c0 = (double)s.cb, c1 = (double)s.cs;
+            double v0 = c0, v1 = c1;
+            if (DYN) {
+                const double q0 = c0 * rtb, q1 = c1 * rT;
+                v0 = __builtin_fma(__builtin_fma(-q0, dtb, c0), rtb, q0);
+                v1 = __builtin_fma(__builtin_fma(-q1, dT, c1), rT, q1);
+                if (__builtin_expect(__any(live && s.tb <= 0), 0)) { // never in practice; the asm keeps it a branch (no if-conversion)
+                    asm volatile("" ::: "memory");
+                    v0 = c0 / dtb;
+                }
+            }
+            cur.sc = el == K::W ? v0 : v1;
+        }
+        cur.iou_fx = 0;
+        if (__builtin_expect(__any(own && done), 0)) {               // iou :138-151 of the finished episode, before the reset clears the row
+            if (own && done) {
+                int a1 = 0, a2 = 0, kk = 0;
+                for (int i = 0; i < 30; ++i) {
+                    const int g = min(hrow[2 + i], CNT_MAX), pp = prow[i];
+                    a1 += pp; a2 += g; kk += max(g - pp, 0);
+                }
+                const int cross = a2 - kk;
+                cur.iou_fx = __double2ll_rn(((double)cross / (double)(a1 + a2 - cross)) * FX40);
+            }
+        }
+        cur.drop = drop; cur.term = term; cur.done = done; cur.act = act; cur.k = k; cur.pidx = s.pidx;
+        if (t > 0) finish(prev, t - 1, was_reset);
+        cur.ret = s.ep_ret;                                          // the running return without this step's reward
+    };
+    for (int t = 0; t < a.T; t += 2) {                               // two steps per trip: the register sets alternate
+        tick(t, o[0], o[1]);
+        if (t + 1 < a.T) tick(t + 1, o[1], o[0]);
+    }
+    if ((a.T - 1) & 1) finish(o[1], a.T - 1, false);
+    else finish(o[0], a.T - 1, false);
+    {   // LDS -> records
+        int16_t* g16 = (int16_t*)a.grid;
+        for (int i = lane; i < nenv * K::GE; i += 64) {
+            const int ee = i >> 5, c = i & 31;
+            g16[(size_t)(env0 + ee) * K::GE + c] = c < 30 ? (int16_t)min(H[ee * 34 + 2 + c], CNT_MAX) : (int16_t)0;
+        }
+    }
+    if (own) {
+        a.hdr[env] = s.pack();
+        a.episode[env] = episode;
+        if (d_eps) {
+            a.stat_episodes[env] += d_eps;
+            a.stat_return[env] += d_ret;
+            a.stat_iou_fx[env] += d_iou;
+        }
+    }
 }
 
 // transition(state, action) of the MCTS variants (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175 and the eight sibling files;
@@ -1818,7 +2031,7 @@ int pick_tile(int kind, int n) {
     return 8;                        // small batches: one-wave blocks of 8 envs, so that 4096 envs still reach every CU
 }
 
-// SNAC_3D_PIPELINE=0 keeps 3D rollouts and 2D / 3D single steps on the generic kernels (A/B timing, tests of both paths)
+// SNAC_3D_PIPELINE=0 keeps every launch on the generic tile kernels (A/B timing, tests of both paths)
 bool pipeline_off() {
     static const bool off = [] { const char* e = std::getenv("SNAC_3D_PIPELINE"); return e && e[0] == '0'; }();
     return off;
@@ -1842,6 +2055,23 @@ void launch_roll3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     } else {
         if (dyn) f32 ? launch_roll3d_w<true, float, 4>(a, s) : launch_roll3d_w<true, double, 4>(a, s);
         else f32 ? launch_roll3d_w<false, float, 4>(a, s) : launch_roll3d_w<false, double, 4>(a, s);
+    }
+}
+
+template <bool DYN, typename OT, int WPB>
+void launch_roll1d_w(const KArgs& a, hipStream_t s) {
+    const int tiles = (a.n + 7) / 8, blocks = (tiles + WPB - 1) / WPB;
+    const dim3 grid((unsigned)(((blocks + 7) / 8) * 8)), block(WPB * 64);   // a multiple of 8: the XCD remap covers every tile
+    hipLaunchKernelGGL((k_rollout1d<DYN, OT, WPB>), grid, block, 0, s, a);
+}
+void launch_roll1d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
+    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
+    if (a.n < 8192) {   // one-wave blocks reach every CU with small batches
+        if (dyn) f32 ? launch_roll1d_w<true, float, 1>(a, s) : launch_roll1d_w<true, double, 1>(a, s);
+        else f32 ? launch_roll1d_w<false, float, 1>(a, s) : launch_roll1d_w<false, double, 1>(a, s);
+    } else {            // 64 envs per block: reward / done leave as whole 256-byte / 64-byte runs
+        if (dyn) f32 ? launch_roll1d_w<true, float, 8>(a, s) : launch_roll1d_w<true, double, 8>(a, s);
+        else f32 ? launch_roll1d_w<false, float, 8>(a, s) : launch_roll1d_w<false, double, 8>(a, s);
     }
 }
 
@@ -1885,7 +2115,11 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     const bool dyn = d->dynamic != 0;
     const int E = pick_tile(d->kind, a.n);
     switch (d->kind) {
-        case SNAC_ENV_1D: launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
+        case SNAC_ENV_1D:
+            // up to two waves per SIMD (N <= 16 384) a 1D pass is bound by its dependency chain: the chain-shaped kernel; beyond,
+            // by instruction issue: the tile kernel (lane-per-env transition) needs fewer instructions per env-step
+            if (op == OP_ROLLOUT && a.n <= 16384 && !a.variant && a.obs_mode == SNAC_OBS_ALL && !a.actions && !a.step_size && !pipeline_off()) { launch_roll1d(d, a, s); break; }
+            launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D:
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans2d(d, a, s); break; }
             launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;

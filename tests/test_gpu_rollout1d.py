@@ -1,0 +1,107 @@
+"""GPU: the chain-shaped 1D rollout kernel (k_rollout1d: counter RNG, every observation written, N <= 16 384) against the
+CPU oracle -- one-wave blocks and 64-env blocks, ragged tiles and blocks with idle waves, odd / tiny tick counts (the two
+register sets alternate per step), episodes that end by count_brick and by the time limit, the `>` rule bits, float32
+observations, the per-step record outputs, and equality with the generic tile kernel (explicit inputs take that one)."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(dyn):
+    t = helpers.plan_table(1, dyn, "sin_train" if dyn else "p1")
+    return t, t.reshape(len(t), 30)
+
+
+def _pair(dyn, n, seed, total_step=None, obs_dtype=None, brick_gt=False, time_gt=False):
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table, full = _tables(dyn)
+    env = BatchedDMPEnv(1, dyn, n, plans=full, seed=seed, env_id_base=77, total_step=total_step, obs_dtype=obs_dtype or torch.float64,
+                        brick_gt=brick_gt, time_gt=time_gt)
+    orc = helpers.oracle().OracleBatch(1, dyn, n, table, seed=seed, env_id_base=77)
+    if total_step:
+        orc.set_total_step(total_step)
+    orc.set_rules(brick_gt, time_gt)
+    o = orc.reset()
+    assert env.reset().cpu().numpy().tobytes() == (o.astype(np.float32) if obs_dtype == torch.float32 else o).tobytes()
+    return env, orc
+
+
+def _compare(env, orc, T, t0, f32=False):
+    og, rg, dg = env.rollout(T)
+    oc, rc, dc = orc.rollout(T, t0=t0, nthreads=8)
+    want = oc.astype(np.float32) if f32 else oc
+    assert og.cpu().numpy().tobytes() == want.tobytes()
+    assert rg.cpu().numpy().tobytes() == rc.tobytes()
+    assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+
+
+def _end_state(env, orc):
+    st = orc.state()
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(env.num_envs, -1), st["grid"].astype(np.float64))
+    for name, key in (("count_brick", "cb"), ("count_step", "cs"), ("plan_idx", "plan_idx"), ("episode", "episode"), ("episode_return", "ep_return")):
+        assert np.array_equal(getattr(env, name).cpu().numpy(), st[key]), name
+    assert np.array_equal(env.need_reset.cpu().numpy().astype(np.uint8), st["need_reset"])
+    s, e = orc.stats(), env.episodic_stats()
+    assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
+
+
+@pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
+@pytest.mark.parametrize("n", [1, 13, 4100, 8200, 16384])
+def test_batch_shapes_and_tick_counts(dyn, n):
+    """n = 1 / 13: a lone ragged tile; 4100: one-wave blocks, last tile ragged; 8200: 64-env blocks, the last block holds one
+    full tile and seven waves without envs; 16 384: the largest batch the kernel takes.  Launches of 1, 2, 37 and 80 steps."""
+    env, orc = _pair(dyn, n, seed=5, total_step=60)
+    t0 = 0
+    for T in (1, 2, 37, 80):
+        _compare(env, orc, T, t0)
+        t0 += T
+    _end_state(env, orc)
+
+
+@pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
+@pytest.mark.parametrize("rules", [(False, False), (True, False), (False, True), (True, True)], ids=str)
+def test_episodes_end_by_bricks_and_by_time(dyn, rules):
+    """total_step 3000: a third of the steps drop a brick, so episodes end at count_brick >= (>) total_brick (~600) long before the
+    time limit; total_step 45: they end by time, > 60 episodes per env."""
+    for total_step, T in ((3000, 2900), (45, 2900)):
+        env, orc = _pair(dyn, 72, seed=9, total_step=total_step, brick_gt=rules[0], time_gt=rules[1])
+        _compare(env, orc, T, 0)
+        _end_state(env, orc)
+        assert env.episodic_stats()["episodes"] > 0
+
+
+def test_float32_observations():
+    import torch
+
+    env, orc = _pair(True, 200, seed=2, obs_dtype=torch.float32)
+    _compare(env, orc, 750, 0, f32=True)
+    _compare(env, orc, 33, 750, f32=True)
+
+
+@pytest.mark.parametrize("n", [40, 9000])
+def test_record_outputs_and_the_tile_kernel_agree(n):
+    """The record outputs (action taken, step size used, plan row, first-step flag) of a counter-RNG rollout, fed back as
+    explicit inputs -- which the generic tile kernel handles -- must reproduce observations, rewards and done flags."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    _, full = _tables(True)
+    T = 130
+    a = BatchedDMPEnv(1, True, n, plans=full, seed=21, total_step=50)
+    b = BatchedDMPEnv(1, True, n, plans=full, seed=21, total_step=50)
+    a.reset()
+    b.reset()
+    rec = {"actions": torch.empty((T, n), dtype=torch.int8, device="cuda"), "step_size": torch.empty((T, n), dtype=torch.int8, device="cuda"),
+           "plan_idx": torch.empty((T, n), dtype=torch.int16, device="cuda"), "first": torch.empty((T, n), dtype=torch.uint8, device="cuda")}
+    oa, ra, da = a.rollout(T, record=rec)
+    ob, rb, db = b.rollout(T, actions=rec["actions"], step_size=rec["step_size"])
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    first = rec["first"].cpu().numpy()
+    done = da.cpu().numpy()
+    assert first[0].all() and np.array_equal(first[1:], done[:-1].astype(np.uint8))   # auto-reset: a step opens an episode iff the last one ended one
+    assert np.array_equal(rec["plan_idx"][-1].cpu().numpy(), a.plan_idx.cpu().numpy())   # an env is reset by its NEXT step
