@@ -632,7 +632,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
         int reward = 0;
         bool done = false;
         const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
-        if (__any(nr)) {
+        if (__builtin_expect(__any(nr), 0)) {                        // rare paths out of line: a taken branch costs a lone wave ~30 cycles
             const int old_pidx = s.pidx, old_tb = s.tb;
             if (nr) {
                 episode += 1;
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
             if (a.plan_idx_out) a.plan_idx_out[row + lane] = (int16_t)s.pidx;
             if (a.first_out) a.first_out[row + lane] = s.cs == 1 ? 1 : 0;   // first step of its episode
         }
-        if (__any(done)) {
+        if (__builtin_expect(__any(done), 0)) {
             const double v = K::iou(lds, s, active ? lane : 0);      // idle lanes stay inside the wave's LDS slice
             if (done) { d_eps += 1; d_ret += s.ep_ret; d_iou += __double2ll_rn(v * FX40); }
         }
