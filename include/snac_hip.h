@@ -187,6 +187,13 @@ int snac_step_scalar(const snac_env_desc* desc, const snac_state* st, uint32_t t
 /* snac_reset of every env onto plan row `plan_idx`, passed by value (the single-env caller's reset()) */
 int snac_reset_scalar(const snac_env_desc* desc, const snac_state* st, int32_t plan_idx, void* obs, void* stream);
 
+/* Block the calling thread until everything enqueued on `stream` has finished (hipStreamSynchronize).  The single-env caller's
+ * read-back: `obs` of snac_step_scalar / snac_reset_scalar may point into page-locked host memory (hipHostMalloc, a pinned
+ * torch tensor: mapped into the GPU's address space), the kernel then stores its row there itself and this wait is all that
+ * separates the launch from reading it -- env.step(action) -> (obs, reward, done) of the reference classes
+ * (Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:85-147) as one launch and one wait, no copy command. */
+int snac_stream_sync(void* stream);
+
 /* the driver loop of multiprocess.py:78-84 -- T vector steps with auto-reset, fused in one launch with the
  * env state held on chip.
  *   actions / step_size   int8[T][N] or NULL (counter RNG, ticks t0 .. t0+T-1)

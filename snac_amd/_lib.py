@@ -22,7 +22,7 @@ TAIL_POSITION, TAIL_PLAN, TAIL_RECORD = 1, 2, 4
 EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_obs_dim", "snac_reset", "snac_reset_scalar", "snac_step",
            "snac_step_scalar", "snac_rollout",
            "snac_rollout_rec", "snac_replay_gather", "snac_make_plans", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
-           "snac_import_state", "snac_obs_equal")
+           "snac_import_state", "snac_obs_equal", "snac_stream_sync")
 
 
 class Sizes(C.Structure):
@@ -77,6 +77,7 @@ def lib():
         vp = C.c_void_p
         L.snac_version.restype = C.c_int
         L.snac_last_error.restype = C.c_char_p
+        L.snac_stream_sync.argtypes = [vp]
         L.snac_env_sizes.argtypes = [C.c_int, C.c_int, C.POINTER(Sizes)]
         L.snac_obs_dim.argtypes = [C.POINTER(EnvDesc)]
         L.snac_reset.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp, vp, vp]

@@ -2145,6 +2145,11 @@ int snac_version(void) { return SNAC_ABI_VERSION; }
 
 const char* snac_last_error(void) { return g_err; }
 
+int snac_stream_sync(void* stream) {
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? SNAC_OK : fail_hip(e, "hipStreamSynchronize");
+}
+
 int snac_env_sizes(int kind, int dynamic, snac_sizes* o) {
     if (!o) return fail(SNAC_ERR_ARG, "null out");
     std::memset(o, 0, sizeof(*o));

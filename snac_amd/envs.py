@@ -54,19 +54,23 @@ class _Facade(_Base):
 
         lay = dict(self._layout)
         tail = tuple(lay.pop("obs_tail", ())) + ("record",)
-        # obs_tail "record": every reset() / step() is ONE launch and ONE device-to-host copy -- the row carries the
+        # obs_tail "record": every reset() / step() is ONE launch and ONE wait -- the row carries the
         # observation, reward, done, position and counters (SNAC_TAIL_RECORD); action / step size / plan index travel by value
         self._env = BatchedDMPEnv(self._dim, self._dynamic, 1, plans=plans_full, total_step=total_step,
                                   brick_gt=getattr(self, "_brick_gt", False), time_gt=getattr(self, "_time_gt", False),
                                   obs_tail=tail, **lay)
         self._table = np.asarray(plans_full, np.float64)
-        self._row = self._env._new_obs()                       # reused device row
+        # the row lives in page-locked host memory: the kernel writes it over the bus, the host waits for the stream -- a
+        # step is one launch and one wait, no copy command (tools/facade_time.py: 22 -> 16 us per step)
+        self._row = self._env.new_host_obs()
+        self._row_np = self._row.numpy()
         self._nobs = self._env.obs_dim - 8                     # the observation proper (with the variant's own tail)
 
     # ---- shared plumbing ---------------------------------------------------------------------------
     def _read(self):
-        """The one device-to-host copy of a reset() / step(): -> (obs [1, n], reward, done, r, c, cb, cs, tb)."""
-        row = self._row.cpu().numpy()
+        """The one wait of a reset() / step(): -> (obs [1, n], reward, done, r, c, cb, cs, tb)."""
+        self._env.sync()
+        row = self._row_np.copy()                              # the buffer is rewritten by the next launch
         rec = row[0, self._nobs:]
         return row[:, :self._nobs], float(rec[0]), bool(rec[1]), int(rec[2]), int(rec[3]), int(rec[4]), int(rec[5]), int(rec[6])
 

@@ -120,6 +120,34 @@ def test_scalar_step_and_reset_equal_the_array_forms():
         env.reset_scalar(400)
 
 
+@pytest.mark.parametrize("kind", [1, 2, 3])
+def test_rows_written_into_page_locked_host_memory(kind):
+    """new_host_obs(): the kernels store their rows straight into page-locked host memory (what the single-env classes read
+    after one wait); the same steps into a device row must give the same bytes.  Unpinned or mis-shaped host tensors are refused."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    n = 5
+    a = BatchedDMPEnv(kind, True, n, seed=4, obs_tail=("record",))
+    b = BatchedDMPEnv(kind, True, n, seed=4, obs_tail=("record",))
+    host = a.new_host_obs()
+    assert host.is_pinned() and host.device.type == "cpu"
+    a.reset_scalar(11, out=host)
+    a.sync()
+    assert host.numpy().tobytes() == b.reset_scalar(11).cpu().numpy().tobytes()
+    A = helpers.DIMS[kind]["A"]
+    rng = np.random.default_rng(kind)
+    for t in range(300):
+        act, k = int(rng.integers(0, A)), int(rng.integers(1, 4))
+        a.step_scalar(act, k, auto_reset=True, out=host)
+        a.sync()
+        assert host.numpy().tobytes() == b.step_scalar(act, k, auto_reset=True).cpu().numpy().tobytes(), t
+    with pytest.raises(ValueError):
+        a.step_scalar(0, 1, out=torch.empty((n, a.obs_dim), dtype=torch.float64))            # not page-locked
+    with pytest.raises(ValueError):
+        a.step_scalar(0, 1, out=torch.empty((n + 1, a.obs_dim), dtype=torch.float64, pin_memory=True))
+
+
 # ---- the reference's own recordings through the BATCHED path --------------------------------------------------------------------
 def _npz(name):
     return np.load(os.path.join(helpers.GOLDEN, name))

@@ -63,6 +63,43 @@ def record(pinned=False):
     return STEPS / (time.perf_counter() - t0)
 
 
+def zerocopy(spin=False):
+    """The kernel writes its row straight into page-locked host memory (the pointer is valid on the device: unified addressing);
+    the host only waits for the stream -- no copy command at all."""
+    import ctypes as C
+
+    from snac_amd import _lib
+
+    env = BatchedDMPEnv(2, True, 1, seed=1, obs_tail=("record",))
+    host = torch.empty((1, env.obs_dim), dtype=torch.float64, pin_memory=True)
+    view = host.numpy()
+    L = env._lib
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    hp = C.c_void_p(host.data_ptr())
+    _lib.check(L.snac_reset_scalar(C.byref(env._desc), C.byref(env._state), 3, hp, sp))
+    stream.synchronize()
+    env._was_reset = True
+    rng = np.random.RandomState(0)
+    acts = rng.randint(0, 5, STEPS)
+    ev = torch.cuda.Event()
+    t0 = time.perf_counter()
+    for i in range(STEPS):
+        k = int(np.random.randint(1, 4))
+        _lib.check(L.snac_step_scalar(C.byref(env._desc), C.byref(env._state), env.t & 0xFFFFFFFF, int(acts[i]), k, 0, hp, None, None, sp))
+        env.t += 1
+        if spin:
+            ev.record(stream)
+            while not ev.query():
+                pass
+        else:
+            stream.synchronize()
+        if view[0, 52]:
+            _lib.check(L.snac_reset_scalar(C.byref(env._desc), C.byref(env._state), int(np.random.randint(0, 400)), hp, sp))
+            stream.synchronize()
+    return STEPS / (time.perf_counter() - t0)
+
+
 def the_class():
     from snac_amd.envs import deep_mobile_printing_2d1r_dynamic
 
@@ -81,6 +118,8 @@ def the_class():
 def main():
     for name, fn in (("round-1 path (2 H2D + 4 D2H syncs per step)", legacy), ("record row + .cpu() (1 D2H per step)", record),
                      ("record row + pinned async copy + stream sync", lambda: record(True)),
+                     ("row written into pinned host memory + stream sync", zerocopy),
+                     ("row written into pinned host memory + event spin", lambda: zerocopy(True)),
                      ("deep_mobile_printing_2d1r.step() (the class)", the_class)):
         fn()                                                     # warm-up pass
         rate = fn()
