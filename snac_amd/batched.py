@@ -117,6 +117,7 @@ class BatchedDMPEnv:
         self.t = 0  # tick: number of vector steps taken (keys the counter RNG)
         self._was_reset = False
         self._host_ok = None                                         # the new_host_obs() row validated last
+        self._mapped = {}                                            # page-locked host tensors seen by _is_mapped
 
     # ---- helpers -------------------------------------------------------------------------------
     def _stream(self):
@@ -125,11 +126,25 @@ class BatchedDMPEnv:
             return C.c_void_p(raw(self.device.index))
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _is_mapped(self, t):
+        """A page-locked host tensor: mapped into the GPU's address space, kernels read / write it over the bus (inputs and
+        outputs of a host-side caller without a copy command)."""
+        if t.device.type != "cpu":
+            return False
+        if self._mapped.get(id(t)) is t:
+            return True
+        if not t.is_pinned():
+            return False
+        if len(self._mapped) >= 32:
+            self._mapped.clear()
+        self._mapped[id(t)] = t
+        return True
+
     def _i8(self, x, shape, what):
         if x is None:
             return None
-        if torch.is_tensor(x) and x.dtype == torch.int8 and x.device == self.device and x.is_contiguous() \
-                and tuple(x.shape) == tuple(shape):
+        if torch.is_tensor(x) and x.dtype == torch.int8 and x.is_contiguous() and tuple(x.shape) == tuple(shape) \
+                and (x.device == self.device or self._is_mapped(x)):
             return x                                            # the per-tick case: nothing to convert
         if not torch.is_tensor(x):
             x = torch.as_tensor(np.asarray(x), device=self.device)
@@ -158,13 +173,10 @@ class BatchedDMPEnv:
             return self._new_obs()
         if out is self._host_ok:                                     # checked before: the per-step call of a single-env class
             return out
+        self._buf(out, (self.num_envs, self.obs_dim), self.obs_dtype, "out")
         if out.device.type == "cpu":                                 # new_host_obs(): written by the kernel over the bus
-            if not out.is_pinned() or tuple(out.shape) != (self.num_envs, self.obs_dim) or out.dtype != self.obs_dtype or not out.is_contiguous():
-                raise ValueError("a host `out` must be a contiguous page-locked %s tensor of shape %s (new_host_obs())"
-                                 % (self.obs_dtype, (self.num_envs, self.obs_dim)))
             self._host_ok = out
-            return out
-        return self._buf(out, (self.num_envs, self.obs_dim), self.obs_dtype, "out")
+        return out
 
     # ---- API -----------------------------------------------------------------------------------
     def reset(self, mask=None, plan_idx=None):
@@ -195,6 +207,8 @@ class BatchedDMPEnv:
         """One vector step.  actions int[N] (None: counter RNG), step_size int[N] in {1,2,3} (None: counter RNG).
         out: optional preallocated (obs [N, obs_dim] obs_dtype, reward [N] float32, done [N] uint8) reused every tick -- a
         training loop that steps small batches is bound by host time, and three allocations are a third of it.
+        Inputs and outputs may also be page-locked HOST tensors (torch.empty(..., pin_memory=True); new_host_obs()): the kernel
+        reads / writes them over the bus and the caller only waits (sync()) -- what VectorizedEnvWrapper does.
         Returns (obs [N, obs_dim], reward float32 [N], done bool [N])."""
         if not self._was_reset:
             raise _lib.SnacError("step() before reset()")
@@ -245,8 +259,9 @@ class BatchedDMPEnv:
         return obs
 
     def _buf(self, t, shape, dtype, what):
-        if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != self.device or not t.is_contiguous():
-            raise ValueError("%s must be a contiguous %s tensor of shape %s on %s" % (what, dtype, tuple(shape), self.device))
+        if tuple(t.shape) != tuple(shape) or t.dtype != dtype or not t.is_contiguous() or not (t.device == self.device or self._is_mapped(t)):
+            raise ValueError("%s must be a contiguous %s tensor of shape %s on %s (or in page-locked host memory)"
+                             % (what, dtype, tuple(shape), self.device))
         return t
 
     def rollout(self, T, actions=None, step_size=None, obs="all", out=None, want_reward=True, want_done=True,

@@ -19,6 +19,8 @@ from .batched import BatchedDMPEnv
 
 
 class VectorizedEnvWrapper:
+    HOST_OBS_MAX = 1024
+
     def __init__(self, env_, num_envs=1, device="cuda", obs_dtype=None):
         """env_: one of the snac_amd.envs facades (its kind, plan set and plan mode are copied), or a
         (kind, dynamic, plans) tuple."""
@@ -36,6 +38,15 @@ class VectorizedEnvWrapper:
         self.batched = BatchedDMPEnv(kind, dynamic, self.num_envs, plans=plans, device=device,
                                      obs_dtype=obs_dtype or torch.float64)
         self.envs = [self.batched] * self.num_envs        # len(wrapper.envs) and envs[0].total_step keep working
+        # numpy in, numpy out without copy commands: actions, step sizes, rewards and done flags live in page-locked host
+        # memory that the kernel reads / writes over the bus; so do the observation rows of a small batch (up to HOST_OBS_MAX
+        # envs the kernel's own stores beat a DMA copy, tools/hostrow_time.py), a large batch copies them from the device
+        n = self.num_envs
+        pin = dict(pin_memory=True)
+        self._a, self._k = torch.empty(n, dtype=torch.int8, **pin), torch.empty(n, dtype=torch.int8, **pin)
+        self._r, self._d = torch.empty(n, dtype=torch.float32, **pin), torch.empty(n, dtype=torch.uint8, **pin)
+        self._o = self.batched.new_host_obs() if n <= self.HOST_OBS_MAX else self.batched._new_obs()
+        self._a_np, self._k_np, self._r_np, self._d_np = self._a.numpy(), self._k.numpy(), self._r.numpy(), self._d.numpy()
         self.action_dim = self.batched.num_actions
         self.total_step = self.batched.total_step
 
@@ -62,14 +73,19 @@ class VectorizedEnvWrapper:
         return obs[env_index].cpu().numpy().reshape(1, -1)
 
     def step(self, actions):
-        import torch
-
         actions = np.asarray(actions)
         if actions.shape != (self.num_envs,):
             raise ValueError("actions must have shape (%d,)" % self.num_envs)
         if actions.min() < 0 or actions.max() >= self.action_dim:
             raise ValueError("action outside [0, %d)" % self.action_dim)
-        k = np.random.randint(1, 4, size=self.num_envs)
-        obs, rew, done = self.batched.step(torch.from_numpy(actions.astype(np.int8)), torch.from_numpy(k.astype(np.int8)))
-        return (obs.cpu().numpy().reshape(self.num_envs, 1, -1), rew.cpu().numpy().astype(np.float64),
-                done.cpu().numpy())
+        self._k_np[:] = np.random.randint(1, 4, size=self.num_envs)
+        self._a_np[:] = actions
+        b = self.batched
+        b.step(self._a, self._k, out=(self._o, self._r, self._d))
+        if self._o.device.type == "cpu":                         # one launch, one wait
+            b.sync()
+            obs = self._o.numpy().copy()
+        else:                                                    # the copy is ordered behind the kernel on the same stream
+            obs = self._o.cpu().numpy()
+            b.sync()
+        return obs.reshape(self.num_envs, 1, -1), self._r_np.astype(np.float64), self._d_np.astype(bool)

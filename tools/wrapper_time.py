@@ -2,14 +2,14 @@ import sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from snac_amd import VectorizedEnvWrapper, plans
-for n in (4096, 65536):
+for n in (16, 256, 1024, 4096, 65536):
     env = VectorizedEnvWrapper((2, True, plans.dataset(2, "dense", "train")), num_envs=n)
     np.random.seed(0)
     env.reset()
     acts = np.random.randint(5, size=n)
     for _ in range(5): env.step(acts)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    T = 50
+    T = 50 if n >= 4096 else 500
     for _ in range(T):
         env.step(np.random.randint(5, size=n))
     dt = (time.perf_counter() - t0) / T
