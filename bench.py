@@ -345,6 +345,9 @@ def main():
         wpeak = measured_write_peak(torch, dev)
         written = WRITTEN_BYTES[(args.kind, dkey)] * n * T / (kern_ms * 1e-3) / 1e9
         what = "%dD %s dense" % (args.kind, "dynamic" if dynamic else "static")
+        # the kernel this workload dispatches to (snac_hip.hip::launch): the 2D tile kernel, the pipelined 3D rollout, the
+        # chain-shaped 1D rollout up to 16 384 envs
+        kernel_name = "k_rollout3d" if args.kind == 3 else ("k_rollout1d" if args.kind == 1 and n <= 16384 else "k_rollout")
         out = {
             "metric": HEADLINE if headline else "env-steps/sec at N=%d envs (%s, %s obs); bit-exact vs CPU" % (n, what, dkey),
             "value": total_steps / dt,
@@ -368,7 +371,7 @@ def main():
                          "peak_measured_write": wpeak,
                          "written": written,                      # output bytes of the launch / its duration, GB/s
                          "frac_of_measured_write": ((traffic or written) / wpeak) if wpeak else None,
-                         "kernel": "k_rollout", "kernel_ms": kern_ms, "alg_bytes_per_env_step": alg},
+                         "kernel": kernel_name, "kernel_ms": kern_ms, "alg_bytes_per_env_step": alg},
             "backend": backend if world > 1 else None,
             "rccl_ranks": ranks_seen if (world > 1 and backend == "nccl") else None,
             "ranks": ranks_seen,
