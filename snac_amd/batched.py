@@ -330,7 +330,7 @@ class BatchedDMPEnv:
         """Rewrite rows [first, first + count) of the device plan table with freshly generated plans (snac_make_plans): the
         random triangles of the reference's 2D / 3D create_plan() (Env/2D/DMP_Env_2D_dynamic_hindsight_replay_usedata.py:37-59)
         or, 1D, its random sine curves (Env/1D/DMP_Env_1D_dynamic_hindsight_replay.py:29-42) -- one wavefront per plan, so a
-        65 536-env batch gets 65 536 plans of its own instead of the 400 stored ones.  Plan row r is keyed by
+        65 536-env batch can draw from up to 32 767 plans (the table's limit: plan rows are int16) instead of the 400 stored ones.  Plan row r is keyed by
         (seed, id_base + r) on counter-RNG stream 2; vertices: optional int8 [count, 6] = x0 y0 x1 y1 x2 y2 rasterised as
         given (no redraw).  Envs keep stepping on their current row: reset them to pick the new plans up.
         Returns the number of cells set per plan (int32 [count]; 1D: total_brick)."""
