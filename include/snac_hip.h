@@ -89,7 +89,9 @@ enum { SNAC_RULE_BRICK_GT = 1, SNAC_RULE_TIME_GT = 2 };
  *     SNAC_TAIL_PLAN      the env's plan, 1D: 30 heights, 2D / 3D: input_plan 20x20 row-major -- the flat observation of
  *                         script/PPO/{1d,2d,3d}_dynamic (37 / 451 values)
  *     SNAC_TAIL_RECORD    8 values: reward, done, pos_r, pos_c, count_brick, count_step, total_brick, plan_idx of the env
- *                         after the step -- everything a single-env caller reads back, in ONE row (one D2H copy) */
+ *                         after the step -- everything a single-env caller reads back, in ONE row (one D2H copy).  A row
+ *                         written outside a step (snac_reset, also for the envs its mask leaves alone; snac_observe)
+ *                         reports reward 0 and done = the env's pending-reset flag */
 enum { SNAC_SCALARS_DEFAULT = 0, SNAC_SCALARS_RAW = 1, SNAC_SCALARS_NORM = 2 };
 enum { SNAC_TAIL_POSITION = 1, SNAC_TAIL_PLAN = 2, SNAC_TAIL_RECORD = 4 };
 

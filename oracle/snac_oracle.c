@@ -72,7 +72,12 @@ int orc_set_tail(orc_env* e, int tail) {
 
 /* observation: S1:81-83 / D1:66-70 (1D window g[p-2..p+2]); S2:78-82, D2:68-72, D3:125-129 (7x7 window,
  * row-major flatten) followed by [cb, cs] (static) or [cb/tb, cs/T] (dynamic: D2:64-66, D3:73-75, D1:68-70) */
-void orc_observe(const orc_env* e, double* obs) {
+static void observe_row(const orc_env* e, double* obs, int in_step);
+/* the row outside a step (reset of an env a mask leaves alone, snac_observe): the record tail reports reward 0 and done = the
+ * env's pending-reset flag (include/snac_hip.h, SNAC_TAIL_RECORD) */
+void orc_observe(const orc_env* e, double* obs) { observe_row(e, obs, 0); }
+
+static void observe_row(const orc_env* e, double* obs, int in_step) {
     int n = 0;
     if (e->dim == 1) {
         for (int j = -e->hw; j <= e->hw; ++j) obs[n++] = (double)e->grid[e->pos[0] + j];
@@ -98,7 +103,7 @@ void orc_observe(const orc_env* e, double* obs) {
         else for (int r = 3; r < 23; ++r) for (int c = 3; c < 23; ++c) obs[n++] = (double)P(e, r, c);
     }
     if (e->tail & ORC_TAIL_RECORD) {
-        obs[n++] = (double)e->last_reward; obs[n++] = (double)e->last_done;
+        obs[n++] = in_step ? (double)e->last_reward : 0.0; obs[n++] = (double)e->last_done;
         obs[n++] = (double)e->pos[0]; obs[n++] = (double)e->pos[1];
         obs[n++] = (double)e->cb; obs[n++] = (double)e->cs; obs[n++] = (double)e->tb; obs[n++] = (double)e->plan_idx;
     }
@@ -284,7 +289,7 @@ int orc_step(orc_env* e, int action, int k, double* obs, double* reward, int* do
     else rc = step3(e, action, k, &r, &d);
     if (rc) return rc;
     e->last_reward = (int32_t)r; e->last_done = d;
-    if (obs) orc_observe(e, obs);
+    if (obs) observe_row(e, obs, 1);
     if (reward) *reward = r;
     if (done) *done = d;
     return 0;
@@ -303,7 +308,7 @@ int orc_transition(const orc_env* src, orc_env* dst, int action, int k, int gate
     rc = orc_step(dst, action, k, NULL, reward, done);
     dst->tb = tb;
     if (rc) return rc;
-    if (obs) orc_observe(dst, obs);
+    if (obs) observe_row(dst, obs, 1);
     return 0;
 }
 

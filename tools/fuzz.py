@@ -46,9 +46,19 @@ def trial(rng, idx):
     table = helpers.plan_table(dim, dyn, tag)
     full = table.reshape(len(table), 30) if dim == 1 else table.reshape(len(table), 26, 26)
     ctx = dict(trial=idx, dim=dim, dyn=dyn, n=n, f32=f32, total_step=total_step, brick_gt=bgt, time_gt=tgt, seed=seed, base=base, plans=tag)
+    lay = {}
+    if rng.random() < 0.25:                                       # an observation-layout variant: flags of the kernels
+        tails = [t for t in ("position", "plan", "record") if rng.random() < 0.5]
+        if n > 5000 and "plan" in tails:
+            tails.remove("plan")                                  # 400 more values per row: keep the oracle's share small
+        lay = dict(obs_tail=tuple(tails), frame_value=int(rng.choice([-1, 2])) if dim != 3 else -1, obs_scalars=str(rng.choice(["raw", "norm"])))
+    ctx["layout"] = lay
     env = BatchedDMPEnv(dim, dyn, n, plans=full, seed=seed, env_id_base=base, total_step=total_step or None,
-                        obs_dtype=torch.float32 if f32 else torch.float64, brick_gt=bgt, time_gt=tgt)
+                        obs_dtype=torch.float32 if f32 else torch.float64, brick_gt=bgt, time_gt=tgt, **lay)
     orc = helpers.oracle().OracleBatch(dim, dyn, n, table, seed=seed, env_id_base=base)
+    if lay:
+        orc.configure(obs_norm={None: dyn, "raw": False, "norm": True}[env.obs_scalars], frame=env.frame_value, tail=env.obs_tail)
+        assert orc.obs_dim == env.obs_dim
     if total_step:
         orc.set_total_step(total_step)
     orc.set_rules(bgt, tgt)
@@ -133,7 +143,7 @@ def main():
         ctx, t, eps = trial(rng, i)
         print("fuzz %3d ok  %dD %-3s n=%-6d %s T=%-4d rules=%d%d  ticks=%-4d episodes=%-7d ops=%s" % (
             i, ctx["dim"], "dyn" if ctx["dyn"] else "sta", ctx["n"], "f32" if ctx["f32"] else "f64", ctx["total_step"], ctx["brick_gt"], ctx["time_gt"],
-            t, eps, ",".join(ctx["ops"])), flush=True)
+            t, eps, ",".join(ctx["ops"]) + (" layout=%s" % (ctx["layout"],) if ctx["layout"] else "")), flush=True)
     print("fuzz: %d trials identical to the oracle (seed %d, %.0f s)" % (trials, seed, time.time() - t0))
 
 
