@@ -5,7 +5,7 @@
 //   PER    contiguous bytes per lane (16: one dwordx4 per lane per pass; 32 / 64: 2 / 4 adjacent dwordx4 per lane, as a
 //          vectorised elementwise kernel writes)
 //   SPREAD consecutive workgroups go to SPREAD far-apart regions (each region then filled chunk by chunk); the tensor is cleared
-//          before and the bytes written are checked after (a first version without that reported 7.1-7.2 TB/s for these variants)
+//          before and the bytes written are checked after; these variants flip between 5.7-6.2 and 6.9-7.2 TB/s from run to run
 //   SHIFT  workgroup b writes chunk (b / 8) * 8 + ((b + SHIFT) & 7): the same chunks in the same order, but each chunk is written
 //          by a workgroup that is SHIFT positions further round the 8 XCDs (workgroups are dealt to the XCDs round-robin) -- if
 //          the rate depends on SHIFT, it depends on WHICH XCD writes a chunk (XCD <-> HBM-stack distance)
