@@ -298,14 +298,18 @@ def main():
     preroll_ms = float(os.environ.get("SNAC_BENCH_PREROLL_MS", "60"))
     preroll_passes = 0
     if preroll_ms > 0:
+        # on a scratch batch of the same shape: the measured batch runs exactly W + K passes, whatever the pre-roll's length
+        pre = BatchedDMPEnv(args.kind, dynamic, n, device=dev, seed=2, env_id_base=rank * n,
+                            obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+        pre.reset()
         a0, b0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a0.record()
-        env.rollout(T, obs="all", out=obs)
+        pre.rollout(T, obs="all", out=obs)
         b0.record()
         torch.cuda.synchronize()
         preroll_passes = max(1, min(400, int(preroll_ms / max(a0.elapsed_time(b0), 1e-3))))
         for _ in range(preroll_passes):
-            env.rollout(T, obs="all", out=obs)
+            pre.rollout(T, obs="all", out=obs)
     for _ in range(args.warmup):
         one_pass()
 

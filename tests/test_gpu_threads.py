@@ -75,6 +75,6 @@ def test_error_strings_are_per_thread():
     t = threading.Thread(target=bad)
     t.start()
     t.join()
-    assert seen["bad"][0] < 0 and b"num_envs" in seen["bad"][1]
-    assert b"num_envs" not in (L.snac_last_error() or b"")         # this thread never failed with that message
+    assert seen["bad"][0] < 0 and b"num_envs must be positive" in seen["bad"][1]
+    assert b"num_envs must be positive" not in (L.snac_last_error() or b"")   # this thread never failed with that message
     env.step(auto_reset=True)                                    # and the env of this thread is still usable
