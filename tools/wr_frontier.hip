@@ -160,6 +160,20 @@ __global__ __launch_bounds__(256) void k_rot(double* out, int N, int T, int rot)
     }
 }
 
+// W  B's stores into a WAVE-MAJOR tensor [N / 64][T][64][51] (not the reference's layout): every wave streams through its own
+//    15.7 MB, a 2 MB page serves 80 of its ticks -- if this is much faster than B, B pays for touching a new page per wave and tick
+__global__ __launch_bounds__(256) void k_wavemajor(double* out, int N, int T) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave * E >= N) return;
+    for (int t = 0; t < T; ++t) {
+        double* base = out + ((size_t)wave * T + t) * E * D;
+#pragma unroll 8
+        for (int e = 0; e < E; ++e)
+            if (lane < D) base[e * D + lane] = (double)(t + lane + e);
+    }
+}
+
 template <typename F>
 float best_of(F launch, int reps = 5) {
     hipEvent_t a, b;
@@ -198,6 +212,10 @@ int main(int argc, char** argv) {
         float f16 = best_of([&] { hipLaunchKernelGGL((k_strided<16>), dim3(blocks), dim3(256), 0, 0, out, N, T); });
         float f32 = best_of([&] { hipLaunchKernelGGL((k_strided<32>), dim3(blocks), dim3(256), 0, 0, out, N, T); });
         float f8 = best_of([&] { hipLaunchKernelGGL((k_strided<8>), dim3(blocks), dim3(256), 0, 0, out, N, T); });
+        {
+            float g = best_of([&] { hipLaunchKernelGGL(k_wavemajor, dim3(blocks), dim3(256), 0, 0, out, N, T); });
+            printf("%-6d W wave-major layout [N/64][T][64][51]: %5.3f (%4.2f)\n", a, g, bytes / g / 1e9);
+        }
         printf("%-6d M rows rotated per wave:", a);
         for (int R : {0, 1, 7, 13, 16, 21, 32}) {
             float g = best_of([&] { hipLaunchKernelGGL(k_rot, dim3(blocks), dim3(256), 0, 0, out, N, T, R); });
