@@ -310,6 +310,20 @@ class BatchedDMPEnv:
         self.t += T
         return o, reward, (done.view(torch.bool) if done is not None else None)
 
+    def alloc_trajectory(self, T, candidates=6, reps=3):
+        """The [T, N, obs_dim] output tensor of rollout(T, out=...), placed where this batch's rollout writes fastest: on MI355X
+        the write rate of a multi-GB tensor depends on which part of HBM it occupies (5-9 % of a pass, snac_amd/placement.py).
+        `candidates` tensors are allocated, a copy of this batch rolls out into each, the fastest is kept.  The batch itself is
+        not stepped.  Returns (tensor, report)."""
+        from . import placement
+
+        if not self._was_reset:
+            raise _lib.SnacError("alloc_trajectory() before reset()")
+        scratch = self.fork(torch.arange(self.num_envs, device=self.device))
+        return placement.fastest_tensor((int(T), self.num_envs, self.obs_dim), self.obs_dtype, self.device,
+                                        lambda t: scratch.rollout(int(T), obs="all", out=t, want_reward=False, want_done=False),
+                                        candidates=candidates, reps=reps)
+
     def set_plan_row(self, index, full_plan, update_tb=False):
         """Replace row `index` of the device plan table by `full_plan` ([30] / [26, 26] as the reference stores it).
         update_tb=False keeps the row's total_brick: the hindsight scripts overwrite env.plan AFTER reset() has

@@ -1,0 +1,42 @@
+"""Where a large streaming output lies in HBM decides how fast it can be written.
+
+On MI355X the write rate of a multi-GB tensor depends on WHICH part of the 288 GB it occupies: inside one 112 GB allocation a
+16 GB window takes the fused rollout's observation rows at 5.75 TB/s at most offsets and at 6.0-6.2 TB/s in a few regions of
+16-24 GB (tools/wr_scan.hip; a wave-major stream shows 5.65 against 7.1 TB/s), and a freshly allocated tensor lands in one kind of
+region or the other -- which is why the same rollout takes 2.70 to 2.97 ms in twelve tensors allocated one after the other,
+each reproducibly.  The address map is not documented, so the choice is made by measurement:
+fastest_tensor() allocates a few candidates, runs the caller's own workload into each and keeps the fastest.  A trajectory buffer is
+allocated once and written millions of times; half a second of probing at start-up buys 5-9 % on every pass.
+"""
+import torch
+
+
+def fastest_tensor(shape, dtype, device, run, candidates=6, reps=3):
+    """Allocate `candidates` tensors of `shape` one after the other (each is held while the next is allocated, so they lie in
+    different places), time `run(tensor)` -- the caller's workload writing into it, enqueued on the current stream -- `reps` times
+    on each, keep the fastest and release the rest.  Returns (tensor, report) with report = {"candidates_ms": [...], "chosen": i}."""
+    held, times = [], []
+    for _ in range(max(1, int(candidates))):
+        try:
+            t = torch.empty(shape, dtype=dtype, device=device)
+        except RuntimeError:                                       # out of memory: choose among what there is
+            break
+        held.append(t)
+        run(t)                                                     # the first touch (page tables, clocks)
+        best = None
+        for _ in range(max(1, int(reps))):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            run(t)
+            b.record()
+            b.synchronize()
+            ms = a.elapsed_time(b)
+            best = ms if best is None else min(best, ms)
+        times.append(best)
+    if not held:
+        raise RuntimeError("no candidate tensor of shape %s could be allocated" % (tuple(shape),))
+    i = min(range(len(times)), key=times.__getitem__)
+    chosen = held[i]
+    del held, t
+    torch.cuda.empty_cache()                                       # the other candidates go back to the driver
+    return chosen, {"candidates_ms": [round(x, 4) for x in times], "chosen": i}

@@ -134,3 +134,24 @@ def test_transition_with_one_index_array_is_bounded_by_the_pool():
                                None if dst is None else C.c_void_p(dst.data_ptr()), 0, C.c_void_p(a.data_ptr()), None, None, None, None, None)
         assert rc == -1 and b"pool" in L.snac_last_error()
     torch.cuda.synchronize()
+
+
+def test_alloc_trajectory_places_the_output_without_stepping_the_batch():
+    """alloc_trajectory(): candidates are timed with a COPY of the batch; the batch's own rollout into the chosen tensor equals a
+    rollout into a plain tensor, tick for tick."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    a = BatchedDMPEnv(2, True, 2048, seed=5)
+    b = BatchedDMPEnv(2, True, 2048, seed=5)
+    a.reset()
+    b.reset()
+    a.rollout(7)
+    b.rollout(7)
+    out, report = a.alloc_trajectory(50, candidates=3, reps=2)
+    assert tuple(out.shape) == (50, 2048, 51) and out.dtype == torch.float64
+    assert len(report["candidates_ms"]) == 3 and 0 <= report["chosen"] < 3 and min(report["candidates_ms"]) > 0
+    oa, ra, da = a.rollout(50, out=out)
+    ob, rb, db = b.rollout(50)
+    assert oa.data_ptr() == out.data_ptr()
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
