@@ -366,6 +366,23 @@ def main():
     per_rank = allreduce_(per_rank).tolist()
     ranks_seen = int(allreduce_(torch.ones(1, dtype=torch.int64, device=dev)).item())
 
+    # the same workload into the tile-major trajectory layout (obs="tiled": [N / 64][T][64][D], SNAC_OBS_TILED) -- reported
+    # beside the headline, never as `value`: 2D only, the same tensor (viewed tile-major), K more passes after the clock stopped
+    tiled = None
+    if args.kind == 2 and n % 64 == 0 and not args.static:
+        tv = obs.view(n // 64, T, 64, env.obs_dim)
+        for _ in range(2):
+            env.rollout(T, obs="tiled", out=tv)
+        tev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a_, b_ in tev:
+            a_.record()
+            env.rollout(T, obs="tiled", out=tv)
+            b_.record()
+        torch.cuda.synchronize()
+        tms = sum(a_.elapsed_time(b_) for a_, b_ in tev) / max(args.steps, 1)
+        tiled = {"layout": "[N/64][T][64][obs_dim] (rollout(obs='tiled'))", "kernel_ms": tms, "value": n * T / (tms * 1e-3), "unit": "env-steps/s per GPU",
+                 "written": WRITTEN_BYTES[(args.kind, "f32" if args.obs_f32 else "f64")] * n * T / (tms * 1e-3) / 1e9}
+
     if rank == 0:
         total_steps = world * n * T * args.steps
         dkey = "f32" if args.obs_f32 else "f64"
@@ -416,6 +433,7 @@ def main():
             "kernel_ms_per_step": [round(x, 4) for x in per_step_ms],   # rank 0's launches, in order
             "preroll_passes": preroll_passes,                     # untimed, before the W warm-up passes (clock ramp)
             "placement": placement_report,                        # rank 0's choice among SNAC_BENCH_PLACE candidate tensors
+            "tiled_layout": tiled,                                # rank 0, informational: the build's own trajectory layout
             "episodic": {"episodes": s[0], "mean_return": (s[1] / s[0]) if s[0] else None,
                          "mean_iou": (s[2] / 2.0 ** 40 / s[0]) if s[0] else None},
         }

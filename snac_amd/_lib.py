@@ -13,7 +13,7 @@ SNAC_OK = 0
 ABI_VERSION = 4
 ENV_1D, ENV_2D, ENV_3D = 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
-OBS_NONE, OBS_ALL, OBS_LAST = 0, 1, 2
+OBS_NONE, OBS_ALL, OBS_LAST, OBS_TILED = 0, 1, 2, 3
 FLAG_NEED_RESET = 1
 RULE_BRICK_GT, RULE_TIME_GT = 1, 2
 SCALARS_DEFAULT, SCALARS_RAW, SCALARS_NORM = 0, 1, 2

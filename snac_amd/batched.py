@@ -267,7 +267,10 @@ class BatchedDMPEnv:
     def rollout(self, T, actions=None, step_size=None, obs="all", out=None, want_reward=True, want_done=True,
                 reward_out=None, done_out=None, record=None):
         """T vector steps with auto-reset in ONE launch (the loop of multiprocess.py:82-84).
-        actions / step_size: int[T, N] or None (counter RNG).  obs: "all" -> [T, N, D], "last" -> [N, D], None.
+        actions / step_size: int[T, N] or None (counter RNG).  obs: "all" -> [T, N, D], "last" -> [N, D], None;
+        "tiled" -> [ceil(N / 64), T, 64, D], every observation in tile-major order (row (t, env) at [env // 64, t, env % 64]):
+        each tile of 64 envs streams through its own region -- the faster layout for trajectories that stay on the GPU
+        (untile() gives the [T, N, D] view of it as a copy).
         out / reward_out / done_out: optional preallocated outputs (done_out uint8).  record: optional dict of
         preallocated [T, N] tensors {"actions": int8, "step_size": int8, "plan_idx": int16, "first": uint8} that receive
         the action taken, the step size used, the plan row in effect and the first-step-of-episode flag of every env-step.
@@ -277,10 +280,11 @@ class BatchedDMPEnv:
         N, T = self.num_envs, int(T)
         a = self._i8(actions, (T, N), "actions")
         k = self._i8(step_size, (T, N), "step_size")
-        mode = {"all": _lib.OBS_ALL, "last": _lib.OBS_LAST, None: _lib.OBS_NONE}[obs]
+        mode = {"all": _lib.OBS_ALL, "last": _lib.OBS_LAST, "tiled": _lib.OBS_TILED, None: _lib.OBS_NONE}[obs]
         o = None
         if mode != _lib.OBS_NONE:
-            shape = (T, N, self.obs_dim) if mode == _lib.OBS_ALL else (N, self.obs_dim)
+            shape = {_lib.OBS_ALL: (T, N, self.obs_dim), _lib.OBS_LAST: (N, self.obs_dim),
+                     _lib.OBS_TILED: ((N + 63) // 64, T, 64, self.obs_dim)}[mode]
             if out is not None:
                 if tuple(out.shape) != shape or out.dtype != self.obs_dtype or out.device != self.device or not out.is_contiguous():
                     raise ValueError("out must be a contiguous %s tensor of shape %s on %s" % (self.obs_dtype, shape, self.device))
@@ -323,6 +327,11 @@ class BatchedDMPEnv:
         return placement.fastest_tensor((int(T), self.num_envs, self.obs_dim), self.obs_dtype, self.device,
                                         lambda t: scratch.rollout(int(T), obs="all", out=t, want_reward=False, want_done=False),
                                         candidates=candidates, reps=reps)
+
+    def untile(self, tiled):
+        """[ceil(N / 64), T, 64, D] (rollout(obs="tiled")) -> a [T, N, D] copy in the reference order."""
+        G, T, E, D = tiled.shape
+        return tiled.permute(1, 0, 2, 3).reshape(T, G * E, D)[:, :self.num_envs]
 
     def set_plan_row(self, index, full_plan, update_tb=False):
         """Replace row `index` of the device plan table by `full_plan` ([30] / [26, 26] as the reference stores it).

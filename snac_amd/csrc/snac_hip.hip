@@ -670,8 +670,10 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
             const double v = K::iou(lds, s, active ? lane : 0);      // idle lanes stay inside the wave's LDS slice
             if (done) { d_eps += 1; d_ret += s.ep_ret; d_iou += __double2ll_rn(v * FX40); }
         }
-        if (a.obs_mode == SNAC_OBS_ALL || (a.obs_mode == SNAC_OBS_LAST && t == a.T - 1)) {
-            const size_t orow = a.obs_mode == SNAC_OBS_ALL ? row : (size_t)env0;
+        if (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED || (a.obs_mode == SNAC_OBS_LAST && t == a.T - 1)) {
+            // SNAC_OBS_TILED: [ceil(N / 64)][T][64][LD] -- the tile's rows of step t follow its rows of step t - 1
+            const size_t orow = a.obs_mode == SNAC_OBS_ALL ? row
+                              : (a.obs_mode == SNAC_OBS_TILED ? ((size_t)(env0 >> 6) * (size_t)a.T + (size_t)t) * 64 + (size_t)(env0 & 63) : (size_t)env0);
             emit_obs<K, OT, VAR>(lds, obs + orow * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
         }
     }
@@ -2204,7 +2206,7 @@ int snac_rollout_rec(const snac_env_desc* d, const snac_state* st, int32_t T, ui
                      const snac_rollout_record* rec, void* stream) {
     if (int rc = check_common(d, st)) return rc;
     if (T < 0) return fail(SNAC_ERR_ARG, "T must be >= 0");
-    if (obs_mode < SNAC_OBS_NONE || obs_mode > SNAC_OBS_LAST) return fail(SNAC_ERR_ARG, "unknown obs_mode");
+    if (obs_mode < SNAC_OBS_NONE || obs_mode > SNAC_OBS_TILED) return fail(SNAC_ERR_ARG, "unknown obs_mode");
     if (obs_mode != SNAC_OBS_NONE && !obs) return fail(SNAC_ERR_ARG, "obs_mode set but obs is null");
     if (T == 0) return SNAC_OK;
     KArgs a = make_args(d, st);

@@ -245,3 +245,31 @@ def test_3d_plan_table_paths(dyn):
             assert np.array_equal(dg.cpu().numpy().astype(np.uint8), dc)
             t0 += T
         _check_state(env, orc)
+
+
+@pytest.mark.parametrize("kind", KINDS, ids=_ids)
+@pytest.mark.parametrize("n", [1, 63, 64, 200, 16400, 65600])
+def test_tiled_trajectory_layout_holds_the_same_rows(kind, n):
+    """rollout(obs="tiled"): [ceil(N / 64), T, 64, D], row (t, env) at [env // 64, t, env % 64] -- the same observations as
+    obs="all", only laid out tile-major (every tile size of the kernels, ragged last tiles, explicit inputs too)."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    dim, dyn = kind
+    if dim == 3 and n > 20000:
+        n = 16400 + 8
+    full = _full(dim, _table(dim, dyn))
+    a = BatchedDMPEnv(dim, dyn, n, plans=full, seed=8)
+    b = BatchedDMPEnv(dim, dyn, n, plans=full, seed=8)
+    a.reset()
+    b.reset()
+    for T, explicit in ((23, False), (9, True)):
+        acts = ks = None
+        if explicit:
+            g = torch.Generator().manual_seed(n)
+            acts = torch.randint(0, helpers.DIMS[dim]["A"], (T, n), generator=g).to(torch.int8)
+            ks = torch.randint(1, 4, (T, n), generator=g).to(torch.int8)
+        oa, ra, da = a.rollout(T, actions=acts, step_size=ks)
+        ot, rt, dt = b.rollout(T, actions=acts, step_size=ks, obs="tiled")
+        assert tuple(ot.shape) == ((n + 63) // 64, T, 64, a.obs_dim)
+        assert torch.equal(b.untile(ot), oa) and torch.equal(ra, rt) and torch.equal(da, dt)
