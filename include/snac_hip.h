@@ -223,6 +223,14 @@ int snac_rollout_rec(const snac_env_desc* desc, const snac_state* st, int32_t T,
                      const int8_t* step_size, int obs_mode, void* obs, float* reward, uint8_t* done,
                      const snac_rollout_record* rec, void* stream);
 
+/* snac_rollout_rec with SNAC_OBS_TILED into a RING of `ring_ticks` steps: obs is [ceil(N / 64)][ring_ticks][64][obs_dim] and this
+ * launch writes the steps first_tick .. first_tick + T - 1 of it (first_tick + T <= ring_ticks; the caller splits a wrap into
+ * two launches).  reward / done / rec stay [T][N] (the caller passes the ring's own slices).  The tile-major replay ring of
+ * snac_amd.ReplayRing(layout="tiled"): a tile of 64 envs streams through its own contiguous region of the ring. */
+int snac_rollout_tiled(const snac_env_desc* desc, const snac_state* st, int32_t T, uint32_t t0, const int8_t* actions,
+                       const int8_t* step_size, int32_t ring_ticks, int32_t first_tick, void* obs, float* reward, uint8_t* done,
+                       const snac_rollout_record* rec, void* stream);
+
 /* Minibatch assembly for the replay memory of the DQN / DRQN scripts (store_memory / learning_process,
  * script/DQN/2d/DQN_2d_dynamic.py:122-124,145-166): the tuples (s, a, r, s', plan) are not stored, they are gathered from
  * the rollout output ring  obs_ring[cap][N][obs_dim] (obs_dtype)  filled by snac_rollout(_rec) with SNAC_OBS_ALL:
@@ -236,6 +244,12 @@ int snac_replay_gather(const snac_env_desc* desc, const snac_state* st, int32_t 
                        const uint8_t* first_ring, const int16_t* plan_idx_ring, const int32_t* tick_idx,
                        const int32_t* env_idx, int32_t batch, float* s_out, float* s_next_out, float* plan_out,
                        void* stream);
+/* the same from a tile-major ring obs_ring[ceil(N / 64)][cap][64][obs_dim] (filled by snac_rollout_tiled); first_ring and
+ * plan_idx_ring stay [cap][N] */
+int snac_replay_gather_tiled(const snac_env_desc* desc, const snac_state* st, int32_t cap, const void* obs_ring,
+                             const uint8_t* first_ring, const int16_t* plan_idx_ring, const int32_t* tick_idx,
+                             const int32_t* env_idx, int32_t batch, float* s_out, float* s_next_out, float* plan_out,
+                             void* stream);
 
 /* ---- plan generators: the hindsight classes of the reference draw a fresh random plan per reset --
  * random triangles in 2D / 3D (create_plan, Env/2D/DMP_Env_2D_dynamic_hindsight_replay_usedata.py:37-59: three vertices from

@@ -22,7 +22,7 @@ TAIL_POSITION, TAIL_PLAN, TAIL_RECORD = 1, 2, 4
 EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_obs_dim", "snac_reset", "snac_reset_scalar", "snac_step",
            "snac_step_scalar", "snac_rollout",
            "snac_rollout_rec", "snac_replay_gather", "snac_make_plans", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
-           "snac_import_state", "snac_obs_equal", "snac_stream_sync")
+           "snac_import_state", "snac_obs_equal", "snac_stream_sync", "snac_rollout_tiled", "snac_replay_gather_tiled")
 
 
 class Sizes(C.Structure):
@@ -88,6 +88,9 @@ def lib():
         L.snac_rollout_rec.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, C.c_uint32, vp, vp, C.c_int, vp, vp, vp,
                                        C.POINTER(RolloutRecord), vp]
         L.snac_replay_gather.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp]
+        L.snac_replay_gather_tiled.argtypes = L.snac_replay_gather.argtypes
+        L.snac_rollout_tiled.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, C.c_uint32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp,
+                                         C.POINTER(RolloutRecord), vp]
         L.snac_make_plans.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int64, vp, vp, vp]
         L.snac_observe.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
         L.snac_iou.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]

@@ -265,12 +265,13 @@ class BatchedDMPEnv:
         return t
 
     def rollout(self, T, actions=None, step_size=None, obs="all", out=None, want_reward=True, want_done=True,
-                reward_out=None, done_out=None, record=None):
+                reward_out=None, done_out=None, record=None, ring=None):
         """T vector steps with auto-reset in ONE launch (the loop of multiprocess.py:82-84).
         actions / step_size: int[T, N] or None (counter RNG).  obs: "all" -> [T, N, D], "last" -> [N, D], None;
         "tiled" -> [ceil(N / 64), T, 64, D], every observation in tile-major order (row (t, env) at [env // 64, t, env % 64]):
         each tile of 64 envs streams through its own region -- the faster layout for trajectories that stay on the GPU
-        (untile() gives the [T, N, D] view of it as a copy).
+        (untile() gives the [T, N, D] view of it as a copy).  ring=(ring_ticks, first_tick) with obs="tiled": `out` is a tile-major
+        RING [ceil(N / 64), ring_ticks, 64, D] and this call writes its steps first_tick .. first_tick + T - 1 (snac_rollout_tiled).
         out / reward_out / done_out: optional preallocated outputs (done_out uint8).  record: optional dict of
         preallocated [T, N] tensors {"actions": int8, "step_size": int8, "plan_idx": int16, "first": uint8} that receive
         the action taken, the step size used, the plan row in effect and the first-step-of-episode flag of every env-step.
@@ -283,8 +284,10 @@ class BatchedDMPEnv:
         mode = {"all": _lib.OBS_ALL, "last": _lib.OBS_LAST, "tiled": _lib.OBS_TILED, None: _lib.OBS_NONE}[obs]
         o = None
         if mode != _lib.OBS_NONE:
+            if ring is not None and (mode != _lib.OBS_TILED or out is None):
+                raise ValueError("ring=(ring_ticks, first_tick) goes with obs='tiled' and a preallocated `out`")
             shape = {_lib.OBS_ALL: (T, N, self.obs_dim), _lib.OBS_LAST: (N, self.obs_dim),
-                     _lib.OBS_TILED: ((N + 63) // 64, T, 64, self.obs_dim)}[mode]
+                     _lib.OBS_TILED: ((N + 63) // 64, T if ring is None else int(ring[0]), 64, self.obs_dim)}[mode]
             if out is not None:
                 if tuple(out.shape) != shape or out.dtype != self.obs_dtype or out.device != self.device or not out.is_contiguous():
                     raise ValueError("out must be a contiguous %s tensor of shape %s on %s" % (self.obs_dtype, shape, self.device))
@@ -308,24 +311,34 @@ class BatchedDMPEnv:
                 ptrs[name] = None if t is None else self._buf(t, (T, N), dt, "record[%r]" % name).data_ptr()
             rec = _lib.RolloutRecord(ptrs["actions"], ptrs["step_size"], ptrs["plan_idx"], ptrs["first"])
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.snac_rollout_rec(C.byref(self._desc), C.byref(self._state), T, self.t & 0xFFFFFFFF, _ptr(a),
-                                                  _ptr(k), mode, _ptr(o), _ptr(reward), _ptr(done),
-                                                  C.byref(rec) if rec is not None else None, self._stream()))
+            if ring is not None:
+                _lib.check(self._lib.snac_rollout_tiled(C.byref(self._desc), C.byref(self._state), T, self.t & 0xFFFFFFFF, _ptr(a),
+                                                        _ptr(k), int(ring[0]), int(ring[1]), _ptr(o), _ptr(reward), _ptr(done),
+                                                        C.byref(rec) if rec is not None else None, self._stream()))
+            else:
+                _lib.check(self._lib.snac_rollout_rec(C.byref(self._desc), C.byref(self._state), T, self.t & 0xFFFFFFFF, _ptr(a),
+                                                      _ptr(k), mode, _ptr(o), _ptr(reward), _ptr(done),
+                                                      C.byref(rec) if rec is not None else None, self._stream()))
         self.t += T
         return o, reward, (done.view(torch.bool) if done is not None else None)
 
-    def alloc_trajectory(self, T, candidates=6, reps=3):
+    def alloc_trajectory(self, T, candidates=6, reps=3, layout="ticks"):
         """The [T, N, obs_dim] output tensor of rollout(T, out=...), placed where this batch's rollout writes fastest: on MI355X
         the write rate of a multi-GB tensor depends on which part of HBM it occupies (5-9 % of a pass, snac_amd/placement.py).
         `candidates` tensors are allocated, a copy of this batch rolls out into each, the fastest is kept.  The batch itself is
-        not stepped.  Returns (tensor, report)."""
+        not stepped.  layout "tiled": the tensor of rollout(obs="tiled").  Returns (tensor, report)."""
         from . import placement
 
         if not self._was_reset:
             raise _lib.SnacError("alloc_trajectory() before reset()")
         scratch = self.fork(torch.arange(self.num_envs, device=self.device))
-        return placement.fastest_tensor((int(T), self.num_envs, self.obs_dim), self.obs_dtype, self.device,
-                                        lambda t: scratch.rollout(int(T), obs="all", out=t, want_reward=False, want_done=False),
+        T = int(T)
+        if layout == "tiled":                                        # [ceil(N / 64), T, 64, D] for rollout(obs="tiled")
+            return placement.fastest_tensor(((self.num_envs + 63) // 64, T, 64, self.obs_dim), self.obs_dtype, self.device,
+                                            lambda t: scratch.rollout(T, obs="tiled", out=t, want_reward=False, want_done=False),
+                                            candidates=candidates, reps=reps)
+        return placement.fastest_tensor((T, self.num_envs, self.obs_dim), self.obs_dtype, self.device,
+                                        lambda t: scratch.rollout(T, obs="all", out=t, want_reward=False, want_done=False),
                                         candidates=candidates, reps=reps)
 
     def untile(self, tiled):

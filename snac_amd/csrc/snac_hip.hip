@@ -55,6 +55,7 @@ __device__ inline uint32_t rng_word(EnvKeys k, uint32_t t) { return mix32(mix32(
 // ------------------------------------------------------------------------------------------------
 struct KArgs {
     int32_t n, num_plans, static_plan, T, auto_reset, obs_mode;
+    int32_t tiled_T, tiled_t0;  // SNAC_OBS_TILED: steps per tile region of the target ([..][tiled_T][64][LD]) and this launch's first step in it
     int32_t total_step;        // the env's time limit (snac_env_desc.total_step or the kind's default)
     int32_t ts_done;           // count_step >= ts_done ends the episode: total_step (+ 1 with SNAC_RULE_TIME_GT)
     int32_t brick_gt;          // 1: count_brick > total_brick ends the episode (SNAC_RULE_BRICK_GT), 0: >=
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
         if (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED || (a.obs_mode == SNAC_OBS_LAST && t == a.T - 1)) {
             // SNAC_OBS_TILED: [ceil(N / 64)][T][64][LD] -- the tile's rows of step t follow its rows of step t - 1
             const size_t orow = a.obs_mode == SNAC_OBS_ALL ? row
-                              : (a.obs_mode == SNAC_OBS_TILED ? ((size_t)(env0 >> 6) * (size_t)a.T + (size_t)t) * 64 + (size_t)(env0 & 63) : (size_t)env0);
+                              : (a.obs_mode == SNAC_OBS_TILED ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)(a.tiled_t0 + t)) * 64 + (size_t)(env0 & 63) : (size_t)env0);
             emit_obs<K, OT, VAR>(lds, obs + orow * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
         }
     }
@@ -1892,6 +1893,7 @@ __global__ __launch_bounds__(256) void k_make_plans(const PArgs g) {
 struct GArgs {
     int32_t n, cap, batch, num_plans;
     int32_t ld, frame_val;     // row length (K::D, + the position tail) and frame value of the ring's layout
+    int32_t tiled;             // obs is [ceil(n / 64)][cap][64][ld] instead of [cap][n][ld]
     const void* obs;
     const uint8_t* first;
     const int16_t* plan_idx;
@@ -1914,8 +1916,11 @@ __global__ __launch_bounds__(256) void k_gather(const GArgs g) {
     const bool first = g.first[cur] != 0;
     const OT* o = (const OT*)g.obs;
     const int LD = g.ld;                                         // D, or D + the position tail (1 / 2 values)
+    const int tp = t == 0 ? g.cap - 1 : t - 1;
+    const size_t ocur = g.tiled ? ((size_t)(i >> 6) * g.cap + t) * 64 + (i & 63) : cur;
+    const size_t oprev = g.tiled ? ((size_t)(i >> 6) * g.cap + tp) * 64 + (i & 63) : prev;
     if (lane < LD) {
-        g.s_next[(size_t)b * LD + lane] = (float)o[cur * LD + lane];
+        g.s_next[(size_t)b * LD + lane] = (float)o[ocur * LD + lane];
         float sv;
         if (first) {   // reset observation: window at the start position over an empty grid, both scalar slots 0
             const int wi = lane / 7, wj = lane - 7 * wi;
@@ -1923,7 +1928,7 @@ __global__ __launch_bounds__(256) void k_gather(const GArgs g) {
             sv = (lane < W && frame) ? (float)g.frame_val : 0.0f;
             if (lane >= D) sv = KIND == 1 ? 2.0f : 3.0f;         // position tail: the start position
         } else {
-            sv = (float)o[prev * LD + lane];
+            sv = (float)o[oprev * LD + lane];
         }
         g.s[(size_t)b * LD + lane] = sv;
     }
@@ -2211,6 +2216,24 @@ int snac_rollout_rec(const snac_env_desc* d, const snac_state* st, int32_t T, ui
     if (T == 0) return SNAC_OK;
     KArgs a = make_args(d, st);
     a.T = T; a.t0 = t0; a.auto_reset = 1; a.obs_mode = obs_mode;
+    a.tiled_T = T; a.tiled_t0 = 0;
+    a.actions = actions; a.step_size = step_size; a.obs = obs; a.reward = reward; a.done = done;
+    if (rec) {
+        a.actions_out = rec->actions; a.step_size_out = rec->step_size; a.plan_idx_out = rec->plan_idx; a.first_out = rec->first;
+    }
+    return launch(OP_ROLLOUT, d, a, stream);
+}
+
+int snac_rollout_tiled(const snac_env_desc* d, const snac_state* st, int32_t T, uint32_t t0, const int8_t* actions,
+                       const int8_t* step_size, int32_t ring_ticks, int32_t first_tick, void* obs, float* reward, uint8_t* done,
+                       const snac_rollout_record* rec, void* stream) {
+    if (int rc = check_common(d, st)) return rc;
+    if (T < 0 || ring_ticks < 1 || first_tick < 0 || (long long)first_tick + T > ring_ticks) return fail(SNAC_ERR_ARG, "steps outside the ring");
+    if (!obs) return fail(SNAC_ERR_ARG, "obs is null");
+    if (T == 0) return SNAC_OK;
+    KArgs a = make_args(d, st);
+    a.T = T; a.t0 = t0; a.auto_reset = 1; a.obs_mode = SNAC_OBS_TILED;
+    a.tiled_T = ring_ticks; a.tiled_t0 = first_tick;
     a.actions = actions; a.step_size = step_size; a.obs = obs; a.reward = reward; a.done = done;
     if (rec) {
         a.actions_out = rec->actions; a.step_size_out = rec->step_size; a.plan_idx_out = rec->plan_idx; a.first_out = rec->first;
@@ -2223,10 +2246,10 @@ int snac_rollout(const snac_env_desc* d, const snac_state* st, int32_t T, uint32
     return snac_rollout_rec(d, st, T, t0, actions, step_size, obs_mode, obs, reward, done, nullptr, stream);
 }
 
-int snac_replay_gather(const snac_env_desc* d, const snac_state* st, int32_t cap, const void* obs_ring,
-                       const uint8_t* first_ring, const int16_t* plan_idx_ring, const int32_t* tick_idx,
-                       const int32_t* env_idx, int32_t batch, float* s_out, float* s_next_out, float* plan_out,
-                       void* stream) {
+static int replay_gather(const snac_env_desc* d, const snac_state* st, int32_t cap, const void* obs_ring,
+                         const uint8_t* first_ring, const int16_t* plan_idx_ring, const int32_t* tick_idx,
+                         const int32_t* env_idx, int32_t batch, float* s_out, float* s_next_out, float* plan_out,
+                         void* stream, int tiled) {
     if (int rc = check_common(d, st)) return rc;
     if (cap < 2 || batch < 0) return fail(SNAC_ERR_ARG, "cap must be >= 2 and batch >= 0");
     if (!obs_ring || !first_ring || !tick_idx || !env_idx || !s_out || !s_next_out) return fail(SNAC_ERR_ARG, "null pointer");
@@ -2235,7 +2258,7 @@ int snac_replay_gather(const snac_env_desc* d, const snac_state* st, int32_t cap
     if (batch == 0) return SNAC_OK;
     GArgs g;
     g.ld = base_obs_dim(d->kind) + tail_len(d->kind, d->obs_tail); g.frame_val = d->frame_value == 2 ? 2 : -1;
-    g.n = d->num_envs; g.cap = cap; g.batch = batch; g.num_plans = d->num_plans;
+    g.n = d->num_envs; g.cap = cap; g.batch = batch; g.num_plans = d->num_plans; g.tiled = tiled;
     g.obs = obs_ring; g.first = first_ring; g.plan_idx = plan_idx_ring; g.tick = tick_idx; g.env = env_idx;
     g.plans = st->plans; g.s = s_out; g.s_next = s_next_out; g.plan_out = plan_out;
     hipStream_t s = (hipStream_t)stream;
@@ -2249,6 +2272,20 @@ int snac_replay_gather(const snac_env_desc* d, const snac_state* st, int32_t cap
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "gather launch");
     return SNAC_OK;
+}
+
+int snac_replay_gather(const snac_env_desc* d, const snac_state* st, int32_t cap, const void* obs_ring,
+                       const uint8_t* first_ring, const int16_t* plan_idx_ring, const int32_t* tick_idx,
+                       const int32_t* env_idx, int32_t batch, float* s_out, float* s_next_out, float* plan_out,
+                       void* stream) {
+    return replay_gather(d, st, cap, obs_ring, first_ring, plan_idx_ring, tick_idx, env_idx, batch, s_out, s_next_out, plan_out, stream, 0);
+}
+
+int snac_replay_gather_tiled(const snac_env_desc* d, const snac_state* st, int32_t cap, const void* obs_ring,
+                             const uint8_t* first_ring, const int16_t* plan_idx_ring, const int32_t* tick_idx,
+                             const int32_t* env_idx, int32_t batch, float* s_out, float* s_next_out, float* plan_out,
+                             void* stream) {
+    return replay_gather(d, st, cap, obs_ring, first_ring, plan_idx_ring, tick_idx, env_idx, batch, s_out, s_next_out, plan_out, stream, 1);
 }
 
 int snac_step(const snac_env_desc* d, const snac_state* st, uint32_t t, const int8_t* actions, const int8_t* step_size,

@@ -22,14 +22,25 @@ def _ptr(t):
 
 
 class ReplayRing:
-    def __init__(self, env, capacity_ticks):
-        """env: BatchedDMPEnv (already reset); capacity_ticks: ring length in vector steps (>= 2)."""
+    def __init__(self, env, capacity_ticks, layout="ticks", place_candidates=0):
+        """env: BatchedDMPEnv (already reset); capacity_ticks: ring length in vector steps (>= 2).
+        layout "ticks": obs[cap, N, D]; "tiled": obs[ceil(N / 64), cap, 64, D] -- a tile of 64 envs streams through its own
+        contiguous region of the ring (SNAC_OBS_TILED: the faster layout to collect into); row(slot, env) and
+        obs_at(slot) read either.  place_candidates > 1: the observation ring is placed by env.alloc_trajectory (that many
+        candidate tensors timed with the rollout itself, the fastest kept: where a multi-GB ring lies in HBM is worth 5-25 %)."""
         if capacity_ticks < 2:
             raise ValueError("capacity_ticks must be >= 2")
+        if layout not in ("ticks", "tiled"):
+            raise ValueError("layout must be 'ticks' or 'tiled'")
         self.env = env
         self.cap = int(capacity_ticks)
+        self.tiled = layout == "tiled"
         N, D, dev = env.num_envs, env.obs_dim, env.device
-        self.obs = torch.empty((self.cap, N, D), dtype=env.obs_dtype, device=dev)
+        self.placement = None
+        if place_candidates and place_candidates > 1:
+            self.obs, self.placement = env.alloc_trajectory(self.cap, candidates=int(place_candidates), layout=layout)
+        else:
+            self.obs = torch.empty(((N + 63) // 64, self.cap, 64, D) if self.tiled else (self.cap, N, D), dtype=env.obs_dtype, device=dev)
         self.reward = torch.zeros((self.cap, N), dtype=torch.float32, device=dev)
         self.done = torch.zeros((self.cap, N), dtype=torch.uint8, device=dev)
         self.action = torch.zeros((self.cap, N), dtype=torch.int8, device=dev)
@@ -41,8 +52,34 @@ class ReplayRing:
         self.plan_cells = 30 if env.kind == 1 else 400
         # the predecessor of slot 0 is slot cap - 1: seed it with the envs' CURRENT observation, so that the very first
         # transitions have their `s` also when the ring is attached to envs in mid-episode (first[0, i] == 0)
-        self.obs[self.cap - 1].copy_(env.observe())
+        self._put(self.cap - 1, env.observe())
         self._env_t = env.t    # the env may only advance through the ring: s' / s are paired by slot
+
+    def _put(self, slot, rows):
+        """rows [N, D] -> the ring's slot (either layout)"""
+        if not self.tiled:
+            self.obs[slot].copy_(rows)
+            return
+        N, D = rows.shape
+        G = self.obs.shape[0]
+        if N != G * 64:                                            # ragged last tile: pad (the padding rows are never read)
+            rows = torch.cat([rows, rows.new_zeros((G * 64 - N, D))])
+        self.obs[:, slot].copy_(rows.view(G, 64, D))
+
+    def obs_at(self, slot):
+        """The observations of one ring slot as [N, D] (a view for layout "ticks", a copy for "tiled")."""
+        if not self.tiled:
+            return self.obs[slot]
+        G, _, E, D = self.obs.shape
+        return self.obs[:, slot].reshape(G * E, D)[:self.env.num_envs]
+
+    def row(self, slot, env_index):
+        """obs rows of (slot, env) pairs -> [B, D] in the ring's dtype (either layout)."""
+        slot = torch.as_tensor(slot, device=self.env.device).long()
+        env_index = torch.as_tensor(env_index, device=self.env.device).long()
+        if not self.tiled:
+            return self.obs[slot, env_index]
+        return self.obs[env_index >> 6, slot, env_index & 63]
 
     def __len__(self):
         """Number of addressable transitions."""
@@ -67,9 +104,13 @@ class ReplayRing:
             sl = slice(self.head, self.head + n)
             a = None if actions is None else actions[done_ticks:done_ticks + n]
             k = None if step_size is None else step_size[done_ticks:done_ticks + n]
-            self.env.rollout(n, actions=a, step_size=k, obs="all", out=self.obs[sl], reward_out=self.reward[sl], done_out=self.done[sl],
-                             record=dict(actions=self.action[sl], step_size=self.step_size[sl], plan_idx=self.plan_idx[sl],
-                                         first=self.first[sl]))
+            rec = dict(actions=self.action[sl], step_size=self.step_size[sl], plan_idx=self.plan_idx[sl], first=self.first[sl])
+            if self.tiled:
+                self.env.rollout(n, actions=a, step_size=k, obs="tiled", out=self.obs, ring=(self.cap, self.head),
+                                 reward_out=self.reward[sl], done_out=self.done[sl], record=rec)
+            else:
+                self.env.rollout(n, actions=a, step_size=k, obs="all", out=self.obs[sl], reward_out=self.reward[sl],
+                                 done_out=self.done[sl], record=rec)
             self.head = (self.head + n) % self.cap
             self.ticks += n
             done_ticks += n
@@ -97,9 +138,9 @@ class ReplayRing:
         s_next = torch.empty_like(s)
         plan = torch.empty((B, self.plan_cells), dtype=torch.float32, device=e.device) if with_plan else None
         with torch.cuda.device(e.device):
-            _lib.check(e._lib.snac_replay_gather(C.byref(e._desc), C.byref(e._state), self.cap, _ptr(self.obs), _ptr(self.first),
-                                                 _ptr(self.plan_idx), _ptr(slot), _ptr(env_index), B, _ptr(s), _ptr(s_next),
-                                                 _ptr(plan), e._stream()))
+            fn = e._lib.snac_replay_gather_tiled if self.tiled else e._lib.snac_replay_gather
+            _lib.check(fn(C.byref(e._desc), C.byref(e._state), self.cap, _ptr(self.obs), _ptr(self.first),
+                          _ptr(self.plan_idx), _ptr(slot), _ptr(env_index), B, _ptr(s), _ptr(s_next), _ptr(plan), e._stream()))
         sl, ei = slot.long(), env_index.long()
         out = dict(s=s, s_next=s_next, action=self.action[sl, ei].long(), reward=self.reward[sl, ei], done=self.done[sl, ei].bool())
         if with_plan:

@@ -33,5 +33,5 @@ def test_ring_append_matches_a_plain_step():
         ring.append(acts)
         o, r, d = b.step(acts, auto_reset=True)
         slot = (ring.head - 1) % ring.cap
-        assert torch.equal(ring.obs[slot], o) and torch.equal(ring.reward[slot], r) and torch.equal(ring.done[slot].bool(), d)
+        assert torch.equal(ring.obs_at(slot), o) and torch.equal(ring.reward[slot], r) and torch.equal(ring.done[slot].bool(), d)
         assert torch.equal(ring.action[slot], acts)

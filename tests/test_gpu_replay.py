@@ -30,7 +30,8 @@ def _reference_style_memory(dim, dyn, n, T, seed, table):
 
 @pytest.mark.parametrize("kind", [(1, True), (2, False), (2, True), (3, True)], ids=str)
 @pytest.mark.parametrize("f32", [False, True], ids=["f64ring", "f32ring"])
-def test_ring_holds_the_reference_replay_tuples(kind, f32):
+@pytest.mark.parametrize("layout", ["ticks", "tiled"])
+def test_ring_holds_the_reference_replay_tuples(kind, f32, layout):
     import torch
     from snac_amd import BatchedDMPEnv, ReplayRing
 
@@ -41,7 +42,7 @@ def test_ring_holds_the_reference_replay_tuples(kind, f32):
     full = table.reshape(len(table), 30) if dim == 1 else table.reshape(len(table), 26, 26)
     env = BatchedDMPEnv(dim, dyn, n, plans=full, seed=seed, obs_dtype=torch.float32 if f32 else torch.float64)
     env.reset()
-    ring = ReplayRing(env, capacity_ticks=128)
+    ring = ReplayRing(env, capacity_ticks=128, layout=layout)
     ring.collect(40)
     ring.collect(T - 40)
     assert ring.valid_ticks() == T and len(ring) == T * n
@@ -63,7 +64,8 @@ def test_ring_holds_the_reference_replay_tuples(kind, f32):
     assert np.array_equal(got["done"].cpu().numpy().reshape(T, n).astype(np.uint8), np.stack([m["done"] for m in mem]))
 
 
-def test_ring_wraps_and_samples():
+@pytest.mark.parametrize("layout", ["ticks", "tiled"])
+def test_ring_wraps_and_samples(layout):
     import torch
     from snac_amd import BatchedDMPEnv, ReplayRing
 
@@ -71,7 +73,7 @@ def test_ring_wraps_and_samples():
     table = helpers.plan_table(2, True, "dense_train")
     env = BatchedDMPEnv(2, True, n, plans=table.reshape(-1, 26, 26), seed=seed)
     env.reset()
-    ring = ReplayRing(env, cap)
+    ring = ReplayRing(env, cap, layout=layout)
     for _ in range(5):
         ring.collect(20)                                              # 100 ticks through a 32-slot ring
     T = 100
@@ -173,7 +175,40 @@ def test_ring_attached_in_mid_episode_and_guard_against_outside_steps():
     assert int(ring.first[0].sum()) < 64                         # most envs did not start an episode at slot 0
     b = ring.gather(torch.zeros(64, dtype=torch.int32), torch.arange(64, dtype=torch.int32), with_plan=False)
     cont = ring.first[0] == 0
-    assert torch.equal(b["s"][cont], before[cont].float()) and torch.equal(b["s_next"], ring.obs[0].float())
+    assert torch.equal(b["s"][cont], before[cont].float()) and torch.equal(b["s_next"], ring.obs_at(0).float())
     env.step(auto_reset=True)                                    # behind the ring's back
     with pytest.raises(SnacError, match="outside the ring"):
         ring.collect(1)
+
+
+@pytest.mark.parametrize("n", [5, 64, 200, 4100])
+def test_tiled_ring_equals_the_tick_ring(n):
+    """The same collection into both ring layouts (ragged batches, ring wraps, mid-episode attach): every row, every sampled
+    minibatch and every DRQN window identical."""
+    import torch
+    from snac_amd import BatchedDMPEnv, ReplayRing
+
+    envs = [BatchedDMPEnv(2, True, n, seed=12, total_step=40) for _ in range(2)]
+    rings = []
+    for e, layout in zip(envs, ("ticks", "tiled")):
+        e.reset()
+        e.rollout(13, obs=None)                                       # attach in mid-episode
+        rings.append(ReplayRing(e, 48, layout=layout, place_candidates=3 if layout == "tiled" else 0))
+    for T in (20, 30, 48, 7):
+        for r in rings:
+            r.collect(T)
+    a, b = rings
+    assert tuple(b.obs.shape) == ((n + 63) // 64, 48, 64, 51)
+    for slot in range(48):
+        assert torch.equal(a.obs_at(slot), b.obs_at(slot))
+    for name in ("reward", "done", "action", "step_size", "plan_idx", "first"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    slots = torch.randint(0, 48, (500,), device="cuda")
+    idx = torch.randint(0, n, (500,), device="cuda")
+    assert torch.equal(a.row(slots, idx), b.row(slots, idx))
+    ga, gb = torch.Generator(device="cuda"), torch.Generator(device="cuda")
+    ga.manual_seed(3); gb.manual_seed(3)
+    sa, sb = a.sample(300, generator=ga), b.sample(300, generator=gb)
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    qa, qb = a.sample_sequences(40, 6, generator=ga), b.sample_sequences(40, 6, generator=gb)
+    assert all(torch.equal(qa[k], qb[k]) for k in qa)
