@@ -369,7 +369,7 @@ def main():
     # the same workload into the tile-major trajectory layout (obs="tiled": [N / 64][T][64][D], SNAC_OBS_TILED) -- reported
     # beside the headline, never as `value`: 2D only, the same tensor (viewed tile-major), K more passes after the clock stopped
     tiled = None
-    if args.kind == 2 and n % 64 == 0 and not args.static:
+    if args.kind == 2 and n % 64 == 0 and not args.static and os.environ.get("SNAC_BENCH_TILED", "1") != "0":
         tv = obs.view(n // 64, T, 64, env.obs_dim)
         for _ in range(2):
             env.rollout(T, obs="tiled", out=tv)

@@ -5,6 +5,9 @@
 # Outputs land in gpurun_out/prof_<tag>/ ; summaries are copied to profiles/ by hand.  Every pass runs under `timeout`
 # (a counter pass that aborts would otherwise sit until gpurun's own limit).  SQ / FETCH / WRITE counters only: TA_* and
 # TCC_* passes abort rocprofv3 on this pool.
+# SNAC_BENCH_TILED=0: bench.py's extra passes into the tile-major layout use the same kernel symbol and would mix their (shorter)
+# launches into the per-kernel average; the profiled launches are the headline's own (candidates, pre-roll, warm-up, timed).
+export SNAC_BENCH_TILED=0
 TAG=${1:-r1}
 shift
 ARGS="$@"
