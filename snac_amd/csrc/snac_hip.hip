@@ -967,8 +967,12 @@ struct Roll3D {
         sk = env_keys(a.key_step, (uint64_t)(a.env_id_base + env0 + (lane & 7)));   // every lane hashes for env (lane & 7)
         new_tb();
         dT = (double)a.total_step; rT = 1.0 / dT;
-        OT* const obs = (OT*)a.obs + (size_t)env0 * K::D + lane;      // this lane's slot of the tile's row 0 at step 0
-        const size_t tstride = (size_t)a.n * K::D;
+        // this lane's slot of the tile's row 0 at step 0, and the distance to the same slot one step later: [T][N][D], or tile-major
+        // [ceil(N / 64)][tiled_T][64][D] (SNAC_OBS_TILED: the 8 waves of a 64-env block share one tile region)
+        const bool tl = a.obs_mode == SNAC_OBS_TILED;
+        OT* const obs = (OT*)a.obs + (tl ? (((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)a.tiled_t0) * 64 + (size_t)(env0 & 63)) * K::D
+                                         : (size_t)env0 * K::D) + lane;
+        const size_t tstride = tl ? (size_t)64 * K::D : (size_t)a.n * K::D;
         if constexpr (EXPL) { issue_inputs(0); commit_inputs(0); issue_inputs(1); }
         tick<false>(0, nullptr);
         for (int t = 1; t < a.T; ++t) tick<true>(t, obs + (size_t)(t - 1) * tstride);
@@ -1101,8 +1105,10 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1d(const KArgs a) {
     Open o[2];
     o[0] = Open{0, 0, 0, 0.0, 0, false, false, false, false, 0, 1, 0};
     o[1] = o[0];
-    OT* const obs = (OT*)a.obs + (size_t)env0 * K::D + lane;
-    const size_t tstride = (size_t)a.n * K::D;
+    const bool tl = a.obs_mode == SNAC_OBS_TILED;                    // [T][N][D], or tile-major [ceil(N / 64)][tiled_T][64][D]
+    OT* const obs = (OT*)a.obs + (tl ? (((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)a.tiled_t0) * 64 + (size_t)(env0 & 63)) * K::D
+                                     : (size_t)env0 * K::D) + lane;
+    const size_t tstride = tl ? (size_t)64 * K::D : (size_t)a.n * K::D;
     int* const hrow = H + e * 34;
     const int* const prow = PL + e * 32;
 
@@ -2125,13 +2131,13 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
         case SNAC_ENV_1D:
             // up to two waves per SIMD (N <= 16 384) a 1D pass is bound by its dependency chain: the chain-shaped kernel; beyond,
             // by instruction issue: the tile kernel (lane-per-env transition) needs fewer instructions per env-step
-            if (op == OP_ROLLOUT && a.n <= 16384 && !a.variant && a.obs_mode == SNAC_OBS_ALL && !a.actions && !a.step_size && !pipeline_off()) { launch_roll1d(d, a, s); break; }
+            if (op == OP_ROLLOUT && a.n <= 16384 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && !a.actions && !a.step_size && !pipeline_off()) { launch_roll1d(d, a, s); break; }
             launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D:
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans2d(d, a, s); break; }
             launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
-            if (op == OP_ROLLOUT && E == 8 && !a.variant && a.obs_mode == SNAC_OBS_ALL && a.num_plans <= TB_MAX && !pipeline_off()) { launch_roll3d(d, a, s); break; }
+            if (op == OP_ROLLOUT && E == 8 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && !pipeline_off()) { launch_roll3d(d, a, s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans3d(d, a, s); break; }
             if (E == 8 && a.n < 8192) dyn ? launch_dt<K3D, true, 8, 1>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 1>(op, d->obs_dtype, a, s);
             else if (E == 8) dyn ? launch_dt<K3D, true, 8, 4>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 4>(op, d->obs_dtype, a, s);
