@@ -367,11 +367,18 @@ def main():
     ranks_seen = int(allreduce_(torch.ones(1, dtype=torch.int64, device=dev)).item())
 
     # the same workload into the tile-major trajectory layout (obs="tiled": [N / 64][T][64][D], SNAC_OBS_TILED) -- reported
-    # beside the headline, never as `value`: 2D only, the same tensor (viewed tile-major), K more passes after the clock stopped
+    # beside the headline, never as `value`: 2D only, after the clock stopped; its tensor is placed like the headline's (the
+    # tile-major stream is the one that really profits from a fast region: 5.65 against 7.1 TB/s store-only)
     tiled = None
     if args.kind == 2 and n % 64 == 0 and not args.static and os.environ.get("SNAC_BENCH_TILED", "1") != "0":
-        tv = obs.view(n // 64, T, 64, env.obs_dim)
-        for _ in range(2):
+        del obs
+        torch.cuda.empty_cache()
+        tshape = (n // 64, T, 64, env.obs_dim)
+        if place_n > 1:
+            tv, trep = placement.fastest_tensor(tshape, env.obs_dtype, dev, lambda t: env.rollout(T, obs="tiled", out=t), candidates=place_n)
+        else:
+            tv, trep = torch.empty(tshape, dtype=env.obs_dtype, device=dev), None
+        for _ in range(12):
             env.rollout(T, obs="tiled", out=tv)
         tev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         for a_, b_ in tev:
@@ -381,7 +388,7 @@ def main():
         torch.cuda.synchronize()
         tms = sum(a_.elapsed_time(b_) for a_, b_ in tev) / max(args.steps, 1)
         tiled = {"layout": "[N/64][T][64][obs_dim] (rollout(obs='tiled'))", "kernel_ms": tms, "value": n * T / (tms * 1e-3), "unit": "env-steps/s per GPU",
-                 "written": WRITTEN_BYTES[(args.kind, "f32" if args.obs_f32 else "f64")] * n * T / (tms * 1e-3) / 1e9}
+                 "written": WRITTEN_BYTES[(args.kind, "f32" if args.obs_f32 else "f64")] * n * T / (tms * 1e-3) / 1e9, "placement": trep}
 
     if rank == 0:
         total_steps = world * n * T * args.steps
