@@ -79,7 +79,12 @@ def trial(rng, idx):
                 bias = rng.random()
                 a = np.where(rng.random((T, n)) < bias, A - 1, rng.integers(0, A, size=(T, n))).astype(np.int8)
                 k = rng.integers(1, 4, size=(T, n)).astype(np.int8)
-            og, rg, dg = env.rollout(T, actions=None if a is None else torch.from_numpy(a), step_size=None if k is None else torch.from_numpy(k))
+            tiled = rng.random() < 0.3                                # the tile-major trajectory layout holds the same rows
+            og, rg, dg = env.rollout(T, actions=None if a is None else torch.from_numpy(a), step_size=None if k is None else torch.from_numpy(k),
+                                     obs="tiled" if tiled else "all")
+            if tiled:
+                og = env.untile(og)
+                ops[-1] += "/tiled"
             oc, rc, dc = orc.rollout(T, t0=t, actions=a, step_size=k, nthreads=16)
             same(og.cpu().numpy(), cast(oc), "rollout obs", ctx)
             same(rg.cpu().numpy(), rc, "rollout reward", ctx)
