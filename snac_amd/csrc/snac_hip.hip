@@ -11,6 +11,11 @@
 // Round-1's first kernel ran one env per wave with the env scalars in SGPRs: it was bound by the CU's
 // single scalar ALU (67 SALU instructions per env-step, profiles/r01_a_*) and by the store shape.
 // Integer / indexing work only -- no MFMA; the bound is HBM (observation writes).
+// Besides the tile kernels (k_rollout, k_transition, k_aux) four kernels are shaped round what bounds their case, each with the
+// tile kernel behind it for everything else: k_rollout3d (3D rollouts: one late vmcnt wait per step, reward / done in whole runs),
+// k_rollout1d (1D rollouts up to two waves per SIMD: lane = (env, observation element), control chain independent of the heights),
+// k_transition2d / k_transition3d (single steps and tree edges without LDS images).  Rollout outputs are [T][N][D] or, with
+// SNAC_OBS_TILED, tile-major [N / 64][T][64][D] (a tile streams through its own region: 6.9 instead of 6.0 TB/s of writes).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
