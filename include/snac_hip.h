@@ -15,7 +15,9 @@
  * Conventions
  *   - Plain C types only.  Every pointer inside snac_state and every array argument is a DEVICE pointer
  *     owned by the caller (e.g. torch tensors); the library allocates nothing and keeps no global state
- *     except a thread-local error string.
+ *     except a thread-local error string.  Input and output ARRAYS (actions, step sizes, obs, reward, done) may also lie in
+ *     page-locked host memory, which is mapped into the device's address space: the kernels then read / write them over the
+ *     bus themselves and a host-side caller only waits (snac_stream_sync) -- no copy command.
  *   - All work is enqueued on the caller's hipStream_t (`stream`, passed as void*; NULL = default
  *     stream), asynchronously, without host synchronisation.
  *   - Return value: SNAC_OK or a negative snac_status; snac_last_error() describes the last failure on
