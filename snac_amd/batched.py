@@ -268,7 +268,8 @@ class BatchedDMPEnv:
                 reward_out=None, done_out=None, record=None, ring=None):
         """T vector steps with auto-reset in ONE launch (the loop of multiprocess.py:82-84).
         actions / step_size: int[T, N] or None (counter RNG).  obs: "all" -> [T, N, D], "last" -> [N, D], None;
-        "tiled" -> [ceil(N / 64), T, 64, D], every observation in tile-major order (row (t, env) at [env // 64, t, env % 64]):
+        "tiled" -> [ceil(N / 64), T, 64, D], every observation in tile-major order (row (t, env) at [env // 64, t, env % 64];
+        out[g] is the contiguous, reference-shaped [T, 64, D] trajectory of env group g):
         each tile of 64 envs streams through its own region -- the faster layout for trajectories that stay on the GPU
         (untile() gives the [T, N, D] view of it as a copy).  ring=(ring_ticks, first_tick) with obs="tiled": `out` is a tile-major
         RING [ceil(N / 64), ring_ticks, 64, D] and this call writes its steps first_tick .. first_tick + T - 1 (snac_rollout_tiled).
