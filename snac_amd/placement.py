@@ -11,10 +11,16 @@ allocated once and written millions of times; half a second of probing at start-
 import torch
 
 
-def fastest_tensor(shape, dtype, device, run, candidates=6, reps=3):
+def fastest_tensor(shape, dtype, device, run, candidates=6, reps=3, min_bytes=1 << 28):
     """Allocate `candidates` tensors of `shape` one after the other (each is held while the next is allocated, so they lie in
     different places), time `run(tensor)` -- the caller's workload writing into it, enqueued on the current stream -- `reps` times
-    on each, keep the fastest and release the rest.  Returns (tensor, report) with report = {"candidates_ms": [...], "chosen": i}."""
+    on each, keep the fastest and release the rest.  Returns (tensor, report) with report = {"candidates_ms": [...], "chosen": i}.
+    Tensors below `min_bytes` (256 MB) are not probed: the regions are GBs wide, a small tensor is not bound by its place."""
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    if numel * torch.empty((), dtype=dtype).element_size() < min_bytes:
+        return torch.empty(shape, dtype=dtype, device=device), {"candidates_ms": [], "chosen": 0}
     held, times = [], []
     for _ in range(max(1, int(candidates))):
         try:

@@ -148,8 +148,12 @@ def test_alloc_trajectory_places_the_output_without_stepping_the_batch():
     b.reset()
     a.rollout(7)
     b.rollout(7)
-    out, report = a.alloc_trajectory(50, candidates=3, reps=2)
-    assert tuple(out.shape) == (50, 2048, 51) and out.dtype == torch.float64
+    out, report = a.alloc_trajectory(50, candidates=3, reps=2)               # 42 MB: below the probing threshold
+    assert tuple(out.shape) == (50, 2048, 51) and out.dtype == torch.float64 and report["candidates_ms"] == []
+    from snac_amd import placement
+    scratch = a.fork(torch.arange(2048, device="cuda"))
+    out, report = placement.fastest_tensor((50, 2048, 51), torch.float64, a.device, lambda t: scratch.rollout(50, obs="all", out=t),
+                                           candidates=3, reps=2, min_bytes=0)
     assert len(report["candidates_ms"]) == 3 and 0 <= report["chosen"] < 3 and min(report["candidates_ms"]) > 0
     oa, ra, da = a.rollout(50, out=out)
     ob, rb, db = b.rollout(50)
