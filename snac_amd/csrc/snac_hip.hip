@@ -1424,36 +1424,60 @@ __global__ __launch_bounds__(WPB * 64) void k_transition3d(const KArgs a) {
     const uint4* const g4 = (const uint4*)a.grid;
     uint4* const g4w = (uint4*)a.grid;
     OT* const orow = a.obs ? (OT*)a.obs + (size_t)edge0 * K::D + lane : nullptr;
-    for (int e = 0; e < nedge; ++e) {                                // wave-uniform: readlane broadcasts edge e's scalars
-        const int se = __builtin_amdgcn_readlane(srow, e), de = __builtin_amdgcn_readlane(drow, e);
-        const int tp = __builtin_amdgcn_readlane(tpatch, e), nh = __builtin_amdgcn_readlane(newh, e);
-        const bool fresh = __builtin_amdgcn_readlane((int)nr, e) != 0;
-        // the 7x7 window around the NEW position, read from the source record before the record is overwritten in place
-        int wv_cell = -1;
-        double scal = 0.0;
-        if (orow) {
-            const int R = __builtin_amdgcn_readlane(key_r, e) - 3 + wi, C = __builtin_amdgcn_readlane(key_c, e) - 3 + wj;
-            const bool in = (unsigned)(R - 3) < 20u && (unsigned)(C - 3) < 20u;
-            const int idx = in ? (R - 3) * 20 + (C - 3) : 0;
-            const int v = (in && !fresh && lane < K::W) ? (int)g16[(size_t)se * K::GE + idx] : 0;
-            wv_cell = in ? (idx == tp ? nh : v) : -1;
-            scal = sc_all[wv][e][lane >= K::W ? min(lane - K::W, 1) : 0];
-        }
-        if (lane < 50) {
-            uint4 v = fresh ? make_uint4(0u, 0u, 0u, 0u) : g4[(size_t)se * 50 + lane];
-            if (tp >= 0 && (tp >> 3) == lane) {                      // this lane's 8 cells hold the built one
-                const int hw = tp & 7, sh = (hw & 1) * 16;
-                const uint32_t keep = ~(0xFFFFu << sh), put = ((uint32_t)nh & 0xFFFFu) << sh;
-                uint32_t* pv = &v.x;
-                if ((hw >> 1) == 0) v.x = (v.x & keep) | put;
-                else if ((hw >> 1) == 1) v.y = (v.y & keep) | put;
-                else if ((hw >> 1) == 2) v.z = (v.z & keep) | put;
-                else v.w = (v.w & keep) | put;
-                (void)pv;
+    // U edges at a time: every load of the group (record lanes and window cells, both from the SOURCE records) is issued before
+    // the group's first store, so U records are in flight per wave instead of one -- the loop used to be a load -> store ->
+    // load chain, the compiler may not move a load over a store into the same array.  Legal by the contract of
+    // snac_transition (include/snac_hip.h): a destination row is never the source row of a different edge of the call.
+    constexpr int U = 8;
+    for (int e0 = 0; e0 < nedge; e0 += U) {                          // wave-uniform: readlane broadcasts an edge's scalars
+        uint4 rec[U];
+        int wcell[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = min(e0 + u, nedge - 1);                    // a short last group reloads its last edge (not stored)
+            const int se = __builtin_amdgcn_readlane(srow, e);
+            const int tp = __builtin_amdgcn_readlane(tpatch, e), nh = __builtin_amdgcn_readlane(newh, e);
+            const bool fresh = __builtin_amdgcn_readlane((int)nr, e) != 0;
+            // the 7x7 window around the NEW position, from the source record with the built cell patched in
+            wcell[u] = -1;
+            if (orow) {
+                const int R = __builtin_amdgcn_readlane(key_r, e) - 3 + wi, C = __builtin_amdgcn_readlane(key_c, e) - 3 + wj;
+                const bool in = (unsigned)(R - 3) < 20u && (unsigned)(C - 3) < 20u;
+                const int idx = in ? (R - 3) * 20 + (C - 3) : 0;
+                const int v = (in && !fresh && lane < K::W) ? (int)g16[(size_t)se * K::GE + idx] : 0;
+                wcell[u] = in ? (idx == tp ? nh : v) : -1;
             }
-            g4w[(size_t)de * 50 + lane] = v;
+            // a step in place (snac_step, or a tree edge onto its own row) changes ONE cell: no record copy
+            const bool copy = fresh || se != __builtin_amdgcn_readlane(drow, e);
+            rec[u] = (fresh || lane >= 50 || !copy) ? make_uint4(0u, 0u, 0u, 0u) : g4[(size_t)se * 50 + lane];
         }
-        if (orow && lane < K::D) orow[(size_t)e * K::D] = (OT)(lane < K::W ? (double)wv_cell : scal);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u;
+            if (e < nedge) {
+                const int de = __builtin_amdgcn_readlane(drow, e);
+                const int tp = __builtin_amdgcn_readlane(tpatch, e), nh = __builtin_amdgcn_readlane(newh, e);
+                const bool copy = __builtin_amdgcn_readlane((int)nr, e) != 0 || de != __builtin_amdgcn_readlane(srow, e);
+                if (!copy) {
+                    if (tp >= 0 && lane == 0) ((int16_t*)a.grid)[(size_t)de * K::GE + tp] = (int16_t)nh;
+                } else if (lane < 50) {
+                    uint4 v = rec[u];
+                    if (tp >= 0 && (tp >> 3) == lane) {              // this lane's 8 cells hold the built one
+                        const int hw = tp & 7, sh = (hw & 1) * 16;
+                        const uint32_t keep = ~(0xFFFFu << sh), put = ((uint32_t)nh & 0xFFFFu) << sh;
+                        if ((hw >> 1) == 0) v.x = (v.x & keep) | put;
+                        else if ((hw >> 1) == 1) v.y = (v.y & keep) | put;
+                        else if ((hw >> 1) == 2) v.z = (v.z & keep) | put;
+                        else v.w = (v.w & keep) | put;
+                    }
+                    g4w[(size_t)de * 50 + lane] = v;
+                }
+                if (orow && lane < K::D) {
+                    const double scal = sc_all[wv][e][lane >= K::W ? min(lane - K::W, 1) : 0];
+                    orow[(size_t)e * K::D] = (OT)(lane < K::W ? (double)wcell[u] : scal);
+                }
+            }
+        }
     }
     if (active) { a.hdr[drow] = s.pack(); a.episode[drow] = episode; }
 }

@@ -174,6 +174,9 @@ def extras():
         per = 2 * (16 + 4 + rec) + env_obs_bytes(kind) + 5       # read + write one state record, write obs + reward + done
         print("transition %dD dynamic: %d edges (random parents x all actions, pool 2^20)  %8.3f ms  %.3e edges/s  alg %.0f GB/s"
               % (kind, m, ms, m / ms * 1e3, per * m / ms / 1e6))
+    for n in (65536, 524288):
+        ms = step_time(3, True, n)
+        print("step() 3D dynamic N=%-7d counter RNG   %8.4f ms/tick  %.3e env-steps/s" % (n, ms, n / ms * 1e3))
     for n in (1, 4096, 65536):
         print("step() as hipGraph replay 2D dynamic N=%-7d explicit a,k  %8.4f ms/tick" % (n, graph_step_time(n)))
     ms, gbs = gather_time()
