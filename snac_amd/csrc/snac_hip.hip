@@ -1327,7 +1327,7 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
 //                 lanes 49 / 50 take the scalar slots: one 408-byte row store.
 // Four wide memory instructions per edge instead of ~25 narrow ones.  Semantics are K3D::step's (tests compare with the CPU
 // restatement exactly as for k_transition); layout variants stay on the generic kernel.
-template <bool DYN, typename OT, int WPB>
+template <bool DYN, typename OT, int WPB, bool INPLACE>
 __global__ __launch_bounds__(WPB * 64) void k_transition3d(const KArgs a) {
     using K = K3D<DYN, 8>;
     constexpr int E = 32;
@@ -1428,9 +1428,12 @@ __global__ __launch_bounds__(WPB * 64) void k_transition3d(const KArgs a) {
     // the group's first store, so U records are in flight per wave instead of one -- the loop used to be a load -> store ->
     // load chain, the compiler may not move a load over a store into the same array.  Legal by the contract of
     // snac_transition (include/snac_hip.h): a destination row is never the source row of a different edge of the call.
-    constexpr int U = 8;
+    // INPLACE (identity rows: every snac_step): no record is copied at all -- a step writes its one changed cell, an auto-reset
+    // writes the empty map -- so the whole tile's window gathers are issued up front (vmcnt retires in order: a later group's
+    // loads would also wait for the row stores in front of them).
+    constexpr int U = INPLACE ? 32 : 8;
     for (int e0 = 0; e0 < nedge; e0 += U) {                          // wave-uniform: readlane broadcasts an edge's scalars
-        uint4 rec[U];
+        uint4 rec[INPLACE ? 1 : U];
         int wcell[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1448,8 +1451,10 @@ __global__ __launch_bounds__(WPB * 64) void k_transition3d(const KArgs a) {
                 wcell[u] = in ? (idx == tp ? nh : v) : -1;
             }
             // a step in place (snac_step, or a tree edge onto its own row) changes ONE cell: no record copy
-            const bool copy = fresh || se != __builtin_amdgcn_readlane(drow, e);
-            rec[u] = (fresh || lane >= 50 || !copy) ? make_uint4(0u, 0u, 0u, 0u) : g4[(size_t)se * 50 + lane];
+            if constexpr (!INPLACE) {
+                const bool copy = fresh || se != __builtin_amdgcn_readlane(drow, e);
+                rec[u] = (fresh || lane >= 50 || !copy) ? make_uint4(0u, 0u, 0u, 0u) : g4[(size_t)se * 50 + lane];
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1457,11 +1462,11 @@ __global__ __launch_bounds__(WPB * 64) void k_transition3d(const KArgs a) {
             if (e < nedge) {
                 const int de = __builtin_amdgcn_readlane(drow, e);
                 const int tp = __builtin_amdgcn_readlane(tpatch, e), nh = __builtin_amdgcn_readlane(newh, e);
-                const bool copy = __builtin_amdgcn_readlane((int)nr, e) != 0 || de != __builtin_amdgcn_readlane(srow, e);
+                const bool copy = __builtin_amdgcn_readlane((int)nr, e) != 0 || (!INPLACE && de != __builtin_amdgcn_readlane(srow, e));
                 if (!copy) {
                     if (tp >= 0 && lane == 0) ((int16_t*)a.grid)[(size_t)de * K::GE + tp] = (int16_t)nh;
                 } else if (lane < 50) {
-                    uint4 v = rec[u];
+                    uint4 v = INPLACE ? make_uint4(0u, 0u, 0u, 0u) : rec[u];
                     if (tp >= 0 && (tp >> 3) == lane) {              // this lane's 8 cells hold the built one
                         const int hw = tp & 7, sh = (hw & 1) * 16;
                         const uint32_t keep = ~(0xFFFFu << sh), put = ((uint32_t)nh & 0xFFFFu) << sh;
@@ -2121,8 +2126,13 @@ void launch_trans3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
     const int tiles = (a.n + 31) / 32;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    if (dyn) { if (f32) hipLaunchKernelGGL((k_transition3d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<true, double, 4>), grid, block, 0, s, a); }
-    else { if (f32) hipLaunchKernelGGL((k_transition3d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<false, double, 4>), grid, block, 0, s, a); }
+    if (!a.src_index && !a.dst_index) {   // identity rows (snac_step, or a transition on rows i -> i)
+        if (dyn) { if (f32) hipLaunchKernelGGL((k_transition3d<true, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<true, double, 4, true>), grid, block, 0, s, a); }
+        else { if (f32) hipLaunchKernelGGL((k_transition3d<false, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<false, double, 4, true>), grid, block, 0, s, a); }
+        return;
+    }
+    if (dyn) { if (f32) hipLaunchKernelGGL((k_transition3d<true, float, 4, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<true, double, 4, false>), grid, block, 0, s, a); }
+    else { if (f32) hipLaunchKernelGGL((k_transition3d<false, float, 4, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<false, double, 4, false>), grid, block, 0, s, a); }
 }
 
 // E edges per wave.  The kernel is bound by HBM traffic from N = 2^19 down to where the launch itself dominates; 32 edges per
