@@ -186,9 +186,10 @@ def cpu_baseline(kind, dynamic, n, T, seed):
 
 
 # ------------------------------------------------------------------------------------------------
-def measured_write_peak(torch, dev, nbytes=1 << 31, ms_budget=50.0):
+def measured_write_peak(torch, dev, nbytes=1 << 31, ms_budget=50.0, alloc=None):
     """The box's write ceiling, live: hipMemsetAsync over a 2 GiB buffer on the current stream, ~50 ms of it, timed with
-    events on that stream.  (No kernel pattern exceeds it on this pool, profiles/r01_wr_ceiling.txt.)  GB/s or None."""
+    events on that stream.  alloc: where the buffer comes from (default torch.empty = hipMalloc memory; snac_amd.trajmem.traj_empty =
+    memory of the virtual-memory API, the kind the trajectory lies in).  GB/s or None."""
     import ctypes as C
 
     hip = None
@@ -202,7 +203,7 @@ def measured_write_peak(torch, dev, nbytes=1 << 31, ms_budget=50.0):
         return None
     hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
     hip.hipMemsetAsync.restype = C.c_int
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    buf = alloc((nbytes,), torch.uint8, dev) if alloc else torch.empty(nbytes, dtype=torch.uint8, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def run(k):
@@ -282,7 +283,25 @@ def main():
     # Where the 16 GB trajectory tensor lies in HBM is worth 5-9 % of the pass (fast and slow regions of the address map,
     # snac_amd/placement.py): SNAC_BENCH_PLACE candidates (default 6, 0 / 1 = take the first allocation) are
     # allocated, the workload itself -- a scratch batch of the same shape -- is timed on each, the fastest is kept.
-    place_n = int(os.environ.get("SNAC_BENCH_PLACE", "6"))
+    # ... and the KIND of memory is worth more: memory of the HIP virtual-memory API (snac_traj_alloc, snac_amd/trajmem.py) takes the
+    # rollout's rows 10-20 % faster than the hipMalloc memory of torch.empty (tools/wr_vmm.hip).  SNAC_BENCH_MEMORY=vmm (default) |
+    # malloc; if the virtual-memory block cannot be had the run falls back to torch.empty and says so in `placement`.
+    place_n = int(os.environ.get("SNAC_BENCH_PLACE", "4"))
+    memory = os.environ.get("SNAC_BENCH_MEMORY", "vmm")
+    traj_alloc = None
+    if memory == "vmm":
+        try:
+            from snac_amd import trajmem
+
+            trajmem.traj_empty((1 << 20,), torch.uint8, dev)       # one small block: does this box / build do it at all?
+            traj_alloc = trajmem.traj_empty
+        except Exception as e:
+            sys.stderr.write("bench.py: no virtual-memory trajectory block (%r), using torch.empty\n" % (e,))
+            memory = "malloc (vmm failed: %r)" % (e,)
+
+    def plain(shape):
+        return traj_alloc(shape, env.obs_dtype, dev) if traj_alloc else torch.empty(shape, dtype=env.obs_dtype, device=dev)
+
     placement_report = None
     if place_n > 1:
         from snac_amd import placement
@@ -292,14 +311,21 @@ def main():
                                   obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
             probe.reset()
             obs, placement_report = placement.fastest_tensor((T, n, env.obs_dim), env.obs_dtype, dev,
-                                                             lambda t: probe.rollout(T, obs="all", out=t), candidates=place_n)
+                                                             lambda t: probe.rollout(T, obs="all", out=t), candidates=place_n,
+                                                             alloc=traj_alloc)
             del probe
         except Exception as e:                                   # the measurement must not depend on the probe: take a plain tensor
             sys.stderr.write("bench.py: placement probe failed (%r), using the first allocation\n" % (e,))
             torch.cuda.empty_cache()
-            obs, placement_report = torch.empty((T, n, env.obs_dim), dtype=env.obs_dtype, device=dev), {"error": repr(e)}
+            try:
+                obs, placement_report = plain((T, n, env.obs_dim)), {"error": repr(e)}
+            except Exception as e2:
+                traj_alloc, memory = None, "malloc (vmm failed: %r)" % (e2,)
+                obs, placement_report = torch.empty((T, n, env.obs_dim), dtype=env.obs_dtype, device=dev), {"error": repr(e)}
     else:
-        obs = torch.empty((T, n, env.obs_dim), dtype=env.obs_dtype, device=dev)
+        obs = plain((T, n, env.obs_dim))
+        placement_report = {}
+    placement_report["memory"] = memory
     env.reset()
     stats = torch.zeros(3, dtype=torch.int64, device=dev)
 
@@ -311,7 +337,14 @@ def main():
     # The write-ceiling probe (~60 ms of hipMemsetAsync) runs FIRST, on every rank: a GPU that comes from idle needs some tens
     # of milliseconds of load before it holds its sustained clocks (tools/b2b_time.py: the same launch takes 1.51 ms right
     # after an idle gap and 1.29 ms ten launches later), and W warm-up passes of 3 ms each do not get it there.
-    wpeak = measured_write_peak(torch, dev)
+    wpeak_malloc = measured_write_peak(torch, dev)
+    wpeak_vmm = None
+    if traj_alloc:
+        try:
+            wpeak_vmm = measured_write_peak(torch, dev, alloc=traj_alloc)
+        except Exception as e:
+            sys.stderr.write("bench.py: write-ceiling probe on virtual-memory block failed (%r)\n" % (e,))
+    wpeak = max([w for w in (wpeak_malloc, wpeak_vmm) if w] or [0.0]) or None
     # ... and neither does the probe: what brings the clocks up is the workload itself, launched back to back.  So an untimed
     # pre-roll of SNAC_BENCH_PREROLL_MS (default 60 ms, 0 = none) of passes is enqueued before the W warm-up passes, without
     # a host synchronisation in between (tools/b2b_time.py).
@@ -371,6 +404,12 @@ def main():
     per_rank = allreduce_(per_rank).tolist()
     ranks_seen = int(allreduce_(torch.ones(1, dtype=torch.int64, device=dev)).item())
 
+    # integrity of what the timed passes wrote (after the clock stopped): the last step's rows in the trajectory tensor must be the
+    # batch's current observation, read through a different kernel into ordinary memory
+    traj_ok = bool(torch.equal(obs[T - 1], env.observe()))
+    if not traj_ok:
+        sys.stderr.write("bench.py: the trajectory tensor's last step differs from observe() -- the measurement is INVALID\n")
+
     # the same workload into the tile-major trajectory layout (obs="tiled": [N / 64][T][64][D], SNAC_OBS_TILED) -- reported
     # beside the headline, never as `value`: 2D only, after the clock stopped; its tensor is placed like the headline's (the
     # tile-major stream is the one that really profits from a fast region: 5.65 against 7.1 TB/s store-only)
@@ -380,9 +419,10 @@ def main():
         torch.cuda.empty_cache()
         tshape = (n // 64, T, 64, env.obs_dim)
         if place_n > 1:
-            tv, trep = placement.fastest_tensor(tshape, env.obs_dtype, dev, lambda t: env.rollout(T, obs="tiled", out=t), candidates=place_n)
+            tv, trep = placement.fastest_tensor(tshape, env.obs_dtype, dev, lambda t: env.rollout(T, obs="tiled", out=t), candidates=place_n,
+                                                alloc=traj_alloc)
         else:
-            tv, trep = torch.empty(tshape, dtype=env.obs_dtype, device=dev), None
+            tv, trep = plain(tshape), None
         for _ in range(12):
             env.rollout(T, obs="tiled", out=tv)
         tev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -440,16 +480,21 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "frac_traffic": (traffic / HBM_PEAK_GBS) if traffic else None,
-                         "peak_measured_write": wpeak,
+                         "peak_measured_write": wpeak,            # hipMemsetAsync, the faster of the two kinds of memory:
+                         "peak_measured_write_by_memory": {"malloc": wpeak_malloc, "vmm": wpeak_vmm},
                          "written": written,                      # output bytes of the launch / its duration, GB/s
                          "frac_of_measured_write": ((traffic or written) / wpeak) if wpeak else None,
-                         "kernel": kernel_name, "kernel_ms": kern_ms, "alg_bytes_per_env_step": alg},
+                         "kernel": kernel_name, "kernel_ms": kern_ms, "alg_bytes_per_env_step": alg,
+                         "note": "achieved / frac price the launch at the un-fused contract figure (SURVEY.md 8d: %d B per env-step); "
+                                 "the fused kernel keeps window and scalars on chip and moves %d B, so frac may exceed the physical "
+                                 "fraction: frac_traffic = HBM bytes from the PMC counters / time / peak" % (alg, WRITTEN_BYTES[(args.kind, dkey)])},
             "backend": backend if world > 1 else None,
             "rccl_ranks": ranks_seen if (world > 1 and backend == "nccl") else None,
             "ranks": ranks_seen,
             "kernel_ms_per_rank": per_rank,
             "kernel_ms_per_step": [round(x, 4) for x in per_step_ms],   # rank 0's launches, in order
             "preroll_passes": preroll_passes,                     # untimed, before the W warm-up passes (clock ramp)
+            "trajectory_check": traj_ok,                          # obs[T - 1] == observe() after the timed passes
             "placement": placement_report,                        # rank 0's choice among SNAC_BENCH_PLACE candidate tensors
             "tiled_layout": tiled,                                # rank 0, informational: the build's own trajectory layout
             "episodic": {"episodes": s[0], "mean_return": (s[1] / s[0]) if s[0] else None,
@@ -462,6 +507,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not traj_ok:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -51,6 +51,7 @@
  */
 #ifndef SNAC_HIP_H
 #define SNAC_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -197,6 +198,19 @@ int snac_reset_scalar(const snac_env_desc* desc, const snac_state* st, int32_t p
  * separates the launch from reading it -- env.step(action) -> (obs, reward, done) of the reference classes
  * (Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:85-147) as one launch and one wait, no copy command. */
 int snac_stream_sync(void* stream);
+
+/* Trajectory memory (optional; every entry point takes any device pointer).  The reference has no counterpart: its driver
+ * loop (multiprocess.py:78-84) drops each step's arrays.  On MI355X the [T][N][obs_dim] output of snac_rollout is written
+ * 10-20 % faster into memory of the virtual-memory API (hipMemCreate handles mapped into one reserved, contiguous range) than
+ * into a hipMalloc block (tools/wr_vmm.hip), so this is where a caller should put it.
+ *   snac_traj_alloc   `bytes` (rounded up to whole 32 MB handles, or 2 MB pages below that) on `device`, read / write for that
+ *                     device; *out is an ordinary device pointer, contiguous, 2 MB-aligned.  SNAC_ERR_HIP when memory runs out.
+ *   snac_traj_free    waits for the device to go idle, unmaps and releases the block's memory (its address range stays reserved
+ *                     and is never handed out again: a stale pointer faults); NULL is a no-op; a pointer that did not come from
+ *                     snac_traj_alloc is SNAC_ERR_ARG.
+ * The caller owns the block: the library allocates nothing by itself. */
+int snac_traj_alloc(size_t bytes, int device, void** out);
+int snac_traj_free(void* ptr);
 
 /* the driver loop of multiprocess.py:78-84 -- T vector steps with auto-reset, fused in one launch with the
  * env state held on chip.

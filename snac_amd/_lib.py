@@ -22,7 +22,8 @@ TAIL_POSITION, TAIL_PLAN, TAIL_RECORD = 1, 2, 4
 EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_obs_dim", "snac_reset", "snac_reset_scalar", "snac_step",
            "snac_step_scalar", "snac_rollout",
            "snac_rollout_rec", "snac_replay_gather", "snac_make_plans", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
-           "snac_import_state", "snac_obs_equal", "snac_stream_sync", "snac_rollout_tiled", "snac_replay_gather_tiled")
+           "snac_import_state", "snac_obs_equal", "snac_stream_sync", "snac_rollout_tiled", "snac_replay_gather_tiled", "snac_traj_alloc",
+           "snac_traj_free")
 
 
 class Sizes(C.Structure):
@@ -98,6 +99,8 @@ def lib():
         L.snac_transition.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
         L.snac_import_state.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.snac_obs_equal.argtypes = [C.POINTER(EnvDesc), vp, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
+        L.snac_traj_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(vp)]
+        L.snac_traj_free.argtypes = [vp]
         for n in EXPORTS:
             getattr(L, n)
         if L.snac_version() != ABI_VERSION:

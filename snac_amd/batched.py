@@ -323,24 +323,37 @@ class BatchedDMPEnv:
         self.t += T
         return o, reward, (done.view(torch.bool) if done is not None else None)
 
-    def alloc_trajectory(self, T, candidates=6, reps=3, layout="ticks"):
-        """The [T, N, obs_dim] output tensor of rollout(T, out=...), placed where this batch's rollout writes fastest: on MI355X
-        the write rate of a multi-GB tensor depends on which part of HBM it occupies (5-9 % of a pass, snac_amd/placement.py).
-        `candidates` tensors are allocated, a copy of this batch rolls out into each, the fastest is kept.  The batch itself is
-        not stepped.  layout "tiled": the tensor of rollout(obs="tiled").  Returns (tensor, report)."""
+    def alloc_trajectory(self, T, candidates=3, reps=3, layout="ticks", memory="vmm"):
+        """The [T, N, obs_dim] output tensor of rollout(T, out=...), allocated where this batch's rollout writes fastest.  Two
+        things decide that on MI355X: the KIND of memory -- memory="vmm" (default) takes it from
+        snac_traj_alloc (HIP virtual-memory API; snac_amd/trajmem.py), which a streaming write fills 10-20 % faster than the
+        hipMalloc memory of torch.empty (memory="malloc") -- and, for hipMalloc memory above all, WHICH part of HBM it occupies
+        (5-9 % of a pass, snac_amd/placement.py): `candidates` tensors are allocated, a copy of this batch rolls out into each,
+        the fastest is kept.  The batch itself is not stepped.  layout "tiled": the tensor of rollout(obs="tiled").
+        Returns (tensor, report)."""
         from . import placement
 
         if not self._was_reset:
             raise _lib.SnacError("alloc_trajectory() before reset()")
+        if memory not in ("vmm", "malloc"):
+            raise ValueError("memory must be 'vmm' or 'malloc'")
+        alloc = None
+        if memory == "vmm":
+            from . import trajmem
+
+            alloc = trajmem.traj_empty
         scratch = self.fork(torch.arange(self.num_envs, device=self.device))
         T = int(T)
         if layout == "tiled":                                        # [ceil(N / 64), T, 64, D] for rollout(obs="tiled")
-            return placement.fastest_tensor(((self.num_envs + 63) // 64, T, 64, self.obs_dim), self.obs_dtype, self.device,
-                                            lambda t: scratch.rollout(T, obs="tiled", out=t, want_reward=False, want_done=False),
-                                            candidates=candidates, reps=reps)
-        return placement.fastest_tensor((T, self.num_envs, self.obs_dim), self.obs_dtype, self.device,
-                                        lambda t: scratch.rollout(T, obs="all", out=t, want_reward=False, want_done=False),
-                                        candidates=candidates, reps=reps)
+            t, rep = placement.fastest_tensor(((self.num_envs + 63) // 64, T, 64, self.obs_dim), self.obs_dtype, self.device,
+                                              lambda t: scratch.rollout(T, obs="tiled", out=t, want_reward=False, want_done=False),
+                                              candidates=candidates, reps=reps, alloc=alloc)
+        else:
+            t, rep = placement.fastest_tensor((T, self.num_envs, self.obs_dim), self.obs_dtype, self.device,
+                                              lambda t: scratch.rollout(T, obs="all", out=t, want_reward=False, want_done=False),
+                                              candidates=candidates, reps=reps, alloc=alloc)
+        rep["memory"] = memory
+        return t, rep
 
     def untile(self, tiled):
         """[ceil(N / 64), T, 64, D] (rollout(obs="tiled")) -> a [T, N, D] copy in the reference order."""

@@ -1,0 +1,114 @@
+"""Trajectory tensors backed by snac_traj_alloc (include/snac_hip.h): memory from the HIP virtual-memory API.
+
+On MI355X the multi-GB output of a fused rollout is written 10-20 % faster into such memory than into a hipMalloc block -- which is
+what torch.empty() hands out; PyTorch-ROCm's own virtual-memory mode (expandable segments) is not available on this platform --
+(tools/wr_vmm.hip).  traj_empty() returns an ordinary torch tensor viewing one block; the block is unmapped
+and released when the tensor's storage dies.  PyTorch is plumbing here: it only learns the pointer.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class _Block:
+    """Owner of one snac_traj_alloc block.  torch views it through __cuda_array_interface__ (and keeps this object alive for as
+    long as any tensor shares the storage); DLPack is the second route if a build refuses the first."""
+
+    def __init__(self, nbytes, device_index):
+        L = _lib.lib()
+        p = C.c_void_p()
+        _lib.check(L.snac_traj_alloc(int(nbytes), int(device_index), C.byref(p)))
+        self.ptr, self.nbytes, self.device_index = p.value, int(nbytes), int(device_index)
+        self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2,
+                                         "strides": None}
+
+    def free(self):
+        ptr, self.ptr = self.ptr, None
+        if ptr:
+            try:
+                _lib.lib().snac_traj_free(C.c_void_p(ptr))       # waits for the device, then unmaps
+            except Exception:                                   # interpreter shutdown: the process is going away anyway
+                pass
+
+    def __del__(self):
+        self.free()
+
+
+# ---- DLPack route (kDLROCM): torch takes the device from the capsule, not from a pointer query -------------------------------
+class _DLDevice(C.Structure):
+    _fields_ = [("device_type", C.c_int), ("device_id", C.c_int)]
+
+
+class _DLDataType(C.Structure):
+    _fields_ = [("code", C.c_uint8), ("bits", C.c_uint8), ("lanes", C.c_uint16)]
+
+
+class _DLTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("device", _DLDevice), ("ndim", C.c_int), ("dtype", _DLDataType),
+                ("shape", C.POINTER(C.c_int64)), ("strides", C.POINTER(C.c_int64)), ("byte_offset", C.c_uint64)]
+
+
+class _DLManagedTensor(C.Structure):
+    pass
+
+
+_DELETER = C.CFUNCTYPE(None, C.POINTER(_DLManagedTensor))
+_DLManagedTensor._fields_ = [("dl_tensor", _DLTensor), ("manager_ctx", C.c_void_p), ("deleter", _DELETER)]
+_live = {}                                                       # id -> (block, managed tensor, shape array): until torch's deleter runs
+
+
+@_DELETER
+def _dl_deleter(mt):
+    key = C.addressof(mt.contents)
+    ent = _live.pop(key, None)
+    if ent is not None:
+        ent[0].free()
+
+
+def _via_dlpack(block):
+    shape = (C.c_int64 * 1)(block.nbytes)
+    mt = _DLManagedTensor()
+    mt.dl_tensor.data = block.ptr
+    mt.dl_tensor.device = _DLDevice(10, block.device_index)      # kDLROCM
+    mt.dl_tensor.ndim = 1
+    mt.dl_tensor.dtype = _DLDataType(1, 8, 1)                    # uint8
+    mt.dl_tensor.shape = shape
+    mt.dl_tensor.strides = None
+    mt.dl_tensor.byte_offset = 0
+    mt.manager_ctx = None
+    mt.deleter = _dl_deleter
+    _live[C.addressof(mt)] = (block, mt, shape)
+    new = C.pythonapi.PyCapsule_New
+    new.restype, new.argtypes = C.py_object, [C.c_void_p, C.c_char_p, C.c_void_p]
+    cap = new(C.addressof(mt), b"dltensor", None)
+    try:
+        return torch.utils.dlpack.from_dlpack(cap)
+    except Exception:
+        _live.pop(C.addressof(mt), None)
+        raise
+
+
+def traj_empty(shape, dtype, device):
+    """torch.empty(shape, dtype=dtype, device=device) on snac_traj_alloc memory (uninitialised, contiguous).  Raises SnacError
+    when the block cannot be allocated and RuntimeError when this PyTorch build cannot view a foreign device pointer."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.SnacError("trajectory memory lives on a ROCm GPU")
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    nbytes = max(1, numel * torch.empty((), dtype=dtype).element_size())
+    with torch.cuda.device(index):
+        block = _Block(nbytes, index)
+        try:
+            flat = torch.as_tensor(block, device=torch.device("cuda", index))
+            if flat.data_ptr() != block.ptr:                     # a copy instead of a view: not what was asked for
+                raise RuntimeError("__cuda_array_interface__ was copied")
+        except Exception:
+            flat = _via_dlpack(block)
+        if flat.data_ptr() != block.ptr or flat.device.index != index:
+            raise RuntimeError("this PyTorch build does not view a foreign device pointer in place")
+    return flat[: numel * torch.empty((), dtype=dtype).element_size()].view(dtype).view(tuple(int(d) for d in shape))

@@ -1,0 +1,122 @@
+"""Trajectory memory (snac_traj_alloc / snac_traj_free, snac_amd/trajmem.py): blocks of the HIP virtual-memory API viewed as
+torch tensors.  What is checked is that the memory behaves like any other device memory -- every kernel's output in it equals
+the output in a torch.empty tensor bit for bit -- and that blocks are released."""
+import ctypes as C
+import gc
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_raw_abi_alloc_write_read_free():
+    import torch
+    from snac_amd import _lib
+
+    L = _lib.lib()
+    p = C.c_void_p()
+    assert L.snac_traj_alloc(0, 0, C.byref(p)) == -1 and b"bytes" in L.snac_last_error()
+    assert L.snac_traj_alloc(4096, 99, C.byref(p)) == -1 and b"device" in L.snac_last_error()
+    assert L.snac_traj_alloc(4096, 0, None) == -1
+    nbytes = (70 << 20) + 12345                                  # three 32 MB handles, the last one partly used
+    assert L.snac_traj_alloc(nbytes, 0, C.byref(p)) == 0 and p.value and p.value % (2 << 20) == 0
+    src = torch.arange(nbytes // 8, dtype=torch.int64, device="cuda")
+    hip = C.CDLL("libamdhip64.so.7")                         # the SONAME: the copy torch has loaded, not a second runtime
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(p, C.c_void_p(src.data_ptr()), src.numel() * 8, 3) == 0      # device to device, across handle borders
+    back = torch.empty_like(src)
+    assert hip.hipMemcpy(C.c_void_p(back.data_ptr()), p, src.numel() * 8, 3) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(src, back)
+    assert L.snac_traj_free(C.c_void_p(src.data_ptr())) == -1 and b"snac_traj_alloc" in L.snac_last_error()
+    assert L.snac_traj_free(p) == 0
+    assert L.snac_traj_free(p) == -1                             # already gone
+    assert L.snac_traj_free(None) == 0
+
+
+def test_traj_empty_is_an_ordinary_tensor_and_is_released():
+    import torch
+    from snac_amd import trajmem
+
+    free0 = torch.cuda.mem_get_info()[0]
+    t = trajmem.traj_empty((3, 1000, 51), torch.float64, "cuda")
+    assert tuple(t.shape) == (3, 1000, 51) and t.dtype == torch.float64 and t.is_contiguous() and t.device.type == "cuda"
+    assert t.data_ptr() % (2 << 20) == 0
+    t.copy_(torch.arange(t.numel(), dtype=torch.float64, device="cuda").view_as(t))
+    assert float(t.sum().item()) == float(sum(range(t.numel())))
+    v = t[1]                                                     # a view keeps the block alive
+    del t
+    gc.collect()
+    assert float(v[0, 0].item()) == 51000.0
+    big = trajmem.traj_empty((1 << 30,), torch.uint8, "cuda")    # 1 GiB: visible in the driver's free-memory figure
+    assert torch.cuda.mem_get_info()[0] <= free0 - (1 << 30) + (64 << 20)
+    big.zero_()
+    del big, v
+    gc.collect()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)    # both blocks went back
+
+
+@pytest.mark.parametrize("kind,n,T", [(2, 4096, 40), (3, 1024, 60), (1, 5000, 70)])
+def test_rollout_into_trajectory_memory_equals_a_plain_tensor(kind, n, T):
+    import torch
+    from snac_amd import BatchedDMPEnv, trajmem
+
+    a = BatchedDMPEnv(kind, True, n, seed=9)
+    b = BatchedDMPEnv(kind, True, n, seed=9)
+    a.reset(); b.reset()
+    out = trajmem.traj_empty((T, n, a.obs_dim), torch.float64, a.device)
+    oa, ra, da = a.rollout(T, out=out)
+    ob, rb, db = b.rollout(T)
+    assert oa.data_ptr() == out.data_ptr()
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    tiled = trajmem.traj_empty(((n + 63) // 64, T, 64, a.obs_dim), torch.float64, a.device)
+    ta, _, _ = a.rollout(T, obs="tiled", out=tiled)
+    tb, _, _ = b.rollout(T, obs="tiled")
+    assert torch.equal(a.untile(ta), b.untile(tb))               # (rows of the last tile beyond N are never written)
+    # the per-tick step() writes its rows there too
+    row = trajmem.traj_empty((n, a.obs_dim), torch.float64, a.device)
+    rew, done = torch.empty(n, dtype=torch.float32, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda")
+    sa = a.step(auto_reset=True, out=(row, rew, done))
+    sb = b.step(auto_reset=True)
+    assert torch.equal(sa[0], sb[0]) and torch.equal(sa[1], sb[1]) and torch.equal(sa[2], sb[2])
+
+
+def test_alloc_trajectory_uses_trajectory_memory_by_default():
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    env = BatchedDMPEnv(2, True, 2048, seed=3)
+    env.reset()
+    out, rep = env.alloc_trajectory(30)
+    assert rep["memory"] == "vmm" and out.data_ptr() % (2 << 20) == 0 and tuple(out.shape) == (30, 2048, 51)
+    out2, rep2 = env.alloc_trajectory(30, memory="malloc")
+    assert rep2["memory"] == "malloc"
+    with pytest.raises(ValueError):
+        env.alloc_trajectory(30, memory="host")
+    ref = BatchedDMPEnv(2, True, 2048, seed=3)
+    ref.reset()
+    o1, _, _ = env.rollout(30, out=out)
+    o2, _, _ = ref.rollout(30, out=out2)
+    assert torch.equal(o1, o2)
+    assert np.isfinite(o1.cpu().numpy()).all()
+
+
+def test_blocks_allocated_and_freed_in_turn_always_read_back_what_was_written():
+    """Address-range churn: blocks of changing sizes allocated, filled by a kernel, read back through a copy engine and freed, with
+    hipMalloc blocks coming and going in between -- a fresh block must never serve a stale translation of an earlier one."""
+    import torch
+    from snac_amd import trajmem
+
+    for i in range(60):
+        n = (1 + (i * 7) % 35) << 20                             # 1 .. 35 M float16 = 2 .. 70 MB
+        t = trajmem.traj_empty((n,), torch.float16, "cuda")
+        t.fill_(float(i % 200))
+        spare = torch.empty((3 + i % 5) << 20, dtype=torch.uint8, device="cuda")
+        host = t.cpu()
+        assert float(host.min()) == float(i % 200) == float(host.max()), i
+        assert float(t[-1].item()) == float(i % 200)
+        del t, spare, host
+        if i % 4 == 0:
+            torch.cuda.empty_cache()

@@ -21,7 +21,7 @@ def env_obs_bytes(kind):
 def rollout_time(kind, dynamic, n, T, obs_dtype=torch.float64, reps=5, obs="all"):
     env = BatchedDMPEnv(kind, dynamic, n, seed=1, obs_dtype=obs_dtype)
     env.reset()
-    buf = torch.empty((T, n, env.obs_dim), dtype=obs_dtype, device=env.device) if obs == "all" else None
+    buf = env.alloc_trajectory(T, candidates=2)[0] if obs == "all" else None   # snac_traj_alloc memory (two 32 GiB slices)
     env.rollout(T, obs=obs, out=buf)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -67,7 +67,7 @@ def main():
         g = torch.Generator(device=env.device).manual_seed(1)
         probs = torch.tensor([0.2] * 4 + [0.05] * 4, device=env.device)
         acts = torch.multinomial(probs, T * n, replacement=True, generator=g).to(torch.int8).reshape(T, n)
-        buf = torch.empty((T, n, env.obs_dim), dtype=torch.float64, device=env.device)
+        buf = env.alloc_trajectory(T, candidates=2)[0]
         env.rollout(T, actions=acts, out=buf)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
