@@ -324,13 +324,13 @@ class BatchedDMPEnv:
         return o, reward, (done.view(torch.bool) if done is not None else None)
 
     def alloc_trajectory(self, T, candidates=3, reps=3, layout="ticks", memory="vmm"):
-        """The [T, N, obs_dim] output tensor of rollout(T, out=...), allocated where this batch's rollout writes fastest.  Two
-        things decide that on MI355X: the KIND of memory -- memory="vmm" (default) takes it from
-        snac_traj_alloc (HIP virtual-memory API; snac_amd/trajmem.py), which a streaming write fills 10-20 % faster than the
-        hipMalloc memory of torch.empty (memory="malloc") -- and, for hipMalloc memory above all, WHICH part of HBM it occupies
-        (5-9 % of a pass, snac_amd/placement.py): `candidates` tensors are allocated, a copy of this batch rolls out into each,
-        the fastest is kept.  The batch itself is not stepped.  layout "tiled": the tensor of rollout(obs="tiled").
-        Returns (tensor, report)."""
+        """The [T, N, obs_dim] output tensor of rollout(T, out=...), allocated where this batch's rollout writes fastest.  On
+        MI355X write streams confined to one 32 GiB slice of the physical address space reach ~5.7 TB/s, spread over several
+        ~7.1: memory="vmm" (default) takes the tensor from snac_traj_alloc (snac_amd/trajmem.py: one virtual
+        range over three physical runs a slice apart), memory="malloc" from torch.empty (hipMalloc: one run).  Where the driver
+        puts a run is not ours to say, so `candidates` tensors are allocated, a copy of this batch rolls out into each and the
+        fastest is kept (snac_amd/placement.py).  The batch itself is not stepped.  layout "tiled": the tensor of
+        rollout(obs="tiled").  Returns (tensor, report)."""
         from . import placement
 
         if not self._was_reset:

@@ -2463,17 +2463,20 @@ int snac_export_grid(const snac_env_desc* d, const snac_state* st, double* out, 
 // top out at ~5.7 TB/s, the same streams spread over two or more slices reach ~7.1 (tools/wr_blocks.hip, profiles/; the split
 // may be as coarse as 128 MB pieces taking turns).  A tensor from hipMalloc is one contiguous run of at most 16 GB -- inside one
 // slice unless it happens to straddle a boundary, which is all the "fast and slow regions" of the address map ever were.  The
-// virtual-memory API lets ONE contiguous virtual range be backed by two runs of physical memory a slice apart: handles of 32 MB
-// are created back to back (run A, a gap that brings the distance to 32 GiB, run B; consecutive handles follow each other in
-// physical memory on an otherwise idle device), virtual chunk j is mapped to run j % 2, the gap is released.  Nothing about the
-// tensor changes for its users; the rollout's rows land in two slices at any time.  The caller owns the block and frees it with
+// virtual-memory API lets ONE contiguous virtual range be backed by several runs of physical memory a slice apart: handles of
+// 32 MB are created back to back (run 0, a gap that brings the distance to 32 GiB, run 1, a gap, run 2; consecutive handles tend
+// to follow each other in physical memory), virtual chunk j is mapped to run j % 3, the gaps are released.  Three runs, not two:
+// where a handle really lands is the driver's business (after allocations and releases the order is no longer monotonic), and
+// with three runs at least two slices take part in every case measured (tools/wr_vmm.hip: 6.9-7.1 TB/s in four of four layouts,
+// two runs 5.7-7.1).  Nothing about the tensor changes for its users.  The caller owns the block and frees it with
 // snac_traj_free; the library keeps only the bookkeeping needed to unmap it.
 namespace {
 struct TrajBlock { size_t total, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_traj_mu;
 std::unordered_map<void*, TrajBlock> g_traj;
 constexpr size_t TRAJ_CHUNK = (size_t)32 << 20;   // one physical handle per 32 MB: 480 handles for the headline's 16 GB
-constexpr size_t TRAJ_SLICE = (size_t)32 << 30;   // distance between the two runs
+constexpr size_t TRAJ_SLICE = (size_t)32 << 30;   // distance between the starts of consecutive runs
+constexpr int TRAJ_RUNS = 3;
 constexpr size_t TRAJ_SPLIT_MIN = (size_t)256 << 20;   // smaller blocks are not bound by where they lie: one run
 
 // Unmap chunk by chunk (each call undoes exactly one hipMemMap), release the physical handles -- and KEEP the address range
@@ -2504,51 +2507,44 @@ int snac_traj_alloc(size_t bytes, int device, void** out) {
     if (gran < ((size_t)2 << 20)) gran = (size_t)2 << 20;          // whole 2 MB pages whatever the minimum is
     const size_t chunk = bytes >= TRAJ_CHUNK ? ((TRAJ_CHUNK + gran - 1) / gran) * gran : ((bytes + gran - 1) / gran) * gran;
     const size_t k = (bytes + chunk - 1) / chunk, total = k * chunk;
-    const bool split = bytes >= TRAJ_SPLIT_MIN && k >= 2;
-    const size_t ka = split ? (k + 1) / 2 : k;                      // run A: chunks 0, 2, 4, ...; run B: chunks 1, 3, 5, ...
+    const int runs = (bytes >= TRAJ_SPLIT_MIN && k >= (size_t)TRAJ_RUNS) ? TRAJ_RUNS : 1;   // run r: chunks r, r + runs, r + 2 runs, ...
     char* va = nullptr;
     e = hipMemAddressReserve((void**)&va, total, gran, nullptr, 0);
     if (e != hipSuccess) return fail_hip(e, "hipMemAddressReserve");
     std::vector<hipMemGenericAllocationHandle_t> hs(k), gap;
-    size_t made = 0;
-    auto create = [&](size_t first, size_t count, size_t step) -> hipError_t {   // handles of chunks first, first + step, ...
-        for (size_t i = 0; i < count; ++i) {
-            hipError_t ce = hipMemCreate(&hs[first + i * step], chunk, &prop, 0);
-            if (ce != hipSuccess) return ce;
-            ++made;
+    std::vector<size_t> made;                                      // chunk indices whose handles exist, in creation order
+    made.reserve(k);
+    auto drop_gap = [&]() { for (auto g : gap) (void)hipMemRelease(g); gap.clear(); };
+    for (int r = 0; r < runs; ++r) {
+        size_t in_run = 0;
+        for (size_t c = (size_t)r; c < k; c += (size_t)runs) {
+            hipError_t ce = hipMemCreate(&hs[c], chunk, &prop, 0);
+            if (ce != hipSuccess && !gap.empty()) {                 // the gaps hold what this run needs: give them back, try once more
+                drop_gap();
+                (void)hipGetLastError();
+                ce = hipMemCreate(&hs[c], chunk, &prop, 0);
+            }
+            if (ce != hipSuccess) {
+                std::vector<hipMemGenericAllocationHandle_t> have;
+                for (size_t q : made) have.push_back(hs[q]);
+                drop_gap();
+                traj_release(va, 0, chunk, have);
+                return fail_hip(ce, "hipMemCreate (out of device memory?)");
+            }
+            made.push_back(c);
+            ++in_run;
         }
-        return hipSuccess;
-    };
-    auto bail = [&](hipError_t be, const char* where) {
-        // release what exists: the handles created so far are the first `made` in creation order (run A, then run B)
-        std::vector<hipMemGenericAllocationHandle_t> have;
-        for (size_t i = 0; i < made; ++i) have.push_back(i < ka ? hs[split ? 2 * i : i] : hs[2 * (i - ka) + 1]);
-        for (auto g : gap) (void)hipMemRelease(g);
-        traj_release(va, 0, chunk, have);
-        return fail_hip(be, where);
-    };
-    e = create(0, ka, split ? 2 : 1);
-    if (e != hipSuccess) return bail(e, "hipMemCreate (out of device memory?)");
-    if (split) {
-        // the gap: as many handles as bring run B's start 32 GiB behind run A's; best effort (a full device just gets less distance)
-        const size_t run_a = ka * chunk, want = run_a < TRAJ_SLICE ? (TRAJ_SLICE - run_a) / chunk : 0;
-        gap.reserve(want);
-        for (size_t i = 0; i < want; ++i) {
-            hipMemGenericAllocationHandle_t g;
-            if (hipMemCreate(&g, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
-            gap.push_back(g);
+        if (r + 1 < runs) {
+            // the gap: as many handles as bring the next run's start 32 GiB behind this one's; best effort (a full device gets less)
+            const size_t run_bytes = in_run * chunk, want = run_bytes < TRAJ_SLICE ? (TRAJ_SLICE - run_bytes) / chunk : 0;
+            for (size_t g = 0; g < want; ++g) {
+                hipMemGenericAllocationHandle_t x;
+                if (hipMemCreate(&x, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+                gap.push_back(x);
+            }
         }
-        e = create(1, k - ka, 2);
-        if (e != hipSuccess && !gap.empty()) {                      // the gap took what run B needed: give it back and try again
-            for (auto g : gap) (void)hipMemRelease(g);
-            gap.clear();
-            (void)hipGetLastError();
-            e = create(1 + 2 * (made - ka), k - made, 2);
-        }
-        if (e != hipSuccess) return bail(e, "hipMemCreate (out of device memory?)");
-        for (auto g : gap) (void)hipMemRelease(g);
-        gap.clear();
     }
+    drop_gap();
     size_t mapped = 0;
     for (size_t j = 0; j < k; ++j) {
         e = hipMemMap(va + j * chunk, chunk, 0, hs[j], 0);

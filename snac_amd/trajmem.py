@@ -1,9 +1,10 @@
-"""Trajectory tensors backed by snac_traj_alloc (include/snac_hip.h): memory from the HIP virtual-memory API.
+"""Trajectory tensors backed by snac_traj_alloc (include/snac_hip.h): one contiguous virtual range over three runs of physical
+memory 32 GiB apart (HIP virtual-memory API), 32 MB chunks taking turns.
 
-On MI355X the multi-GB output of a fused rollout is written 10-20 % faster into such memory than into a hipMalloc block -- which is
-what torch.empty() hands out; PyTorch-ROCm's own virtual-memory mode (expandable segments) is not available on this platform --
-(tools/wr_vmm.hip).  traj_empty() returns an ordinary torch tensor viewing one block; the block is unmapped
-and released when the tensor's storage dies.  PyTorch is plumbing here: it only learns the pointer.
+On MI355X write streams confined to one 32 GiB slice of the physical address space reach ~5.7 TB/s, spread over several ~7.1
+(tools/wr_blocks.hip); torch.empty() hands out hipMalloc memory -- one physical run -- and PyTorch-ROCm's own
+virtual-memory mode (expandable segments) is not available on this platform.  traj_empty() returns an ordinary torch tensor viewing
+one block; the block is unmapped and released when the tensor's storage dies.  PyTorch is plumbing here: it only learns the pointer.
 """
 import ctypes as C
 

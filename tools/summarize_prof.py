@@ -27,6 +27,20 @@ for f in find("trace/**/*kernel_trace.csv"):
             durs[name].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
             meta[name] = {k: row.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size")}
     print("== kernel trace:", os.path.relpath(f, out))
+    # bench.py's own launches of the rollout kernel, in order: placement candidates (each on its own tensor, the first with a
+    # warm-up), then the pre-roll, the W warm-up and the K timed passes on the chosen tensor.  The whole-run average mixes the
+    # tensors; the trailing launches are the ones bench.py times.
+    seq = []
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if "k_rollout" in row["Kernel_Name"]:
+                seq.append((int(row["Start_Timestamp"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+    seq = [d for _, d in sorted(seq)]
+    if len(seq) >= 6:
+        tail = seq[-6:]
+        print("rollout launches in order (us): " + " ".join("%.0f" % d for d in seq))
+        print("last 6 launches (1 warm-up + 5 timed passes of profile.sh's bench.py --steps 5 --warmup 1, on the chosen tensor): avg %.1f us min %.1f max %.1f"
+              % (sum(tail) / len(tail), min(tail), max(tail)))
     for name, d in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
         short = name[:90]
         print("%-90s n=%d avg=%.1f us min=%.1f max=%.1f total=%.3f ms %s" % (short, len(d), sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3, sum(d) / 1e6, meta[name]))

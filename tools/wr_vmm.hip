@@ -1,7 +1,8 @@
 // wr_vmm.hip -- can the ONE contiguous [T][N][51] tensor get the 7.1 TB/s of tools/wr_blocks.hip's split tensors?  The virtual
-// range stays contiguous; its physical backing is dealt over two (or four) far-apart pieces with the virtual-memory API:
-// hipMemCreate handles of `chunk` bytes created one after the other (assumed to follow each other in physical memory), virtual
-// chunk j mapped to handle (j % B) * (k / B) + j / B.  Patterns: R = the rollout's rows (plain addresses), W = wave-major.
+// range stays contiguous; its physical backing is dealt over runs of memory a 32 GiB slice apart with the virtual-memory API:
+// hipMemCreate handles of 32 MB created one after the other (they follow each other in physical memory on an idle device), gap
+// handles between the runs (released afterwards), virtual chunk j mapped to run j % runs.  This is what snac_traj_alloc does
+// (snac_amd/csrc/snac_hip.hip).  Patterns: R = the rollout's rows (plain addresses), W = wave-major.
 // build: hipcc -O3 --offload-arch=gfx950 -o wr_vmm wr_vmm.hip ; run: ./wr_vmm
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -39,44 +40,52 @@ void report(const char* what, char* p, size_t bytes) {
     printf("%-72s R %5.2f  W %5.2f TB/s   (R %.3f ms)\n", what, bytes / r / 1e9, bytes / w / 1e9, r);
     fflush(stdout);
 }
+// one contiguous virtual range of `bytes`, backed by `runs` runs of 32 MB handles; consecutive runs start `dist` bytes apart in creation
+// order (gap handles in between, released afterwards); virtual chunk j -> run j % runs.  dist = 0: the runs follow each other directly.
+struct Block { char* va; size_t total, chunk; std::vector<hipMemGenericAllocationHandle_t> h; };
+Block make(size_t bytes, int runs, size_t dist, int dev) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+    Block b; b.chunk = (size_t)32 << 20;
+    const size_t k = ((bytes + b.chunk - 1) / b.chunk + runs - 1) / runs * runs, per = k / runs;
+    b.total = k * b.chunk; b.h.resize(k);
+    std::vector<hipMemGenericAllocationHandle_t> gap;
+    for (int r = 0; r < runs; ++r) {
+        for (size_t i = 0; i < per; ++i) CK(hipMemCreate(&b.h[i * runs + r], b.chunk, &prop, 0));
+        if (r + 1 < runs && dist > per * b.chunk)
+            for (size_t g = 0; g < (dist - per * b.chunk) / b.chunk; ++g) { hipMemGenericAllocationHandle_t x; CK(hipMemCreate(&x, b.chunk, &prop, 0)); gap.push_back(x); }
+    }
+    for (auto x : gap) CK(hipMemRelease(x));
+    CK(hipMemAddressReserve((void**)&b.va, b.total, 0, nullptr, 0));
+    for (size_t j = 0; j < k; ++j) CK(hipMemMap(b.va + j * b.chunk, b.chunk, 0, b.h[j], 0));
+    hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    CK(hipMemSetAccess(b.va, b.total, &acc, 1));
+    return b;
+}
+void drop(Block& b) {
+    CK(hipDeviceSynchronize());
+    for (size_t off = 0; off < b.total; off += b.chunk) CK(hipMemUnmap(b.va + off, b.chunk));
+    for (auto x : b.h) CK(hipMemRelease(x));
+}
 int main() {
     int dev = 0; CK(hipSetDevice(dev));
     const size_t bytes = (size_t)T * WAVES * TILE;
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
-    size_t gran = 0; CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-    size_t gmin = 0; CK(hipMemGetAllocationGranularity(&gmin, &prop, hipMemAllocationGranularityMinimum));
-    printf("allocation granularity: minimum %zu, recommended %zu bytes\n", gmin, gran);
-    { char* p; CK(hipMalloc((void**)&p, bytes)); report("hipMalloc", p, bytes); CK(hipFree(p)); }
-    hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
-    for (size_t chunk_mb : {2048, 256, 32, 2}) {
-        const size_t chunk = chunk_mb << 20;
-        if (chunk % gran) { printf("chunk %zu MB is not a multiple of the granularity\n", chunk_mb); continue; }
-        const size_t k = (bytes + chunk - 1) / chunk;                 // chunks of the tensor
-        // handles: the tensor's k chunks plus a gap of `gap` chunks between the halves, released after mapping
-        for (int B : {1, 2, 4}) {
-            const size_t kk = ((k + B - 1) / B) * B, per = kk / B;
-            const size_t gap = B == 1 ? 0 : ((size_t)8 << 30) / chunk;      // >= 8 GiB of other memory between the pieces
-            std::vector<hipMemGenericAllocationHandle_t> h(kk), pad;
-            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-            size_t made = 0;
-            for (int b = 0; b < B; ++b) {
-                for (size_t i = 0; i < per; ++i) CK(hipMemCreate(&h[made++], chunk, &prop, 0));
-                if (b + 1 < B) for (size_t i = 0; i < gap; ++i) { hipMemGenericAllocationHandle_t g; CK(hipMemCreate(&g, chunk, &prop, 0)); pad.push_back(g); }
-            }
-            char* va = nullptr; CK(hipMemAddressReserve((void**)&va, kk * chunk, 0, nullptr, 0));
-            for (size_t j = 0; j < kk; ++j) CK(hipMemMap(va + j * chunk, chunk, 0, h[(j % B) * per + j / B], 0));
-            CK(hipMemSetAccess(va, kk * chunk, &acc, 1));
-            for (auto g : pad) CK(hipMemRelease(g));
-            char what[160];
-            snprintf(what, sizeof what, "virtual memory: %zu chunks of %zu MB dealt over %d piece(s), >= 8 GiB between", kk, chunk_mb, B);
-            report(what, va, bytes);
-            CK(hipMemUnmap(va, kk * chunk));
-            for (auto x : h) CK(hipMemRelease(x));
-            CK(hipMemAddressFree(va, kk * chunk));
-            CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
-            if (chunk_mb == 2 && B == 2) break;                         // the 2 MB case: one layout is enough (7650 handles)
-        }
+    const size_t G = (size_t)1 << 30;
+    printf("target %.2f GB: R = the rollout's rows in the reference order [T][N][51], W = wave-major; store-only, TB/s\n", bytes / 1e9);
+    for (int round = 0; round < 4; ++round) {
+        printf("-- round %d%s\n", round, round ? " (the allocator has seen allocations and releases by now)" : " (fresh process)");
+        { char* p; CK(hipMalloc((void**)&p, bytes)); report("hipMalloc (one contiguous run)", p, bytes); CK(hipFree(p)); }
+        struct V { const char* what; int runs; size_t dist; } vs[] = {
+            {"virtual memory, one run of 32 MB handles", 1, 0},
+            {"virtual memory, two runs back to back (7.5 GiB apart), chunks taking turns", 2, 0},
+            {"virtual memory, two runs 16 GiB apart, chunks taking turns", 2, 16 * G},
+            {"virtual memory, two runs 32 GiB apart, chunks taking turns", 2, 32 * G},
+            {"virtual memory, two runs 64 GiB apart, chunks taking turns", 2, 64 * G},
+            {"virtual memory, three runs 32 GiB apart, chunks taking turns", 3, 32 * G},
+            {"virtual memory, four runs 16 GiB apart, chunks taking turns", 4, 16 * G},
+            {"virtual memory, four runs 24 GiB apart, chunks taking turns", 4, 24 * G},
+        };
+        for (auto& v : vs) { Block b = make(bytes, v.runs, v.dist, dev); report(v.what, b.va, bytes); drop(b); }
     }
     return 0;
 }
