@@ -281,13 +281,13 @@ def main():
                         obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
     T = args.T or env.total_step
     # Where the 16 GB trajectory tensor lies in HBM is worth 5-9 % of the pass (fast and slow regions of the address map,
-    # snac_amd/placement.py): SNAC_BENCH_PLACE candidates (default 6, 0 / 1 = take the first allocation) are
+    # snac_amd/placement.py): SNAC_BENCH_PLACE candidates (default 3, 0 / 1 = take the first allocation) are
     # allocated, the workload itself -- a scratch batch of the same shape -- is timed on each, the fastest is kept.
     # What those regions are (tools/wr_blocks.hip): slices of 32 GiB of the physical address space -- streams inside one slice write at
     # ~5.7 TB/s, spread over several at ~7.1 -- and a hipMalloc tensor is one physical run.  snac_traj_alloc (snac_amd/trajmem.py) backs
     # ONE virtual range with three runs a slice apart: SNAC_BENCH_MEMORY=vmm (default) | malloc; if such a block cannot be had the run
     # falls back to torch.empty and says so in `placement`.
-    place_n = int(os.environ.get("SNAC_BENCH_PLACE", "4"))
+    place_n = int(os.environ.get("SNAC_BENCH_PLACE", "3"))
     memory = os.environ.get("SNAC_BENCH_MEMORY", "vmm")
     traj_alloc = None
     if memory == "vmm":

@@ -203,14 +203,17 @@ int snac_stream_sync(void* stream);
  * loop (multiprocess.py:78-84) drops each step's arrays.  On MI355X the physical address space behaves as slices of 32 GiB:
  * write streams confined to one slice reach ~5.7 TB/s, spread over two or more ~7.1 (tools/wr_blocks.hip).
  * A hipMalloc block of 16 GB is one physical run, inside one slice unless it happens to straddle a boundary.  A block from here
- * is ONE contiguous virtual range backed -- through the HIP virtual-memory API -- by three runs of physical memory 32 GiB apart,
- * 32 MB chunks taking turns, so the [T][N][obs_dim] output of snac_rollout keeps several slices busy at any time: the headline
- * pass takes 2.3-2.5 ms instead of 2.75-2.95 (tools/mem_ab.py).  Where the driver really puts a handle is not under the
- * library's control; callers that care time their workload on a few blocks and keep the best (snac_amd/placement.py).
- *   snac_traj_alloc   `bytes` (rounded up to whole 32 MB handles, or 2 MB pages below that; blocks under 256 MB are one run) on
- *                     `device`, read / write for that device; *out is an ordinary device pointer, contiguous, 2 MB-aligned.
- *                     While it runs it holds up to 2 x 32 GiB more (the gaps between the runs), released before it returns; on a
- *                     full device the gaps shrink.  SNAC_ERR_HIP when memory runs out.
+ * is ONE contiguous virtual range backed -- through the HIP virtual-memory API -- by 32 MB chunks of physical memory from
+ * different slices taking turns, so the [T][N][obs_dim] output of snac_rollout keeps two slices busy at any time: the headline
+ * pass takes 2.33-2.40 ms instead of 2.75-2.95 (tools/mem_ab.py).  Which slice a chunk lies in cannot be asked of the driver; it
+ * is measured: a pool of handles (the block + 64 GiB) is mapped into a scratch range and every group of 16 handles is timed
+ * together with a reference group under the rollout's own store pattern -- partners in another slice run 20 % faster.
+ *   snac_traj_alloc   `bytes` (rounded up to whole 32 MB handles, or 2 MB pages below that; blocks under 1 GiB are one plain
+ *                     run) on `device`, read / write for that device; *out is an ordinary device pointer, contiguous, 2 MB-
+ *                     aligned.  Takes 1.5-2.5 s for a large block and holds up to 64 GiB more while it runs (the pool; on a
+ *                     full device it shrinks, and without a usable measurement the block falls back to three runs created
+ *                     32 GiB apart); launches its probe on the null stream.  SNAC_ERR_HIP when memory runs out.
+ *                     SNAC_TRAJ_PROBE=0 skips the measurement, SNAC_TRAJ_DEBUG=1 prints it.
  *   snac_traj_free    waits for the device to go idle, unmaps and releases the block's memory (its address range stays reserved
  *                     and is never handed out again: a stale pointer faults); NULL is a no-op; a pointer that did not come from
  *                     snac_traj_alloc is SNAC_ERR_ARG.

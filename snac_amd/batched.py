@@ -323,13 +323,13 @@ class BatchedDMPEnv:
         self.t += T
         return o, reward, (done.view(torch.bool) if done is not None else None)
 
-    def alloc_trajectory(self, T, candidates=3, reps=3, layout="ticks", memory="vmm"):
+    def alloc_trajectory(self, T, candidates=2, reps=3, layout="ticks", memory="vmm"):
         """The [T, N, obs_dim] output tensor of rollout(T, out=...), allocated where this batch's rollout writes fastest.  On
         MI355X write streams confined to one 32 GiB slice of the physical address space reach ~5.7 TB/s, spread over several
-        ~7.1 (DESIGN.md section 5): memory="vmm" (default) takes the tensor from snac_traj_alloc (snac_amd/trajmem.py: one virtual
-        range over three physical runs a slice apart), memory="malloc" from torch.empty (hipMalloc: one run).  Where the driver
-        puts a run is not ours to say, so `candidates` tensors are allocated, a copy of this batch rolls out into each and the
-        fastest is kept (snac_amd/placement.py).  The batch itself is not stepped.  layout "tiled": the tensor of
+        ~7.1 (DESIGN.md section 3): memory="vmm" (default) takes the tensor from snac_traj_alloc (snac_amd/trajmem.py: one virtual
+        range over chunks from two slices taking turns, found by measurement; 1.5-2.5 s per block), memory="malloc" from
+        torch.empty (hipMalloc: one run).  `candidates` tensors are allocated, a copy of this batch rolls out into each and the
+        fastest is kept (snac_amd/placement.py; blocks differ by 1-3 % now, hipMalloc tensors by 5-9 %).  The batch itself is not stepped.  layout "tiled": the tensor of
         rollout(obs="tiled").  Returns (tensor, report)."""
         from . import placement
 

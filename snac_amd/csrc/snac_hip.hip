@@ -20,6 +20,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -2463,21 +2464,21 @@ int snac_export_grid(const snac_env_desc* d, const snac_state* st, double* out, 
 // top out at ~5.7 TB/s, the same streams spread over two or more slices reach ~7.1 (tools/wr_blocks.hip, profiles/; the split
 // may be as coarse as 128 MB pieces taking turns).  A tensor from hipMalloc is one contiguous run of at most 16 GB -- inside one
 // slice unless it happens to straddle a boundary, which is all the "fast and slow regions" of the address map ever were.  The
-// virtual-memory API lets ONE contiguous virtual range be backed by several runs of physical memory a slice apart: handles of
-// 32 MB are created back to back (run 0, a gap that brings the distance to 32 GiB, run 1, a gap, run 2; consecutive handles tend
-// to follow each other in physical memory), virtual chunk j is mapped to run j % 3, the gaps are released.  Three runs, not two:
-// where a handle really lands is the driver's business (after allocations and releases the order is no longer monotonic), and
-// with three runs at least two slices take part in every case measured (tools/wr_vmm.hip: 6.9-7.1 TB/s in four of four layouts,
-// two runs 5.7-7.1).  Nothing about the tensor changes for its users.  The caller owns the block and frees it with
-// snac_traj_free; the library keeps only the bookkeeping needed to unmap it.
+// virtual-memory API lets ONE contiguous virtual range be backed by 32 MB handles from different slices taking turns; nothing
+// about the tensor changes for its users.  Which slice a handle lies in cannot be asked, so it is measured (traj_alloc_probed
+// below: a pool of handles, each group of 16 timed together with a reference group; 1.5-2.5 s per block).  The fallback when that
+// is not to be had: handles created back to back -- run 0, a gap that brings the distance to 32 GiB, run 1, a gap, run 2 --,
+// virtual chunk j mapped to run j % 3, the gaps released; consecutive handles follow each other in physical memory only on an
+// allocator that has seen no releases, so that layout is a lottery (5.7-7.1 TB/s, tools/wr_vmm.hip) where the probed one is not.
+// The caller owns the block and frees it with snac_traj_free; the library keeps only the bookkeeping needed to unmap it.
 namespace {
-struct TrajBlock { size_t total, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
+struct TrajBlock { size_t total, chunk; int device; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_traj_mu;
 std::unordered_map<void*, TrajBlock> g_traj;
 constexpr size_t TRAJ_CHUNK = (size_t)32 << 20;   // one physical handle per 32 MB: 480 handles for the headline's 16 GB
 constexpr size_t TRAJ_SLICE = (size_t)32 << 30;   // distance between the starts of consecutive runs
 constexpr int TRAJ_RUNS = 3;
-constexpr size_t TRAJ_SPLIT_MIN = (size_t)256 << 20;   // smaller blocks are not bound by where they lie: one run
+constexpr size_t TRAJ_SPLIT_MIN = (size_t)1 << 30;     // smaller blocks are not worth the two seconds: one run
 
 // Unmap chunk by chunk (each call undoes exactly one hipMemMap), release the physical handles -- and KEEP the address range
 // reserved: a range that is handed out again right after an unmap has been seen to serve stale translations (a fresh block at a
@@ -2487,6 +2488,161 @@ void traj_release(char* va, size_t mapped, size_t chunk, std::vector<hipMemGener
     for (size_t off = 0; off < mapped; off += chunk) (void)hipMemUnmap(va + off, chunk);
     for (auto h : hs) (void)hipMemRelease(h);
     (void)hipGetLastError();
+}
+
+// ---- the probed layout -------------------------------------------------------------------------------------------------------
+// Where a handle lands is the driver's business, so the block is built from what a measurement says: a pool of 32 MB handles
+// (the tensor + 64 GiB, created back to back) is mapped into a scratch range and taken in groups of 16 (512 MB); group 0 is the
+// reference, and every other group is timed TOGETHER with it -- the rollout's own store pattern over the two groups' chunks taking
+// turns, 1 GiB per probe, ~0.17 ms.  Pairs in different slices run at ~7 TB/s, pairs in the same slice at ~5.7: the times fall into
+// two classes, "far" (another slice than the reference) and "near" (its own).  The block then alternates near and far chunks.
+// No contrast (a pool inside one slice, a driver that scatters handles below the group size), too few groups of a class, or
+// no memory for the pool: the caller falls back to the fixed three-run layout.
+constexpr size_t TRAJ_GROUP = 16;                                // chunks per probed group
+constexpr int PROBE_E = 64, PROBE_D = 51;                        // the rollout's tile: 64 rows of 51 doubles per wave and step
+
+__global__ __launch_bounds__(256) void k_traj_probe(char* a, char* b, int chunk_log2, int chunks_total) {
+    constexpr size_t TILE = (size_t)PROBE_E * PROBE_D * 8;
+    const int lane = threadIdx.x & 63, wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), waves = (int)gridDim.x * 4;
+    const size_t total = (size_t)chunks_total << chunk_log2, mask = ((size_t)1 << chunk_log2) - 1;
+    const int steps = (int)(total / ((size_t)waves * TILE));
+    for (int t = 0; t < steps; ++t) {
+        const size_t L0 = ((size_t)t * waves + wave) * TILE + (size_t)lane * 8;
+#pragma unroll 8
+        for (int e = 0; e < PROBE_E; ++e)
+            if (lane < PROBE_D) {
+                const size_t L = L0 + (size_t)e * (PROBE_D * 8), c = L >> chunk_log2;      // logical chunk c -> a or b in turn
+                *(double*)(((c & 1) ? b : a) + ((c >> 1) << chunk_log2) + (L & mask)) = (double)(t + e);
+            }
+    }
+}
+
+// 0: *out holds the block; 1: not applicable / no contrast (nothing allocated: use the fixed layout); < 0: error code
+int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop, size_t gran, void** out) {
+    const size_t chunk = TRAJ_CHUNK;
+    if (chunk % gran) return 1;
+    const size_t k = (bytes + chunk - 1) / chunk, kg = (k + TRAJ_GROUP - 1) / TRAJ_GROUP;
+    const size_t want_groups = kg + (2 * TRAJ_SLICE) / (TRAJ_GROUP * chunk);
+    const bool debug = std::getenv("SNAC_TRAJ_DEBUG") != nullptr;
+    std::vector<hipMemGenericAllocationHandle_t> pool;
+    pool.reserve(want_groups * TRAJ_GROUP);
+    for (size_t i = 0; i < want_groups * TRAJ_GROUP; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+        pool.push_back(h);
+    }
+    size_t groups = pool.size() / TRAJ_GROUP;
+    while (pool.size() > groups * TRAJ_GROUP) { (void)hipMemRelease(pool.back()); pool.pop_back(); }
+    auto give_up = [&](char* va, size_t mapped) {
+        traj_release(va, mapped, chunk, pool);
+        return 1;
+    };
+    if (groups < kg + 8) return give_up(nullptr, 0);             // not enough memory for a pool worth probing
+    char* scratch = nullptr;
+    if (hipMemAddressReserve((void**)&scratch, pool.size() * chunk, gran, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return give_up(nullptr, 0); }
+    size_t mapped = 0;
+    for (size_t i = 0; i < pool.size(); ++i) {
+        if (hipMemMap(scratch + i * chunk, chunk, 0, pool[i], 0) != hipSuccess) { (void)hipGetLastError(); return give_up(scratch, mapped); }
+        mapped += chunk;
+    }
+    hipMemAccessDesc acc;
+    std::memset(&acc, 0, sizeof(acc));
+    acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(scratch, mapped, &acc, 1) != hipSuccess) { (void)hipGetLastError(); return give_up(scratch, mapped); }
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != device) (void)hipSetDevice(device);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    const size_t gbytes = TRAJ_GROUP * chunk;
+    auto probe = [&](size_t ga, size_t gb, bool timed) -> float {
+        if (timed) (void)hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(k_traj_probe, dim3(256), dim3(256), 0, nullptr, scratch + ga * gbytes, scratch + gb * gbytes, 25, (int)(2 * TRAJ_GROUP));
+        if (!timed) return 0.f;
+        (void)hipEventRecord(e1, nullptr);
+        if (hipEventSynchronize(e1) != hipSuccess) { ok = false; return 0.f; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ok = false;
+        return ms;
+    };
+    std::vector<size_t> order_a, order_b;                        // groups of class A (the reference's slice) / class B, best first
+    size_t na = 0, nb = 0;
+    if (ok) {
+        for (int i = 0; i < 120; ++i) probe(0, 1, false);        // ~20 ms of the probe itself: the clocks are up before anything is timed
+        if (hipGetLastError() != hipSuccess) ok = false;
+        std::vector<char> todo(groups, 1);                       // groups not yet assigned to a reference's slice
+        size_t ref = 0;
+        for (int round = 0; round < 4 && ok; ++round) {
+            std::vector<float> t(groups, 0.f);
+            float lo = 1e30f, hi = 0.f;
+            for (size_t g = 0; g < groups; ++g) {
+                if (g == ref || !todo[g]) continue;
+                const float t1 = probe(ref, g, true), t2 = probe(ref, g, true);
+                t[g] = t1 < t2 ? t1 : t2;
+                lo = t[g] < lo ? t[g] : lo; hi = t[g] > hi ? t[g] : hi;
+            }
+            if (debug) {
+                std::fprintf(stderr, "snac_traj_alloc: probe round %d, reference group %zu, %zu groups, %.3f .. %.3f ms:", round, ref, groups, lo, hi);
+                for (size_t g = 0; g < groups; ++g) std::fprintf(stderr, " %.0f", t[g] * 1000.f);
+                std::fprintf(stderr, "\n");
+            }
+            if (!ok || hi < lo * 1.10f) break;                   // no contrast: every group behaves the same against this reference
+            const float thr = 0.5f * (lo + hi);
+            std::vector<size_t> near{ref}, far;
+            for (size_t g = 0; g < groups; ++g) if (g != ref && todo[g]) (t[g] >= thr ? near : far).push_back(g);
+            // class A = this reference's slice if it can carry half the block, else look at the far groups from one of their own
+            size_t aside = 0;                                    // groups of earlier references' slices: class B material
+            for (size_t g = 0; g < groups; ++g) aside += todo[g] ? 0 : 1;
+            if (near.size() * TRAJ_GROUP >= (k + 1) / 2 && (far.size() + aside) * TRAJ_GROUP >= k / 2) {
+                // the clearest cases first: the slowest partners are surest to share the reference's slice, the fastest surest not to
+                // (in-between times are groups that straddle two regions)
+                std::sort(near.begin() + 1, near.end(), [&](size_t x, size_t y) { return t[x] > t[y]; });
+                std::sort(far.begin(), far.end(), [&](size_t x, size_t y) { return t[x] < t[y]; });
+                for (size_t g : near) order_a.push_back(g);
+                for (size_t g : far) order_b.push_back(g);
+                for (size_t g = 0; g < groups; ++g) if (!todo[g]) order_b.push_back(g);    // earlier references' slices: not this one
+                na = nb = 1;
+                break;
+            }
+            if (far.empty()) break;
+            for (size_t g : near) todo[g] = 0;                   // too small a slice share: set it aside, it will serve as class B
+            ref = far[0];
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipDeviceSynchronize();
+    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    if (!ok || !na || !nb) return give_up(scratch, mapped);
+    // the block: chunk j from class A (j even) or B (j odd), groups in pool order
+    std::vector<size_t> ca, cb;
+    for (size_t g : order_a) for (size_t i = 0; i < TRAJ_GROUP; ++i) ca.push_back(g * TRAJ_GROUP + i);
+    for (size_t g : order_b) for (size_t i = 0; i < TRAJ_GROUP; ++i) cb.push_back(g * TRAJ_GROUP + i);
+    if (ca.size() < (k + 1) / 2 || cb.size() < k / 2) return give_up(scratch, mapped);
+    std::vector<char> used(pool.size(), 0);
+    std::vector<hipMemGenericAllocationHandle_t> hs(k);
+    for (size_t j = 0; j < k; ++j) { const size_t idx = (j & 1) ? cb[j >> 1] : ca[j >> 1]; hs[j] = pool[idx]; used[idx] = 1; }
+    for (size_t off = 0; off < mapped; off += chunk) (void)hipMemUnmap(scratch + off, chunk);   // the scratch range stays reserved, unused
+    for (size_t i = 0; i < pool.size(); ++i) if (!used[i]) (void)hipMemRelease(pool[i]);
+    (void)hipGetLastError();
+    char* va = nullptr;
+    const size_t total = k * chunk;
+    hipError_t e = hipMemAddressReserve((void**)&va, total, gran, nullptr, 0);
+    if (e != hipSuccess) { traj_release(nullptr, 0, chunk, hs); return fail_hip(e, "hipMemAddressReserve"); }
+    size_t m2 = 0;
+    for (size_t j = 0; j < k; ++j) {
+        e = hipMemMap(va + j * chunk, chunk, 0, hs[j], 0);
+        if (e != hipSuccess) { traj_release(va, m2, chunk, hs); return fail_hip(e, "hipMemMap"); }
+        m2 += chunk;
+    }
+    e = hipMemSetAccess(va, total, &acc, 1);
+    if (e != hipSuccess) { traj_release(va, m2, chunk, hs); return fail_hip(e, "hipMemSetAccess"); }
+    {
+        std::lock_guard<std::mutex> lk(g_traj_mu);
+        g_traj[va] = TrajBlock{total, chunk, device, std::move(hs)};
+    }
+    *out = va;
+    return 0;
 }
 }  // namespace
 
@@ -2505,6 +2661,13 @@ int snac_traj_alloc(size_t bytes, int device, void** out) {
     e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
     if (e != hipSuccess) return fail_hip(e, "hipMemGetAllocationGranularity");
     if (gran < ((size_t)2 << 20)) gran = (size_t)2 << 20;          // whole 2 MB pages whatever the minimum is
+    if (bytes >= TRAJ_SPLIT_MIN) {                                // the measured layout first; 1 = not to be had, take the fixed one
+        const char* off = std::getenv("SNAC_TRAJ_PROBE");
+        if (!(off && off[0] == '0')) {
+            const int rc = traj_alloc_probed(bytes, device, prop, gran, out);
+            if (rc <= 0) return rc;
+        }
+    }
     const size_t chunk = bytes >= TRAJ_CHUNK ? ((TRAJ_CHUNK + gran - 1) / gran) * gran : ((bytes + gran - 1) / gran) * gran;
     const size_t k = (bytes + chunk - 1) / chunk, total = k * chunk;
     const int runs = (bytes >= TRAJ_SPLIT_MIN && k >= (size_t)TRAJ_RUNS) ? TRAJ_RUNS : 1;   // run r: chunks r, r + runs, r + 2 runs, ...
@@ -2561,7 +2724,7 @@ int snac_traj_alloc(size_t bytes, int device, void** out) {
     if (e != hipSuccess) { traj_release(va, mapped, chunk, hs); return fail_hip(e, "hipMemSetAccess"); }
     {
         std::lock_guard<std::mutex> lk(g_traj_mu);
-        g_traj[va] = TrajBlock{total, chunk, std::move(hs)};
+        g_traj[va] = TrajBlock{total, chunk, device, std::move(hs)};
     }
     *out = va;
     return SNAC_OK;
@@ -2577,7 +2740,11 @@ int snac_traj_free(void* ptr) {
         b = std::move(it->second);
         g_traj.erase(it);
     }
-    (void)hipDeviceSynchronize();                                // nothing may still be writing into the block
+    int cur = -1;                                                // nothing may still be writing into the block: its device goes idle
+    (void)hipGetDevice(&cur);
+    if (cur != b.device) (void)hipSetDevice(b.device);
+    (void)hipDeviceSynchronize();
+    if (cur >= 0 && cur != b.device) (void)hipSetDevice(cur);
     traj_release((char*)ptr, b.total, b.chunk, b.handles);
     return SNAC_OK;
 }

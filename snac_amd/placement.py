@@ -4,9 +4,10 @@ On MI355X the physical address space behaves as slices of 32 GiB: write streams 
 same streams spread over two or more ~7.1 (tools/wr_blocks.hip, tools/wr_vmm.hip).  A hipMalloc tensor of
 16 GB is one physical run: slow unless it happens to straddle a slice boundary -- which is why the same rollout takes 2.70 to
 2.97 ms in twelve tensors allocated one after the other, each reproducibly.  snac_traj_alloc (snac_amd/trajmem.py) backs one
-virtual range with three runs a slice apart; where the driver really puts them is its own business, so the last word is a
-measurement: fastest_tensor() allocates a few candidates, runs the caller's own workload into each and keeps the fastest.  A
-trajectory buffer is allocated once and written millions of times; half a second of probing at start-up buys 15-20 % on every pass.
+virtual range with chunks from two slices taking turns, the slices found by a measurement of its own; blocks built that way differ
+by 1-3 %.  Either way the last word is the workload: fastest_tensor() allocates a few candidates, runs the caller's own rollout
+into each and keeps the fastest.  A trajectory buffer is allocated once and written millions of times; a few seconds at start-up
+buy 15-20 % on every pass.
 """
 import torch
 
@@ -17,7 +18,7 @@ def fastest_tensor(shape, dtype, device, run, candidates=6, reps=3, min_bytes=1 
     on each, keep the fastest and release the rest.  Returns (tensor, report) with report = {"candidates_ms": [...], "chosen": i}.
     Tensors below `min_bytes` (256 MB) are not probed: the regions are GBs wide, a small tensor is not bound by its place.
     alloc(shape, dtype, device) -> tensor replaces torch.empty as the source of the candidates (snac_amd.trajmem.traj_empty:
-    one virtual range over three physical runs 32 GiB apart)."""
+    one virtual range over chunks from two slices of physical memory)."""
     if alloc is None:
         def alloc(shape, dtype, device):
             return torch.empty(shape, dtype=dtype, device=device)

@@ -22,12 +22,14 @@ def _ptr(t):
 
 
 class ReplayRing:
-    def __init__(self, env, capacity_ticks, layout="ticks", place_candidates=0):
+    def __init__(self, env, capacity_ticks, layout="ticks", place_candidates=0, memory="auto"):
         """env: BatchedDMPEnv (already reset); capacity_ticks: ring length in vector steps (>= 2).
         layout "ticks": obs[cap, N, D]; "tiled": obs[ceil(N / 64), cap, 64, D] -- a tile of 64 envs streams through its own
         contiguous region of the ring (SNAC_OBS_TILED: the faster layout to collect into); row(slot, env) and
-        obs_at(slot) read either.  place_candidates > 1: the observation ring is placed by env.alloc_trajectory (that many
-        candidate tensors timed with the rollout itself, the fastest kept: where a multi-GB ring lies in HBM is worth 5-25 %)."""
+        obs_at(slot) read either.  memory: where the observation ring lives -- "vmm": a snac_traj_alloc block (one virtual range
+        over chunks from two 32 GiB slices of physical memory: MI355X writes it 15-20 % faster), "malloc":
+        torch.empty, "auto" (default): "vmm" from 1 GiB up.  place_candidates > 1: the ring is placed by env.alloc_trajectory (that many
+        candidate blocks timed with the rollout itself, the fastest kept: where the driver puts a block's runs still matters)."""
         if capacity_ticks < 2:
             raise ValueError("capacity_ticks must be >= 2")
         if layout not in ("ticks", "tiled"):
@@ -37,10 +39,21 @@ class ReplayRing:
         self.tiled = layout == "tiled"
         N, D, dev = env.num_envs, env.obs_dim, env.device
         self.placement = None
+        if memory not in ("auto", "vmm", "malloc"):
+            raise ValueError("memory must be 'auto', 'vmm' or 'malloc'")
+        shape = ((N + 63) // 64, self.cap, 64, D) if self.tiled else (self.cap, N, D)
+        nbytes = shape[0] * shape[1] * shape[2] * (shape[3] if self.tiled else 1) * torch.empty((), dtype=env.obs_dtype).element_size()
+        if memory == "auto":
+            memory = "vmm" if nbytes >= (1 << 30) else "malloc"
         if place_candidates and place_candidates > 1:
-            self.obs, self.placement = env.alloc_trajectory(self.cap, candidates=int(place_candidates), layout=layout)
+            self.obs, self.placement = env.alloc_trajectory(self.cap, candidates=int(place_candidates), layout=layout, memory=memory)
+        elif memory == "vmm":
+            from . import trajmem
+
+            self.obs = trajmem.traj_empty(shape, env.obs_dtype, dev)
         else:
-            self.obs = torch.empty(((N + 63) // 64, self.cap, 64, D) if self.tiled else (self.cap, N, D), dtype=env.obs_dtype, device=dev)
+            self.obs = torch.empty(shape, dtype=env.obs_dtype, device=dev)
+        self.memory = memory
         self.reward = torch.zeros((self.cap, N), dtype=torch.float32, device=dev)
         self.done = torch.zeros((self.cap, N), dtype=torch.uint8, device=dev)
         self.action = torch.zeros((self.cap, N), dtype=torch.int8, device=dev)

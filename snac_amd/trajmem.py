@@ -1,10 +1,10 @@
-"""Trajectory tensors backed by snac_traj_alloc (include/snac_hip.h): one contiguous virtual range over three runs of physical
-memory 32 GiB apart (HIP virtual-memory API), 32 MB chunks taking turns.
+"""Trajectory tensors backed by snac_traj_alloc (include/snac_hip.h): one contiguous virtual range over 32 MB chunks of physical
+memory from different 32 GiB slices of the address space taking turns (HIP virtual-memory API; the slices are found by measurement).
 
-On MI355X write streams confined to one 32 GiB slice of the physical address space reach ~5.7 TB/s, spread over several ~7.1
-(tools/wr_blocks.hip); torch.empty() hands out hipMalloc memory -- one physical run -- and PyTorch-ROCm's own
-virtual-memory mode (expandable segments) is not available on this platform.  traj_empty() returns an ordinary torch tensor viewing
-one block; the block is unmapped and released when the tensor's storage dies.  PyTorch is plumbing here: it only learns the pointer.
+On MI355X write streams confined to one slice reach ~5.7 TB/s, spread over two ~7.1 (tools/wr_blocks.hip);
+torch.empty() hands out hipMalloc memory -- one physical run -- and PyTorch-ROCm's own virtual-memory mode (expandable segments) is
+not available on this platform.  traj_empty() returns an ordinary torch tensor viewing one block; the block is unmapped and released
+when the tensor's storage dies.  A block of 1 GiB or more takes 1.5-2.5 s to build.  PyTorch is plumbing here: it only learns the pointer.
 """
 import ctypes as C
 

@@ -54,7 +54,10 @@ int main() {
     double* d_obs;
     float* d_rew;
     uint8_t* d_done;
-    HIP_OK(hipMalloc((void**)&d_obs, (size_t)T * N * 51 * 8));
+    // the trajectory in trajectory memory (snac_traj_alloc: one virtual range over chunks from two slices of physical memory), asked
+    // for generously so that the block takes the measured layout (>= 1 GiB); everything else stays hipMalloc'ed
+    const size_t obs_bytes = (size_t)T * N * 51 * 8, block_bytes = obs_bytes < ((size_t)1100 << 20) ? ((size_t)1100 << 20) : obs_bytes;
+    SNAC_CHECK(snac_traj_alloc(block_bytes, 0, (void**)&d_obs));
     HIP_OK(hipMalloc((void**)&d_rew, (size_t)T * N * 4));
     HIP_OK(hipMalloc((void**)&d_done, (size_t)T * N));
     hipStream_t stream;
@@ -143,6 +146,7 @@ int main() {
     HIP_OK(hipMemcpy(o5.data(), d_obs, o5.size() * 8, hipMemcpyDeviceToHost));
     ok = ok && std::memcmp(o5.data(), o4.data(), o5.size() * 8) == 0;
     orc_batch_destroy(b);
+    SNAC_CHECK(snac_traj_free(d_obs));
     std::printf("%s: %d envs x %d ticks, %lld episodes (oracle %lld); %d tree edges, import / export, equality\n",
                 ok ? "PARITY OK" : "MISMATCH", N, T, eps, eps2, M);
     return ok ? 0 : 8;

@@ -193,7 +193,10 @@ def test_tiled_ring_equals_the_tick_ring(n):
     for e, layout in zip(envs, ("ticks", "tiled")):
         e.reset()
         e.rollout(13, obs=None)                                       # attach in mid-episode
-        rings.append(ReplayRing(e, 48, layout=layout, place_candidates=3 if layout == "tiled" else 0))
+        # the tile-major ring in trajectory memory (snac_traj_alloc), the tick ring in torch.empty memory
+        rings.append(ReplayRing(e, 48, layout=layout, place_candidates=3 if layout == "tiled" else 0,
+                                memory="vmm" if layout == "tiled" else "malloc"))
+    assert rings[1].memory == "vmm" and rings[1].obs.data_ptr() % (2 << 20) == 0 and rings[0].memory == "malloc"
     for T in (20, 30, 48, 7):
         for r in rings:
             r.collect(T)

@@ -51,10 +51,16 @@ def test_traj_empty_is_an_ordinary_tensor_and_is_released():
     assert float(v[0, 0].item()) == 51000.0
     big = trajmem.traj_empty((1 << 30,), torch.uint8, "cuda")    # 1 GiB: visible in the driver's free-memory figure
     assert torch.cuda.mem_get_info()[0] <= free0 - (1 << 30) + (64 << 20)
-    big.zero_()
-    del big, v
+    # a block of this size takes the measured layout (probe of a handle pool, near / far chunks in turn): every one of its 32
+    # chunks must be its own memory -- a counter written through the whole block reads back intact
+    words = big.view(torch.int64)
+    words.copy_(torch.arange(words.numel(), dtype=torch.int64, device="cuda"))
+    assert bool((words[1:] - words[:-1] == 1).all()) and int(words[-1].item()) == words.numel() - 1
+    assert int(words[::4099].sum().item()) == sum(range(0, words.numel(), 4099))
+    del big, v, words
     gc.collect()
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()                                     # the temporaries of the checks above (torch caches them)
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)    # both blocks went back
 
 

@@ -122,9 +122,8 @@ int main(int argc, char** argv) {
         for (int B : {2, 4})
             for (size_t smb : {32, 128, 512, 2048, 8192, 16384, 24576}) {
                 const size_t stride = smb << 20;
-                if (stride < bytes / B + ((size_t)2 << 20)) { if (smb < 8192) { /* pieces would overlap: interleave pieces instead */ } }
                 if (first + (size_t)(B - 1) * stride + bytes / B + ((size_t)4 << 20) > total) continue;
-                if (stride < bytes / B + ((size_t)4 << 20)) continue;
+                if (stride < bytes / B + ((size_t)4 << 20)) continue;          // the pieces would overlap
                 float r = best_of([&] { hipLaunchKernelGGL(k_c, dim3(256), dim3(256), 0, 0, slab, first, B, stride, 21); });
                 printf("2 MB chunks over %d pieces %5zu MiB apart: %5.2f TB/s\n", B, smb, bytes / r / 1e9);
                 fflush(stdout);
