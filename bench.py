@@ -27,8 +27,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic bytes per env-step (DESIGN.md "Roofline"); f32 = the same with 4-byte observations
-ALG_BYTES = {(2, "f64"): 481, (2, "f32"): 277, (1, "f64"): 88, (1, "f32"): 60, (3, "f64"): 574, (3, "f32"): 370}
+# SURVEY.md section 8d's per-env-step figure: an UN-FUSED step (state and window read, scalars written back); f32 = the same with
+# 4-byte observations.  Reported as roofline.contract -- the fused launch keeps state and window on chip, so since the trajectory
+# memory went in this figure / time comes out ABOVE the 8 TB/s peak, which no launch can be
+CONTRACT_BYTES = {(2, "f64"): 481, (2, "f32"): 277, (1, "f64"): 88, (1, "f32"): 60, (3, "f64"): 574, (3, "f32"): 370}
+# per-env state a launch loads once and stores once: header 16 + episode 4 + grid record + episodic sums 24
+STATE_BYTES = {1: 16 + 4 + 64 + 24, 2: 16 + 4 + 80 + 24, 3: 16 + 4 + 800 + 24}
 # bytes the fused rollout really writes per env-step: the observation row + reward (4) + done (1); state stays on chip
 WRITTEN_BYTES = {(2, "f64"): 413, (2, "f32"): 209, (1, "f64"): 61, (1, "f32"): 33, (3, "f64"): 413, (3, "f32"): 209}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -445,8 +449,12 @@ def main():
     if rank == 0:
         total_steps = world * n * T * args.steps
         dkey = "f32" if args.obs_f32 else "f64"
-        alg = ALG_BYTES[(args.kind, dkey)]
+        # algorithmic bytes of the FUSED launch: what any implementation of T fused steps has to move through HBM -- every
+        # observation row + reward + done written, the state loaded and stored once (2D: 413 + 248 / 600 = 413.4 B per env-step)
+        alg = WRITTEN_BYTES[(args.kind, dkey)] + 2.0 * STATE_BYTES[args.kind] / T
         achieved = alg * n * T / (kern_ms * 1e-3) / 1e9
+        contract = CONTRACT_BYTES[(args.kind, dkey)]
+        achieved_contract = contract * n * T / (kern_ms * 1e-3) / 1e9
         s = stats.tolist()
         # measured HBM bytes per launch (rocprofv3 PMC passes of this same command, tools/profile.sh ->
         # profiles/traffic.json), turned into GB/s with the live launch duration; null for other workloads
@@ -486,9 +494,10 @@ def main():
                          "written": written,                      # output bytes of the launch / its duration, GB/s
                          "frac_of_measured_write": ((traffic or written) / wpeak) if wpeak else None,
                          "kernel": kernel_name, "kernel_ms": kern_ms, "alg_bytes_per_env_step": alg,
-                         "note": "achieved / frac price the launch at the un-fused contract figure (SURVEY.md 8d: %d B per env-step); "
-                                 "the fused kernel keeps window and scalars on chip and moves %d B, so frac may exceed the physical "
-                                 "fraction: frac_traffic = HBM bytes from the PMC counters / time / peak" % (alg, WRITTEN_BYTES[(args.kind, dkey)])},
+                         "contract": {"alg_bytes_per_env_step": contract, "achieved": achieved_contract,
+                                      "frac": achieved_contract / HBM_PEAK_GBS,
+                                      "note": "SURVEY.md 8d's un-fused per-step figure (state, window and scalars through HBM every step); "
+                                              "rounds 1-2 reported this as achieved / frac (0.83-0.86 then)"}},
             "backend": backend if world > 1 else None,
             "rccl_ranks": ranks_seen if (world > 1 and backend == "nccl") else None,
             "ranks": ranks_seen,
