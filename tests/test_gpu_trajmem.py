@@ -126,3 +126,23 @@ def test_blocks_allocated_and_freed_in_turn_always_read_back_what_was_written():
         del t, spare, host
         if i % 4 == 0:
             torch.cuda.empty_cache()
+
+
+def test_fixed_three_run_layout_when_the_measurement_is_switched_off(monkeypatch):
+    """SNAC_TRAJ_PROBE=0: the fallback layout (runs created 32 GiB apart, chunk j -> run j % 3) is a block like any other."""
+    import torch
+    from snac_amd import BatchedDMPEnv, trajmem
+
+    monkeypatch.setenv("SNAC_TRAJ_PROBE", "0")
+    blk = trajmem.traj_empty(((1 << 30) + (40 << 20),), torch.uint8, "cuda")          # 34 chunks: runs of 12 / 11 / 11
+    words = blk[: (1 << 30)].view(torch.int64)
+    words.copy_(torch.arange(words.numel(), dtype=torch.int64, device="cuda"))
+    assert int(words[::4099].sum().item()) == sum(range(0, words.numel(), 4099))
+    assert bool((words[1:] - words[:-1] == 1).all())
+    a = BatchedDMPEnv(2, True, 4096, seed=4)
+    b = BatchedDMPEnv(2, True, 4096, seed=4)
+    a.reset(); b.reset()
+    out = blk[: 60 * 4096 * 51 * 8].view(torch.float64).view(60, 4096, 51)           # 100 MB across four chunk borders
+    oa, _, _ = a.rollout(60, out=out)
+    ob, _, _ = b.rollout(60)
+    assert torch.equal(oa, ob)
