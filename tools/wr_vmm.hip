@@ -1,8 +1,9 @@
 // wr_vmm.hip -- can the ONE contiguous [T][N][51] tensor get the 7.1 TB/s of tools/wr_blocks.hip's split tensors?  The virtual
 // range stays contiguous; its physical backing is dealt over runs of memory a 32 GiB slice apart with the virtual-memory API:
 // hipMemCreate handles of 32 MB created one after the other (they follow each other in physical memory on an idle device), gap
-// handles between the runs (released afterwards), virtual chunk j mapped to run j % runs.  This is what snac_traj_alloc does
-// (snac_amd/csrc/snac_hip.hip).  Patterns: R = the rollout's rows (plain addresses), W = wave-major.
+// handles between the runs (released afterwards), virtual chunk j mapped to run j % runs.  This is the FALLBACK layout of
+// snac_traj_alloc (snac_amd/csrc/snac_hip.hip): the runs show that the order of creation says little about where a handle lies once
+// the allocator has seen releases -- which is why snac_traj_alloc measures instead.  Patterns: R = the rollout's rows, W = wave-major.
 // build: hipcc -O3 --offload-arch=gfx950 -o wr_vmm wr_vmm.hip ; run: ./wr_vmm
 #include <hip/hip_runtime.h>
 #include <cstdio>
