@@ -2475,7 +2475,8 @@ namespace {
 struct TrajBlock { size_t total, chunk; int device; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_traj_mu;
 std::unordered_map<void*, TrajBlock> g_traj;
-constexpr size_t TRAJ_CHUNK = (size_t)32 << 20;   // one physical handle per 32 MB: 480 handles for the headline's 16 GB
+constexpr int TRAJ_CHUNK_LOG2 = 25;
+constexpr size_t TRAJ_CHUNK = (size_t)1 << TRAJ_CHUNK_LOG2;   // one physical handle per 32 MB: 480 handles for the headline's 16 GB
 constexpr size_t TRAJ_SLICE = (size_t)32 << 30;   // distance between the starts of consecutive runs
 constexpr int TRAJ_RUNS = 3;
 constexpr size_t TRAJ_SPLIT_MIN = (size_t)1 << 30;     // smaller blocks are not worth the two seconds: one run
@@ -2557,7 +2558,7 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
     const size_t gbytes = TRAJ_GROUP * chunk;
     auto probe = [&](size_t ga, size_t gb, bool timed) -> float {
         if (timed) (void)hipEventRecord(e0, nullptr);
-        hipLaunchKernelGGL(k_traj_probe, dim3(256), dim3(256), 0, nullptr, scratch + ga * gbytes, scratch + gb * gbytes, 25, (int)(2 * TRAJ_GROUP));
+        hipLaunchKernelGGL(k_traj_probe, dim3(256), dim3(256), 0, nullptr, scratch + ga * gbytes, scratch + gb * gbytes, TRAJ_CHUNK_LOG2, (int)(2 * TRAJ_GROUP));
         if (!timed) return 0.f;
         (void)hipEventRecord(e1, nullptr);
         if (hipEventSynchronize(e1) != hipSuccess) { ok = false; return 0.f; }
