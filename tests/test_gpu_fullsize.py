@@ -27,12 +27,17 @@ def _pair(dim, dyn, n, tag, seed=1, base=0, **kw):
     return env, orc
 
 
-def _compare_chunks(env, orc, T, chunk):
+def _compare_chunks(env, orc, T, chunk, memory="malloc"):
     import torch
 
     nt = _threads()
     assert env.reset().cpu().numpy().tobytes() == orc.reset().tobytes()
-    buf = torch.empty((chunk, env.num_envs, env.obs_dim), dtype=torch.float64, device=env.device)
+    if memory == "vmm":                                           # trajectory memory (snac_traj_alloc): chunks of two slices taking turns
+        from snac_amd import trajmem
+
+        buf = trajmem.traj_empty((chunk, env.num_envs, env.obs_dim), torch.float64, env.device)
+    else:
+        buf = torch.empty((chunk, env.num_envs, env.obs_dim), dtype=torch.float64, device=env.device)
     t = 0
     while t < T:
         c = min(chunk, T - t)
@@ -58,9 +63,10 @@ def test_config2_1d_static_4096_envs_full_episode():
 
 def test_config3_2d_dynamic_dense_65536_envs_full_pass():
     """BASELINE configs[2] (headline): 2D dynamic dense, N = 65536, T = 600 -- every observation, reward and done
-    flag of all 39 321 600 env-steps equals the oracle's."""
+    flag of all 39 321 600 env-steps equals the oracle's.  The observations are written into trajectory memory (a 1.07 GB block of
+    snac_traj_alloc, the measured two-slice layout: what bench.py writes into) and read back from there."""
     env, orc = _pair(2, True, 65536, "dense_train")
-    e = _compare_chunks(env, orc, 600, 40)
+    e = _compare_chunks(env, orc, 600, 40, memory="vmm")
     assert e["episodes"] > 65536
 
 
