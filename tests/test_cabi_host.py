@@ -55,6 +55,15 @@ def test_argument_validation_happens_before_any_launch():
     bad = _lib.EnvDesc(2, 1, 0, 4, 0, 0, 1, 0, 0, 0)
     assert L.snac_iou(C.byref(bad), C.byref(st), None, None) == -1
     assert L.snac_rollout(None, None, 1, 0, None, None, 0, None, None, None, None) == -1
+    # trajectory memory: arguments first, and without a GPU the call reports an error instead of handing out host memory
+    p = C.c_void_p()
+    assert L.snac_traj_alloc(0, 0, C.byref(p)) == -1 and b"bytes" in L.snac_last_error()
+    assert L.snac_traj_alloc(1 << 20, 0, None) == -1
+    assert L.snac_traj_free(None) == 0
+    assert L.snac_traj_free(C.c_void_p(0x1000)) == -1 and b"snac_traj_alloc" in L.snac_last_error()
+    import torch
+    if not torch.cuda.is_available():
+        assert L.snac_traj_alloc(1 << 20, 0, C.byref(p)) < 0 and not p.value
 
 
 def test_hdr_struct_is_16_bytes():
