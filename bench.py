@@ -384,7 +384,9 @@ def main():
         ev[i][0].record()
         env.rollout(T, obs="all", out=obs)
         ev[i][1].record()
-        s = env.stats_tensor()
+        s = env.stats_tensor(out=stats) if world == 1 else env.stats_tensor()   # one rank: the sums land where they are kept
+        if world == 1:
+            continue
         if world > 1 and backend == "nccl":
             # the pass's one exchange (24 bytes, RCCL): enqueued behind the rollout on RCCL's stream, it overlaps the next
             # pass instead of holding it up; every pass still performs it and all are complete before the clock stops

@@ -658,6 +658,9 @@ class BatchedDMPEnv:
         s = self._stats.sum(dim=1).tolist()
         return dict(episodes=int(s[0]), return_sum=int(s[1]), iou_fx_sum=int(s[2]))
 
-    def stats_tensor(self):
-        """int64 [3] on device: [episodes, return_sum, iou_fx_sum]; what snac_amd.dist all-reduces."""
-        return self._stats.sum(dim=1)
+    def stats_tensor(self, out=None):
+        """int64 [3] on device: [episodes, return_sum, iou_fx_sum]; what snac_amd.dist all-reduces.  out: a preallocated int64 [3]
+        tensor on this device that receives the sums (one kernel instead of sum + copy)."""
+        if out is None:
+            return self._stats.sum(dim=1)
+        return torch.sum(self._stats, dim=1, out=out)
