@@ -18,7 +18,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import helpers  # noqa: E402
-from snac_amd import BatchedDMPEnv  # noqa: E402
+from snac_amd import BatchedDMPEnv, trajmem  # noqa: E402
 
 SIZES = [1, 2, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 255, 300, 1000, 4095, 4096, 4100, 8191, 8192, 8200, 16380, 16384, 16390,
          32768, 33000, 65536, 65600]
@@ -80,8 +80,13 @@ def trial(rng, idx):
                 a = np.where(rng.random((T, n)) < bias, A - 1, rng.integers(0, A, size=(T, n))).astype(np.int8)
                 k = rng.integers(1, 4, size=(T, n)).astype(np.int8)
             tiled = rng.random() < 0.3                                # the tile-major trajectory layout holds the same rows
+            out = None
+            if rng.random() < 0.3:                                    # the observations into trajectory memory (snac_traj_alloc)
+                shape = ((n + 63) // 64, T, 64, env.obs_dim) if tiled else (T, n, env.obs_dim)
+                out = trajmem.traj_empty(shape, env.obs_dtype, env.device)
+                ops[-1] += "/vmm"
             og, rg, dg = env.rollout(T, actions=None if a is None else torch.from_numpy(a), step_size=None if k is None else torch.from_numpy(k),
-                                     obs="tiled" if tiled else "all")
+                                     obs="tiled" if tiled else "all", out=out)
             if tiled:
                 og = env.untile(og)
                 ops[-1] += "/tiled"
