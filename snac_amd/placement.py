@@ -35,16 +35,16 @@ def fastest_tensor(shape, dtype, device, run, candidates=6, reps=3, min_bytes=1 
             break
         held.append(t)
         run(t)                                                     # the first touch (page tables)
-        if len(held) == 1:
-            # a GPU that comes from idle needs ~15-30 ms of launches to reach its sustained clocks: without
-            # this the first candidate is timed on the ramp and looks slower than it is
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
+        # a GPU that comes from idle needs ~15-30 ms of launches to reach its sustained clocks, and every
+        # candidate's allocation (up to 2 s for a snac_traj_alloc block) lets it idle again: without this warm-up a candidate is
+        # timed on the ramp and an issue-bound workload looks 15 % slower than it is
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        run(t)
+        b.record()
+        b.synchronize()
+        for _ in range(max(0, min(200, int(30.0 / max(a.elapsed_time(b), 1e-3))))):
             run(t)
-            b.record()
-            b.synchronize()
-            for _ in range(max(0, min(200, int(30.0 / max(a.elapsed_time(b), 1e-3))))):
-                run(t)
         best = None
         for _ in range(max(1, int(reps))):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
