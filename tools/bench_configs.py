@@ -11,7 +11,8 @@ import torch  # noqa: E402
 
 from snac_amd import BatchedDMPEnv  # noqa: E402
 
-ALG = {1: 88, 2: 481, 3: 574}
+ALG = {1: 88, 2: 481, 3: 574}       # SURVEY.md 8d's un-fused contract figures per env-step
+WRITTEN = {1: 61, 2: 413, 3: 413}   # what the fused rollout writes: observation row + reward + done
 
 
 def env_obs_bytes(kind):
@@ -57,7 +58,8 @@ def main():
             ("3D dynamic     N=65536  T=250 ", 3, True, 65536, 250), ("3D static      N=16384  T=1300", 3, False, 16384, 1300)]
     for name, kind, dyn, n, T in rows:
         ms = rollout_time(kind, dyn, n, T)
-        print("rollout f64 %s  %8.3f ms  %.3e env-steps/s  alg %.0f GB/s" % (name, ms, n * T / ms * 1e3, ALG[kind] * n * T / ms / 1e6))
+        print("rollout f64 %s  %8.3f ms  %.3e env-steps/s  written %.0f GB/s  (contract figure %.0f GB/s)" % (
+            name, ms, n * T / ms * 1e3, WRITTEN[kind] * n * T / ms / 1e6, ALG[kind] * n * T / ms / 1e6))
     # 3D with the reference's own action mix [0.2 x 4 moves, 0.05 x 4 builds] (Env/3D/DMP_simulator_3d_static_circle.py:361-362):
     # explicit int8 actions drawn with that distribution on the device, step sizes from the counter RNG
     for dyn, T in ((True, 1000), (False, 1300)):
