@@ -220,6 +220,11 @@ int snac_stream_sync(void* stream);
  * The caller owns the block: the library allocates nothing by itself. */
 int snac_traj_alloc(size_t bytes, int device, void** out);
 int snac_traj_free(void* ptr);
+/* how a live block of snac_traj_alloc is backed (diagnostics): one of the values below, or SNAC_ERR_ARG for any other pointer */
+#define SNAC_TRAJ_ONE_RUN 1      /* below 1 GiB: handles in creation order */
+#define SNAC_TRAJ_THREE_RUNS 2   /* the fallback: three runs created 32 GiB apart, chunk j -> run j % 3 */
+#define SNAC_TRAJ_MEASURED 3     /* chunks of the reference group's slice and of another slice in turn, as probed */
+int snac_traj_layout(const void* ptr);
 
 /* the driver loop of multiprocess.py:78-84 -- T vector steps with auto-reset, fused in one launch with the
  * env state held on chip.

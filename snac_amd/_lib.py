@@ -23,7 +23,7 @@ EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_obs_dim", 
            "snac_step_scalar", "snac_rollout",
            "snac_rollout_rec", "snac_replay_gather", "snac_make_plans", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
            "snac_import_state", "snac_obs_equal", "snac_stream_sync", "snac_rollout_tiled", "snac_replay_gather_tiled", "snac_traj_alloc",
-           "snac_traj_free")
+           "snac_traj_free", "snac_traj_layout")
 
 
 class Sizes(C.Structure):
@@ -101,6 +101,7 @@ def lib():
         L.snac_obs_equal.argtypes = [C.POINTER(EnvDesc), vp, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
         L.snac_traj_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(vp)]
         L.snac_traj_free.argtypes = [vp]
+        L.snac_traj_layout.argtypes = [vp]
         for n in EXPORTS:
             getattr(L, n)
         if L.snac_version() != ABI_VERSION:

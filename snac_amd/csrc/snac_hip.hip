@@ -2472,7 +2472,7 @@ int snac_export_grid(const snac_env_desc* d, const snac_state* st, double* out, 
 // allocator that has seen no releases, so that layout is a lottery (5.7-7.1 TB/s, tools/wr_vmm.hip) where the probed one is not.
 // The caller owns the block and frees it with snac_traj_free; the library keeps only the bookkeeping needed to unmap it.
 namespace {
-struct TrajBlock { size_t total, chunk; int device; std::vector<hipMemGenericAllocationHandle_t> handles; };
+struct TrajBlock { size_t total, chunk; int device, layout; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_traj_mu;
 std::unordered_map<void*, TrajBlock> g_traj;
 constexpr int TRAJ_CHUNK_LOG2 = 25;
@@ -2640,7 +2640,7 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
     if (e != hipSuccess) { traj_release(va, m2, chunk, hs); return fail_hip(e, "hipMemSetAccess"); }
     {
         std::lock_guard<std::mutex> lk(g_traj_mu);
-        g_traj[va] = TrajBlock{total, chunk, device, std::move(hs)};
+        g_traj[va] = TrajBlock{total, chunk, device, SNAC_TRAJ_MEASURED, std::move(hs)};
     }
     *out = va;
     return 0;
@@ -2725,10 +2725,16 @@ int snac_traj_alloc(size_t bytes, int device, void** out) {
     if (e != hipSuccess) { traj_release(va, mapped, chunk, hs); return fail_hip(e, "hipMemSetAccess"); }
     {
         std::lock_guard<std::mutex> lk(g_traj_mu);
-        g_traj[va] = TrajBlock{total, chunk, device, std::move(hs)};
+        g_traj[va] = TrajBlock{total, chunk, device, runs > 1 ? SNAC_TRAJ_THREE_RUNS : SNAC_TRAJ_ONE_RUN, std::move(hs)};
     }
     *out = va;
     return SNAC_OK;
+}
+
+int snac_traj_layout(const void* ptr) {
+    std::lock_guard<std::mutex> lk(g_traj_mu);
+    auto it = g_traj.find(const_cast<void*>(ptr));
+    return it == g_traj.end() ? fail(SNAC_ERR_ARG, "not a block of snac_traj_alloc") : it->second.layout;
 }
 
 int snac_traj_free(void* ptr) {

@@ -61,4 +61,13 @@ def fastest_tensor(shape, dtype, device, run, candidates=6, reps=3, min_bytes=1 
     chosen = held[i]
     del held, t
     torch.cuda.empty_cache()                                       # the other candidates go back to the driver
-    return chosen, {"candidates_ms": [round(x, 4) for x in times], "chosen": i}
+    rep = {"candidates_ms": [round(x, 4) for x in times], "chosen": i}
+    try:                                                           # how the chosen tensor is backed, when it is a snac_traj_alloc block
+        from . import trajmem
+
+        lay = trajmem.layout_of(chosen)
+        if lay:
+            rep["layout"] = lay
+    except Exception:
+        pass
+    return chosen, rep

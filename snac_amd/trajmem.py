@@ -91,6 +91,15 @@ def _via_dlpack(block):
         raise
 
 
+LAYOUTS = {1: "one run", 2: "three runs 32 GiB apart", 3: "measured: two slices in turn"}
+
+
+def layout_of(t):
+    """How the snac_traj_alloc block under tensor `t` is backed (LAYOUTS), or None if `t` does not start at such a block."""
+    rc = _lib.lib().snac_traj_layout(C.c_void_p(t.untyped_storage().data_ptr()))
+    return LAYOUTS.get(rc)
+
+
 def traj_empty(shape, dtype, device):
     """torch.empty(shape, dtype=dtype, device=device) on snac_traj_alloc memory (uninitialised, contiguous).  Raises SnacError
     when the block cannot be allocated and RuntimeError when this PyTorch build cannot view a foreign device pointer."""

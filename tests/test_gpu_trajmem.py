@@ -49,7 +49,9 @@ def test_traj_empty_is_an_ordinary_tensor_and_is_released():
     del t
     gc.collect()
     assert float(v[0, 0].item()) == 51000.0
+    assert trajmem.layout_of(v) == "one run" and trajmem.layout_of(torch.empty(4, device="cuda")) is None
     big = trajmem.traj_empty((1 << 30,), torch.uint8, "cuda")    # 1 GiB: visible in the driver's free-memory figure
+    assert trajmem.layout_of(big) in ("measured: two slices in turn", "three runs 32 GiB apart")
     assert torch.cuda.mem_get_info()[0] <= free0 - (1 << 30) + (64 << 20)
     # a block of this size takes the measured layout (probe of a handle pool, near / far chunks in turn): every one of its 32
     # chunks must be its own memory -- a counter written through the whole block reads back intact
@@ -135,6 +137,7 @@ def test_fixed_three_run_layout_when_the_measurement_is_switched_off(monkeypatch
 
     monkeypatch.setenv("SNAC_TRAJ_PROBE", "0")
     blk = trajmem.traj_empty(((1 << 30) + (40 << 20),), torch.uint8, "cuda")          # 34 chunks: runs of 12 / 11 / 11
+    assert trajmem.layout_of(blk) == "three runs 32 GiB apart"
     words = blk[: (1 << 30)].view(torch.int64)
     words.copy_(torch.arange(words.numel(), dtype=torch.int64, device="cuda"))
     assert int(words[::4099].sum().item()) == sum(range(0, words.numel(), 4099))
