@@ -1,4 +1,4 @@
-"""Workload for profiling the single-step kernel (k_transition): snac_step at N = 524 288 (50 ticks, counter RNG) and
+"""Workload for profiling the single-step kernels (k_transition2d / 3d): snac_step at N = 524 288 (2D and 3D, 50 ticks, counter RNG) and
 snac_transition on a 2^20-row node pool (2D and 3D: random parents x all actions, 20 launches each).  Run under rocprofv3."""
 import os
 import sys
@@ -13,6 +13,14 @@ from snac_amd import BatchedDMPEnv  # noqa: E402
 
 def main():
     env = BatchedDMPEnv(2, True, 524288, seed=1)
+    env.reset()
+    out = (torch.empty((env.num_envs, 51), dtype=torch.float64, device="cuda"), torch.empty(env.num_envs, dtype=torch.float32, device="cuda"),
+           torch.empty(env.num_envs, dtype=torch.uint8, device="cuda"))
+    for _ in range(50):
+        env.step(auto_reset=True, out=out)
+    torch.cuda.synchronize()
+    del env, out
+    env = BatchedDMPEnv(3, True, 524288, seed=1)                     # 3D snac_step: k_transition3d on identity rows
     env.reset()
     out = (torch.empty((env.num_envs, 51), dtype=torch.float64, device="cuda"), torch.empty(env.num_envs, dtype=torch.float32, device="cuda"),
            torch.empty(env.num_envs, dtype=torch.uint8, device="cuda"))
