@@ -268,7 +268,7 @@ int snac_rollout_tiled(const snac_env_desc* desc, const snac_state* st, int32_t 
  *   s    = obs_ring[tick-1 mod cap][env], or the reset observation when first_ring[tick][env] != 0
  *   plan = the env's input_plan (2D / 3D: 20x20, 1D: 30 heights) expanded from the plan table
  * for `batch` samples (tick_idx[b], env_idx[b]); outputs are float32 as the scripts feed them to the networks:
- * s_out / s_next_out [batch][obs_dim], plan_out [batch][400 | 30] or NULL.  a, r, done are plain gathers of the [cap][N]
+ * s_out / s_next_out [batch][obs_dim], plan_out [batch][400 | 30] or NULL (2D / 3D: 16-byte aligned, it is written four cells at a time).  a, r, done are plain gathers of the [cap][N]
  * arrays and stay with the caller. */
 int snac_replay_gather(const snac_env_desc* desc, const snac_state* st, int32_t cap, const void* obs_ring,
                        const uint8_t* first_ring, const int16_t* plan_idx_ring, const int32_t* tick_idx,

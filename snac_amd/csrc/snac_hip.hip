@@ -1951,39 +1951,80 @@ struct GArgs {
 
 template <int KIND, typename OT>
 __global__ __launch_bounds__(256) void k_gather(const GArgs g) {
-    constexpr int D = KIND == 1 ? 7 : 51, W = KIND == 1 ? 5 : 49, PC = KIND == 1 ? 30 : 400;
+    // S samples per wave: the index loads of all of them first (lane u = sample u), then every row load of the group in flight
+    // before the first store -- one sample per wave was a chain of three dependent loads with a single row in flight.
+    constexpr int D = KIND == 1 ? 7 : 51, W = KIND == 1 ? 5 : 49, PC = KIND == 1 ? 30 : 400, S = 4;
     const int lane = threadIdx.x & 63;
-    const int b = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (b >= g.batch) return;
-    const int t = min(max(g.tick[b], 0), g.cap - 1), i = min(max(g.env[b], 0), g.n - 1);
-    const size_t cur = (size_t)t * g.n + i, prev = (size_t)(t == 0 ? g.cap - 1 : t - 1) * g.n + i;
-    const bool first = g.first[cur] != 0;
-    const OT* o = (const OT*)g.obs;
+    const int b0 = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * S;
+    if (b0 >= g.batch) return;
+    const int ns = min(S, g.batch - b0);
     const int LD = g.ld;                                         // D, or D + the position tail (1 / 2 values)
-    const int tp = t == 0 ? g.cap - 1 : t - 1;
-    const size_t ocur = g.tiled ? ((size_t)(i >> 6) * g.cap + t) * 64 + (i & 63) : cur;
-    const size_t oprev = g.tiled ? ((size_t)(i >> 6) * g.cap + tp) * 64 + (i & 63) : prev;
-    if (lane < LD) {
-        g.s_next[(size_t)b * LD + lane] = (float)o[ocur * LD + lane];
-        float sv;
-        if (first) {   // reset observation: window at the start position over an empty grid, both scalar slots 0
-            const int wi = lane / 7, wj = lane - 7 * wi;
-            const bool frame = KIND == 1 ? lane < 2 : (wi < 3 || wj < 3);
-            sv = (lane < W && frame) ? (float)g.frame_val : 0.0f;
-            if (lane >= D) sv = KIND == 1 ? 2.0f : 3.0f;         // position tail: the start position
-        } else {
-            sv = (float)o[oprev * LD + lane];
+    const OT* o = (const OT*)g.obs;
+    // lane u < ns: the sample's slot, env, first-step flag and plan row
+    int t = 0, i = 0, first = 0, p = 0;
+    if (lane < ns) {
+        t = min(max(g.tick[b0 + lane], 0), g.cap - 1);
+        i = min(max(g.env[b0 + lane], 0), g.n - 1);
+        const size_t cur = (size_t)t * g.n + i;
+        first = g.first[cur] != 0;
+        if (g.plan_out) p = min(max((int)g.plan_idx[cur], 0), g.num_plans - 1);
+    }
+    OT vcur[S], vprev[S];
+    int fst[S];
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int tu = __builtin_amdgcn_readlane(t, u), iu = __builtin_amdgcn_readlane(i, u);
+        fst[u] = __builtin_amdgcn_readlane(first, u);
+        const int tp = tu == 0 ? g.cap - 1 : tu - 1;
+        const size_t ocur = g.tiled ? ((size_t)(iu >> 6) * g.cap + tu) * 64 + (iu & 63) : (size_t)tu * g.n + iu;
+        const size_t oprev = g.tiled ? ((size_t)(iu >> 6) * g.cap + tp) * 64 + (iu & 63) : (size_t)tp * g.n + iu;
+        vcur[u] = (OT)0; vprev[u] = (OT)0;
+        if (u < ns && lane < LD) {
+            vcur[u] = o[ocur * LD + lane];
+            if (!fst[u]) vprev[u] = o[oprev * LD + lane];
         }
-        g.s[(size_t)b * LD + lane] = sv;
+    }
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        if (u < ns && lane < LD) {
+            const size_t b = (size_t)(b0 + u);
+            g.s_next[b * LD + lane] = (float)vcur[u];
+            float sv;
+            if (fst[u]) {   // reset observation: window at the start position over an empty grid, both scalar slots 0
+                const int wi = lane / 7, wj = lane - 7 * wi;
+                const bool frame = KIND == 1 ? lane < 2 : (wi < 3 || wj < 3);
+                sv = (lane < W && frame) ? (float)g.frame_val : 0.0f;
+                if (lane >= D) sv = KIND == 1 ? 2.0f : 3.0f;         // position tail: the start position
+            } else {
+                sv = (float)vprev[u];
+            }
+            g.s[b * LD + lane] = sv;
+        }
     }
     if (g.plan_out) {
-        const int p = min(max((int)g.plan_idx[cur], 0), g.num_plans - 1);
-        for (int c = lane; c < PC; c += 64) {
-            int v;
-            if (KIND == 2) { const int row = c / 20, col = c - row * 20; v = (((const uint32_t*)g.plans)[p * 20 + row] >> col) & 1u; }
-            else if (KIND == 3) v = ((const int16_t*)g.plans)[p * 400 + c];
-            else v = ((const int16_t*)g.plans)[p * 32 + c];
-            g.plan_out[(size_t)b * PC + c] = (float)v;
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            if (u >= ns) break;
+            const int pu = __builtin_amdgcn_readlane(p, u);
+            float* po = g.plan_out + (size_t)(b0 + u) * PC;
+            if (KIND == 1) {
+                if (lane < PC) po[lane] = (float)((const int16_t*)g.plans)[pu * 32 + lane];
+            } else {
+                // four consecutive cells per lane (a row of 20 holds five such groups): one 16-byte store each, 100 lanes a plan
+                for (int q = lane; q < PC / 4; q += 64) {
+                    const int c = q * 4;
+                    float4 v;
+                    if (KIND == 2) {
+                        const int row = c / 20, col = c - row * 20;
+                        const uint32_t w = ((const uint32_t*)g.plans)[pu * 20 + row] >> col;
+                        v = make_float4((float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u));
+                    } else {
+                        const short4 h = *(const short4*)((const int16_t*)g.plans + (size_t)pu * 400 + c);
+                        v = make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+                    }
+                    *(float4*)(po + c) = v;
+                }
+            }
         }
     }
 }
@@ -2303,6 +2344,7 @@ static int replay_gather(const snac_env_desc* d, const snac_state* st, int32_t c
     if (cap < 2 || batch < 0) return fail(SNAC_ERR_ARG, "cap must be >= 2 and batch >= 0");
     if (!obs_ring || !first_ring || !tick_idx || !env_idx || !s_out || !s_next_out) return fail(SNAC_ERR_ARG, "null pointer");
     if (plan_out && !plan_idx_ring) return fail(SNAC_ERR_ARG, "plan_out needs plan_idx_ring");
+    if (plan_out && d->kind != SNAC_ENV_1D && ((uintptr_t)plan_out & 15)) return fail(SNAC_ERR_ARG, "plan_out must be 16-byte aligned");
     if (d->obs_tail & ~SNAC_TAIL_POSITION) return fail(SNAC_ERR_UNSUPPORTED, "replay gather supports the position tail only");
     if (batch == 0) return SNAC_OK;
     GArgs g;
@@ -2311,7 +2353,7 @@ static int replay_gather(const snac_env_desc* d, const snac_state* st, int32_t c
     g.obs = obs_ring; g.first = first_ring; g.plan_idx = plan_idx_ring; g.tick = tick_idx; g.env = env_idx;
     g.plans = st->plans; g.s = s_out; g.s_next = s_next_out; g.plan_out = plan_out;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)((batch + 3) / 4)), block(256);
+    const dim3 grid((unsigned)((batch + 15) / 16)), block(256);   // 4 waves x 4 samples (S of k_gather; 8 were no faster)
     const bool f32 = d->obs_dtype == SNAC_OBS_F32;
     void (*kern)(const GArgs);
     if (d->kind == SNAC_ENV_1D) kern = f32 ? k_gather<1, float> : k_gather<1, double>;
