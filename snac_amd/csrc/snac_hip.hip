@@ -2615,7 +2615,10 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
         if (hipGetLastError() != hipSuccess) ok = false;
         std::vector<char> todo(groups, 1);                       // groups not yet assigned to a reference's slice
         size_t ref = 0;
-        for (int round = 0; round < 4 && ok; ++round) {
+        // SNAC_TRAJ_REFINE=0 (tuning): skip the second look below
+        const char* rf = std::getenv("SNAC_TRAJ_REFINE");
+        bool refined = rf && rf[0] == '0';
+        for (int round = 0; round < 5 && ok; ++round) {
             std::vector<float> t(groups, 0.f);
             float lo = 1e30f, hi = 0.f;
             for (size_t g = 0; g < groups; ++g) {
@@ -2633,6 +2636,15 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
             const float thr = 0.5f * (lo + hi);
             std::vector<size_t> near{ref}, far;
             for (size_t g = 0; g < groups; ++g) if (g != ref && todo[g]) (t[g] >= thr ? near : far).push_back(g);
+            if (!refined && near.size() > 1) {
+                // a second look from a better vantage point: group 0 may itself straddle two stretches of physical memory, which blurs
+                // every time measured against it; its slowest partner lies in its slice for sure -- probe everything against that one
+                refined = true;
+                size_t best = near[1];
+                for (size_t g : near) if (g != ref && t[g] > t[best]) best = g;
+                ref = best;
+                continue;
+            }
             // class A = this reference's slice if it can carry half the block, else look at the far groups from one of their own
             size_t aside = 0;                                    // groups of earlier references' slices: class B material
             for (size_t g = 0; g < groups; ++g) aside += todo[g] ? 0 : 1;
