@@ -1,0 +1,145 @@
+"""GPU: the staged 2D rollout kernel (k_rollout2d, round 3: lane-per-env window extraction, rows transposed through an LDS
+staging tile, 16-byte-per-lane stores; the plan table, its popcounts and total_brick in LDS; incremental boolean IoU; reciprocal
+observation scalars; prefetched explicit inputs) against the CPU oracle.  The kernel takes 2D rollouts on tiles of 64 envs
+(N >= 65 536) that write every observation: full tiles and a ragged last tile, float64 (two staged halves) and float32, static and
+dataset plans, [T][N][D] and tile-major outputs, launches of 1 / 2 / 37 steps, explicit actions / step sizes, the `>` rule bits,
+short time limits (many resets per launch), the record outputs -- and, bit for bit, the rows the tile kernel writes for the same
+batch (forced by an unaligned output, which the 16-byte stores do not take)."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+N0 = 65536
+
+
+def _pair(dyn, n, seed, tag=None, total_step=None, obs_dtype=None, brick_gt=False, time_gt=False, base=0):
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(2, dyn, tag or ("dense_train" if dyn else "p0"))
+    env = BatchedDMPEnv(2, dyn, n, plans=table.reshape(len(table), 26, 26), seed=seed, env_id_base=base, total_step=total_step,
+                        obs_dtype=obs_dtype or torch.float64, brick_gt=brick_gt, time_gt=time_gt)
+    orc = helpers.oracle().OracleBatch(2, dyn, n, table, seed=seed, env_id_base=base)
+    if total_step:
+        orc.set_total_step(total_step)
+    orc.set_rules(brick_gt, time_gt)
+    o = orc.reset()
+    assert env.reset().cpu().numpy().tobytes() == (o.astype(np.float32) if obs_dtype == torch.float32 else o).tobytes()
+    return env, orc
+
+
+def _compare(env, orc, T, t0, f32=False, actions=None, step_size=None):
+    import torch
+
+    a = None if actions is None else torch.from_numpy(actions).to(env.device)
+    k = None if step_size is None else torch.from_numpy(step_size).to(env.device)
+    og, rg, dg = env.rollout(T, actions=a, step_size=k)
+    oc, rc, dc = orc.rollout(T, t0=t0, actions=actions, step_size=step_size, nthreads=16)
+    want = oc.astype(np.float32) if f32 else oc
+    assert og.cpu().numpy().tobytes() == want.tobytes(), "observations"
+    assert rg.cpu().numpy().tobytes() == rc.tobytes(), "rewards"
+    assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc), "done flags"
+
+
+def _end_state(env, orc):
+    s, e = orc.stats(), env.episodic_stats()
+    assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
+    assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
+@pytest.mark.parametrize("n", [N0, N0 + 36, N0 + 64 + 4])
+def test_tiles_dtypes_and_launch_lengths(dyn, n, f32):
+    """n = 65 536: full tiles only; + 36: a ragged last tile that ends inside the first staged half of a float64 tile; + 68: one that
+    is a lone 4-env tile in a block of its own.  Launches of 1, 2 and 37 steps; time limit 30, so every env resets in every launch of 37."""
+    import torch
+
+    env, orc = _pair(dyn, n, seed=5, total_step=30, obs_dtype=torch.float32 if f32 else None, base=11)
+    t0 = 0
+    for T in (1, 2, 37):
+        _compare(env, orc, T, t0, f32)
+        t0 += T
+    _end_state(env, orc)
+    _compare(env, orc, 3, t0, f32)                                # the records written back by the launches above carry on
+
+
+@pytest.mark.parametrize("rules", [(False, False), (True, False), (False, True), (True, True)], ids=str)
+def test_episodes_end_by_bricks_and_by_time(rules):
+    """Sparse plans (total_brick floored at 30) and drop-heavy explicit actions: episodes end at count_brick >= (>) total_brick
+    within ~40 steps; the time limit 45 (> with the rule bit) ends the rest."""
+    n, T = N0 + 36, 120
+    env, orc = _pair(True, n, seed=9, tag="sparse_train", total_step=45, brick_gt=rules[0], time_gt=rules[1])
+    rng = np.random.default_rng(3)
+    acts = rng.choice(np.arange(5, dtype=np.int8), size=(T, n), p=[0.05, 0.05, 0.05, 0.05, 0.8])
+    _compare(env, orc, T, 0, actions=acts)                        # explicit actions, counter-RNG step sizes
+    _end_state(env, orc)
+    e = env.episodic_stats()
+    assert e["episodes"] > 2 * n
+
+
+def test_explicit_inputs_prefetched_a_tick_ahead():
+    """actions only, step sizes only, both; out-of-range step sizes are clamped into {1, 2, 3}; a launch of one step has nothing to prefetch."""
+    n = N0 + 36
+    env, orc = _pair(True, n, seed=2, total_step=50)
+    rng = np.random.default_rng(7)
+    t0 = 0
+    for T, use_a, use_k in ((1, True, True), (23, True, False), (23, False, True), (40, True, True)):
+        acts = rng.integers(0, 5, size=(T, n)).astype(np.int8) if use_a else None
+        ks = rng.integers(0, 6, size=(T, n)).astype(np.int8) if use_k else None
+        if ks is not None:
+            orc_k = np.clip(ks, 1, 3)
+        og, rg, dg = env.rollout(T, actions=acts, step_size=ks)
+        oc, rc, dc = orc.rollout(T, t0=t0, actions=acts, step_size=None if ks is None else orc_k, nthreads=16)
+        assert og.cpu().numpy().tobytes() == oc.tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes()
+        assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+        t0 += T
+    _end_state(env, orc)
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+def test_tile_major_output_and_record(f32):
+    """rollout(obs="tiled") holds the same rows at [env // 64, t, env % 64]; the record outputs (action, step size, plan row,
+    first-step flag) equal what the tile kernel records for an identical batch."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    n, T = N0 + 36, 33
+    dt = torch.float32 if f32 else torch.float64
+    a, orc = _pair(True, n, seed=4, total_step=20, obs_dtype=dt)
+    b = a.fork(torch.arange(n, device=a.device))
+    kinds = {"actions": torch.int8, "step_size": torch.int8, "plan_idx": torch.int16, "first": torch.uint8}
+    ra = {k: torch.empty((T, n), dtype=v, device=a.device) for k, v in kinds.items()}
+    rb = {k: torch.empty((T, n), dtype=v, device=a.device) for k, v in kinds.items()}
+    ot, rt, dtt = a.rollout(T, obs="tiled", record=ra)
+    # the same batch through the tile kernel: an output that is not 16-byte aligned
+    raw = torch.empty(T * n * 51 + 1, dtype=dt, device=a.device)
+    ob, rwb, db = b.rollout(T, out=raw[1:].view(T, n, 51), record=rb)
+    assert ob.data_ptr() % 16 != 0
+    assert torch.equal(a.untile(ot), ob) and torch.equal(rt, rwb) and torch.equal(dtt, db)
+    for k in kinds:
+        assert torch.equal(ra[k], rb[k]), k
+    oc, rc, dc = orc.rollout(T, t0=0, nthreads=16)
+    assert ob.cpu().numpy().tobytes() == (oc.astype(np.float32) if f32 else oc).tobytes()
+    assert torch.equal(a._hdr, b._hdr) and torch.equal(a._grid, b._grid) and torch.equal(a._stats, b._stats) and torch.equal(a._episode, b._episode)
+
+
+def test_header_total_brick_survives_a_reset_onto_the_same_plan():
+    """A static batch whose headers carry a total_brick other than the plan row's (import_states with total_brick): the tile kernel
+    keeps it across auto-resets onto the same row -- so does the staged kernel, whose plan metadata lies in LDS."""
+    import torch
+
+    n = N0
+    env, orc = _pair(False, n, seed=3, total_step=25)
+    other = env.fork(torch.arange(n, device=env.device))
+    for e in (env, other):
+        e._hdr.view(torch.int16)[:, 4] = 17                        # total_brick 17 instead of the plan's
+    o1, r1, d1 = env.rollout(60)
+    raw = torch.empty(60 * n * 51 + 1, dtype=torch.float64, device=env.device)
+    o2, r2, d2 = other.rollout(60, out=raw[1:].view(60, n, 51))
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    assert torch.equal(env._hdr, other._hdr) and torch.equal(env._stats, other._stats)
+    assert int(env.total_brick.min()) == 17

@@ -1,0 +1,55 @@
+"""One fused rollout timed back to back: kind, batch, dtype and the memory the trajectory lies in are arguments, so that two builds
+or two kernels (SNAC_2D_STAGE=0 keeps 2D rollouts on the tile kernel) can be compared on one box, one process per arm.
+
+    gpurun -- python tools/roll_time.py [kind] [N] [T] [reps] [f64|f32] [vmm|malloc] [tiled]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from snac_amd import BatchedDMPEnv, trajmem  # noqa: E402
+
+
+def main():
+    kind = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+    T = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+    dt = torch.float32 if (len(sys.argv) > 5 and sys.argv[5] == "f32") else torch.float64
+    mem = sys.argv[6] if len(sys.argv) > 6 else "vmm"
+    tiled = len(sys.argv) > 7 and sys.argv[7] == "tiled"
+    env = BatchedDMPEnv(kind, True, n, seed=1, obs_dtype=dt)
+    env.reset()
+    T = T or env.total_step
+    shape = ((n + 63) // 64, T, 64, env.obs_dim) if tiled else (T, n, env.obs_dim)
+    buf = trajmem.traj_empty(shape, dt, "cuda") if mem == "vmm" else torch.empty(shape, dtype=dt, device="cuda")
+    rew = torch.empty((T, n), dtype=torch.float32, device="cuda")
+    done = torch.empty((T, n), dtype=torch.uint8, device="cuda")
+
+    def run(k):
+        ev = []
+        for _ in range(k):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            env.rollout(T, obs="tiled" if tiled else "all", out=buf, reward_out=rew, done_out=done)
+            b.record()
+            ev.append((a, b))
+        torch.cuda.synchronize()
+        return sorted(a.elapsed_time(b) for a, b in ev)
+
+    run(max(8, int(60 / 2.5)))                                   # ~60 ms of the workload itself: clocks up
+    t = run(reps)
+    esz = 4 if dt == torch.float32 else 8
+    wb = (env.obs_dim * esz + 5) * n * T
+    med = t[len(t) // 2]
+    print("%dD N=%d T=%d %s %s%s stage=%s: min %.3f  median %.3f ms   %.2f TB/s written   %.3e env-steps/s" % (
+        kind, n, T, "f32" if esz == 4 else "f64", mem, " tiled" if tiled else "", os.environ.get("SNAC_2D_STAGE", "1"), t[0], med,
+        wb / med / 1e9, n * T / med * 1e3), flush=True)
+
+
+if __name__ == "__main__":
+    main()
