@@ -14,8 +14,10 @@
  *
  * Conventions
  *   - Plain C types only.  Every pointer inside snac_state and every array argument is a DEVICE pointer
- *     owned by the caller (e.g. torch tensors); the library allocates nothing and keeps no global state
- *     except a thread-local error string.  Input and output ARRAYS (actions, step sizes, obs, reward, done) may also lie in
+ *     owned by the caller (e.g. torch tensors).  The env entry points allocate nothing and keep no state of their own
+ *     beyond a thread-local error string; the one exception is the optional trajectory-memory allocator
+ *     (snac_traj_alloc / snac_traj_free below), which keeps a mutex-protected table of the blocks it has handed out.
+ *     Input and output ARRAYS (actions, step sizes, obs, reward, done) may also lie in
  *     page-locked host memory, which is mapped into the device's address space: the kernels then read / write them over the
  *     bus themselves and a host-side caller only waits (snac_stream_sync) -- no copy command.
  *   - All work is enqueued on the caller's hipStream_t (`stream`, passed as void*; NULL = default
@@ -58,7 +60,7 @@
 extern "C" {
 #endif
 
-#define SNAC_ABI_VERSION 4
+#define SNAC_ABI_VERSION 5
 
 typedef enum snac_status {
     SNAC_OK = 0,
@@ -206,18 +208,32 @@ int snac_stream_sync(void* stream);
  * is ONE contiguous virtual range backed -- through the HIP virtual-memory API -- by 32 MB chunks of physical memory from
  * different slices taking turns, so the [T][N][obs_dim] output of snac_rollout keeps two slices busy at any time: the headline
  * pass takes 2.33-2.40 ms instead of 2.75-2.95 (tools/mem_ab.py).  Which slice a chunk lies in cannot be asked of the driver; it
- * is measured: a pool of handles (the block + 64 GiB) is mapped into a scratch range and every group of 16 handles is timed
- * together with a reference group under the rollout's own store pattern -- partners in another slice run 20 % faster.
- *   snac_traj_alloc   `bytes` (rounded up to whole 32 MB handles, or 2 MB pages below that; blocks under 1 GiB are one plain
+ * is measured: groups of 16 handles are timed together with a reference group under the rollout's own store pattern -- partners
+ * in another slice run 20 % faster -- and the block alternates chunks of the two kinds.
+ *   snac_traj_alloc_ex  `bytes` (rounded up to whole 32 MB handles, or 2 MB pages below that; blocks under 1 GiB are one plain
  *                     run) on `device`, read / write for that device; *out is an ordinary device pointer, contiguous, 2 MB-
- *                     aligned.  Takes 1.5-2.5 s for a large block and holds up to 64 GiB more while it runs (the pool; on a
- *                     full device it shrinks, and without a usable measurement the block falls back to three runs created
- *                     32 GiB apart); launches its probe on the null stream.  SNAC_ERR_HIP when memory runs out.
+ *                     aligned.  pool_cap_bytes: how much device memory the measurement may hold BEYOND the block while it runs
+ *                     (0 = 64 GiB).  The pool starts at the block + 8 GiB and grows in steps of 8 GiB only until both kinds of
+ *                     chunk are there in sufficient number; it never takes more than half of what is free next to the block nor
+ *                     the last 4 GiB, and is released before the call returns.  With too little room, or without a usable
+ *                     measurement, the block falls back to three runs created 32 GiB apart.  stream: the probe kernels, the
+ *                     check and their waits run on this stream (NULL = the default stream); the call returns when they are done.
+ *                     Every block is CHECKED before it is handed out: a pattern written by one kernel is read back by another
+ *                     and, one word per chunk, by a copy; a measured block is also timed once more as a whole and rebuilt (once,
+ *                     then the fixed layout) if it runs like a single slice.  A block that fails its check is SNAC_ERR_HIP, never
+ *                     a silent retry.  Typically 0.5-1.5 s for the headline's 16 GB.  SNAC_ERR_HIP when memory runs out.
  *                     SNAC_TRAJ_PROBE=0 skips the measurement, SNAC_TRAJ_DEBUG=1 prints it.
- *   snac_traj_free    waits for the device to go idle, unmaps and releases the block's memory (its address range stays reserved
- *                     and is never handed out again: a stale pointer faults); NULL is a no-op; a pointer that did not come from
- *                     snac_traj_alloc is SNAC_ERR_ARG.
- * The caller owns the block: the library allocates nothing by itself. */
+ *   snac_traj_alloc   the same with the default pool cap on the default stream.
+ *   snac_traj_free    waits for the whole device to go idle (hipDeviceSynchronize: no kernel may still be writing the block),
+ *                     unmaps and releases the block's memory.  Its address range stays reserved and is never handed out again (a
+ *                     recycled range has been seen to serve stale translations, tools/vmm_stale.hip; a stale pointer faults instead
+ *                     of hitting someone else's data): every block of 1 GiB or more costs its own size plus its probe ranges in
+ *                     ADDRESS SPACE for the life of the process -- no memory; 47 bits last for more than a thousand headline-sized
+ *                     blocks.  NULL is a no-op; a pointer that did not come from snac_traj_alloc is SNAC_ERR_ARG.  (The Python
+ *                     wrapper frees a block when the last tensor viewing it dies, so the device-wide wait can come from a
+ *                     garbage collection.)
+ * The caller owns the block; the library keeps only what it needs to unmap it again. */
+int snac_traj_alloc_ex(size_t bytes, int device, size_t pool_cap_bytes, void* stream, void** out);
 int snac_traj_alloc(size_t bytes, int device, void** out);
 int snac_traj_free(void* ptr);
 /* how a live block of snac_traj_alloc is backed (diagnostics): one of the values below, or SNAC_ERR_ARG for any other pointer */
@@ -296,7 +312,8 @@ int snac_replay_gather_tiled(const snac_env_desc* desc, const snac_state* st, in
  *                   vertices (the drop-in classes take them from np.random like the reference) and loops on area_out
  *   sparse          0: outline + interior, threshold 50; 1: outline only, threshold 20; 3D plans also need fewer than 110 cells
  *                   (script/HumanPlayerGUI/env/Env3D.py:360-364, how the 3D datasets were drawn)
- *   area_out        int32[count] or NULL: number of cells set (1D: total_brick)
+ *   area_out        int32[count] or NULL: number of cells set (1D: total_brick); NEGATIVE (-cells) for a row whose 64 redraws were
+ *                   all rejected (probability ~ 0): the last triangle stands, with total_brick >= 1
  * Rasteriser: cv2's own rules for this call restated (LineIterator with leftToRight for the outline, the 16.16 fixed-point
  * scanline fill of FillEdgeCollection for dense plans; snac_hip.hip tri_row).  cv2 itself is not available where this was
  * built, but its OUTPUT is: all 1000 2D dataset plans the reference ships, drawn by its authors with this code, are

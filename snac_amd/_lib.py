@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SNAC_OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 ENV_1D, ENV_2D, ENV_3D = 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 OBS_NONE, OBS_ALL, OBS_LAST, OBS_TILED = 0, 1, 2, 3
@@ -23,7 +23,7 @@ EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_obs_dim", 
            "snac_step_scalar", "snac_rollout",
            "snac_rollout_rec", "snac_replay_gather", "snac_make_plans", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
            "snac_import_state", "snac_obs_equal", "snac_stream_sync", "snac_rollout_tiled", "snac_replay_gather_tiled", "snac_traj_alloc",
-           "snac_traj_free", "snac_traj_layout")
+           "snac_traj_alloc_ex", "snac_traj_free", "snac_traj_layout")
 
 
 class Sizes(C.Structure):
@@ -100,6 +100,7 @@ def lib():
         L.snac_import_state.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.snac_obs_equal.argtypes = [C.POINTER(EnvDesc), vp, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
         L.snac_traj_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(vp)]
+        L.snac_traj_alloc_ex.argtypes = [C.c_size_t, C.c_int, C.c_size_t, vp, C.POINTER(vp)]
         L.snac_traj_free.argtypes = [vp]
         L.snac_traj_layout.argtypes = [vp]
         for n in EXPORTS:

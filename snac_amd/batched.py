@@ -419,13 +419,21 @@ class BatchedDMPEnv:
     # ---- snapshots (MCTS-style branching, checkpoints) ---------------------------------------------
     def state_dict(self):
         """Everything that defines the envs' future (tensors are cloned): the MCTS variants of the reference snapshot
-        (position, grid, count_brick, count_step) per env (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175)."""
+        (position, grid, count_brick, count_step) per env (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175).  The device plan table and
+        its total_brick column travel with the snapshot: generate_plans() / set_plan_row() change them, and a header's plan row
+        means nothing without the table it indexes."""
         return dict(hdr=self._hdr.clone(), episode=self._episode.clone(), grid=self._grid.clone(), stats=self._stats.clone(),
+                    plans=self._plans.clone(), plan_tb=self._plan_tb.clone(),
                     t=self.t, kind=self.kind, dynamic=self.dynamic, num_envs=self.num_envs)
 
     def load_state_dict(self, sd):
         if (sd["kind"], sd["dynamic"], sd["num_envs"]) != (self.kind, self.dynamic, self.num_envs):
             raise ValueError("snapshot belongs to a different env batch")
+        if "plans" in sd:
+            if tuple(sd["plans"].shape) != tuple(self._plans.shape):
+                raise ValueError("snapshot holds a plan table of another size")
+            self._plans.copy_(sd["plans"]); self._plan_tb.copy_(sd["plan_tb"])
+            self._plans_stale = True                               # plans_full is re-decoded from the device table when it is needed
         self._hdr.copy_(sd["hdr"]); self._episode.copy_(sd["episode"]); self._grid.copy_(sd["grid"]); self._stats.copy_(sd["stats"])
         self.t = int(sd["t"])
         self._was_reset = True

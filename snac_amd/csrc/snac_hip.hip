@@ -700,6 +700,49 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lane-per-env observation rows (round 3): lane l holds the 51 values of env l of a 64-env tile -- cell(el) for the 49 window
+// cells, v0 / v1 the two scalar slots.  They are transposed through a staging tile in LDS ([env][51] values, odd dword stride:
+// conflict-free) into the tile's contiguous piece of the output (64 x 51 values: 13 056 B of float32, 26 112 B of float64 in two
+// halves of 32 envs), read back 16 bytes per lane and stored with global_store_dwordx4: 1 KiB per store instruction, 13 / 26 per
+// tile instead of 64 row stores.  stg: TILE_STG_BYTES of 16-byte aligned LDS of this wave (every LDS read of a half is issued
+// before its first store; reads of lanes past the tile's end fall into the pad).  g: the tile's first output byte, 16-byte aligned;
+// nenv < 64: a ragged tile (nenv * 51 * sizeof(OT) must be a multiple of 16: the callers require N % 4 == 0).
+constexpr int TILE_STG_BYTES = 13 * 1024;
+
+template <typename OT, class F>
+__device__ __forceinline__ void emit_tile(char* stg, char* g, int lane, int nenv, F cell, double v0, double v1) {
+    constexpr int D = 51, W = 49, E = 64;
+    constexpr int HALVES = sizeof(OT) == 8 ? 2 : 1, HE = E / HALVES;
+    constexpr int STG_BYTES = HE * D * (int)sizeof(OT);              // 13 056 B either way
+    constexpr int NF = (STG_BYTES + 1023) / 1024;
+    static_assert(NF * 1024 <= TILE_STG_BYTES && STG_BYTES % 16 == 0, "staging tile");
+    const bool full = nenv == E;
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+        if (HALVES == 1 || (lane >> 5) == h) {                       // transpose: lane -> row (lane - h * HE) of the staging tile
+            OT* const S = (OT*)stg + (lane - h * HE) * D;
+#pragma unroll
+            for (int el = 0; el < W; ++el) S[el] = (OT)cell(el);
+            S[W] = (OT)v0; S[W + 1] = (OT)v1;
+        }
+        uint4 fv[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) fv[i] = *(const uint4*)(stg + i * 1024 + lane * 16);
+        char* const gh = g + (size_t)h * STG_BYTES + lane * 16;
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+                if ((i + 1) * 1024 <= STG_BYTES || i * 1024 + lane * 16 < STG_BYTES) *(uint4*)(gh + i * 1024) = fv[i];
+        } else {
+            const int valid = min(max(nenv - h * HE, 0), HE) * D * (int)sizeof(OT);
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+                if (i * 1024 + lane * 16 < valid) *(uint4*)(gh + i * 1024) = fv[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 2D fused rollout for full-width tiles (round 3; the headline kernel).  k_rollout's phase 2 builds ONE observation row per
 // wave-instruction -- lanes 0..50 each fetch a cell of the same env -- so a wave-tick of 64 envs costs 64 x ~12 instructions and 64
 // stores of 408 B (f64) / 204 B (f32): with float32 rows the pass is bound by instruction issue (1.79 ms where HBM would allow 1.2,
@@ -729,11 +772,8 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
     using K = K2D<DYN, 64>;
     constexpr int E = 64, D = K::D, RS = K::RS, GE = K::GE;
     constexpr int IMG_WORDS = 26 * RS * 2;                           // the bordered two-bit image: 26 rows x 65 x 8 B
-    constexpr int HALVES = sizeof(OT) == 8 ? 2 : 1, HE = E / HALVES; // envs staged at a time
-    constexpr int STG_BYTES = HE * D * (int)sizeof(OT);              // 13 056 B either way
-    constexpr int STG_PAD = ((STG_BYTES + 1023) / 1024) * 1024;     // the last 16-byte read of a flush ends here
-    constexpr int WAVE_WORDS = IMG_WORDS + STG_PAD / 4;
-    static_assert(IMG_WORDS % 4 == 0 && WAVE_WORDS % 4 == 0 && STG_BYTES % 16 == 0, "16-byte aligned staging tiles");
+    constexpr int WAVE_WORDS = IMG_WORDS + TILE_STG_BYTES / 4;       // + the staging tile of emit_tile
+    static_assert(IMG_WORDS % 4 == 0 && WAVE_WORDS % 4 == 0, "16-byte aligned staging tiles");
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[P2D_MAX * GE + P2D_MAX + WPB * WAVE_WORDS];
     uint32_t* const tab = lds_all;                                   // plan rows [P][20]
     uint32_t* const meta = lds_all + P2D_MAX * GE;                   // per plan: popcount | total_brick << 16
@@ -750,7 +790,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
     const int env0 = __builtin_amdgcn_readfirstlane(tile * E);
     if (env0 >= a.n) return;                                         // behind the block's barriers
     const int nenv = min(E, a.n - env0);
-    const bool active = lane < nenv, full = nenv == E;
+    const bool active = lane < nenv;
     const int env = env0 + (active ? lane : 0);
     uint32_t* const lds = lds_all + P2D_MAX * GE + P2D_MAX + wv * WAVE_WORDS;
     uint64_t* const cells = K::cells(lds);
@@ -868,37 +908,9 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
                 v0 = c0 / dtb;
             }
         }
-        char* const gt = obs0 + (size_t)t * tstride;
-#pragma unroll
-        for (int h = 0; h < HALVES; ++h) {
-            // transpose: lane -> row (lane - h * HE) of the staging tile
-            if (HALVES == 1 || (lane >> 5) == h) {
-                OT* const S = (OT*)stg + (lane - h * HE) * D;
-#pragma unroll
-                for (int el = 0; el < K::W; ++el) {
-                    const int i = el / 7, j = el - 7 * i;
-                    S[el] = (OT)(((int)(wr[i] << (30 - 2 * j))) >> 30);   // signed 2-bit field: 0 / 1 / -1
-                }
-                S[K::W] = (OT)v0; S[K::W + 1] = (OT)v1;
-            }
-            // flush: the tile's bytes [h * STG_BYTES, ...) of step t, 16 bytes per lane; every LDS read of the half is issued
-            // before its first store (the reads of lanes past the tile's end fall into the staging pad)
-            constexpr int NF = (STG_BYTES + 1023) / 1024;
-            uint4 fv[NF];
-#pragma unroll
-            for (int i = 0; i < NF; ++i) fv[i] = *(const uint4*)(stg + i * 1024 + lane * 16);
-            char* const g = gt + (size_t)h * STG_BYTES + lane * 16;
-            if (full) {
-#pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if ((i + 1) * 1024 <= STG_BYTES || i * 1024 + lane * 16 < STG_BYTES) *(uint4*)(g + i * 1024) = fv[i];
-            } else {
-                const int valid = min(max(nenv - h * HE, 0), HE) * D * (int)sizeof(OT);
-#pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (i * 1024 + lane * 16 < valid) *(uint4*)(g + i * 1024) = fv[i];
-            }
-        }
+        emit_tile<OT>(stg, obs0 + (size_t)t * tstride, lane, nenv,
+                      [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; },   // signed 2-bit field: 0 / 1 / -1
+                      v0, v1);
     }
     K::store_grid(lds, a, env0, nenv, lane);
     if (active) {
@@ -951,7 +963,7 @@ __device__ void flush_stage(const KArgs& a, const float* srew, const uint8_t* sd
         const size_t orow = (size_t)(t0 + r) * (size_t)a.n;
         if (a.reward && lane < BE && env < a.n) a.reward[orow + env] = srew[slot + lane];
         if (a.done) {
-            if ((a.n & 3) == 0) {                                    // dword runs (rows are 4-byte aligned)
+            if ((((uintptr_t)a.done | (uintptr_t)a.n) & 3) == 0) {   // dword runs (the caller's array and its rows are 4-byte aligned)
                 if (lane < BE / 4 && benv + 4 * lane < a.n) ((uint32_t*)(a.done + orow + benv))[lane] = ((const uint32_t*)(sdone + slot))[lane];
             } else if (lane < BE && env < a.n) a.done[orow + env] = sdone[slot + lane];
         }
@@ -1853,6 +1865,289 @@ __global__ __launch_bounds__(WPB * 64) void k_transition2d(const KArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// snac_step on the identity rows, round 3.  k_transition2d / k_transition3d spend their time in the texture addresser, not in
+// HBM (profiles/r02j_step_summary.txt: 43 % / 26 % of the wave cycles stalled at ISSUE, half of the HBM rate): they issue one
+// narrow memory instruction per edge -- a 408-byte row store, in 3D also a 49-lane gather of 2-byte cells -- and seven scattered
+// 4-byte / 2-byte loads per lane.  Here a wave takes a tile of 64 consecutive envs and every memory instruction is wide:
+//   2D  the tile's 64 records (5 120 contiguous bytes) arrive as five 16-byte-per-lane loads and lie in LDS; lane l steps env l
+//       on its row word, builds the 7 window rows as two-bit codes (k_transition2d's encoding) and hands them to emit_tile;
+//   3D  lane l loads the 7 window rows of ITS env as seven 16-byte loads (8 cells from a column clamped into the record, 2-byte
+//       aligned: the hardware takes unaligned global accesses) into a scratch row in LDS with -1 on either side, so that frame
+//       cells, the neighbour / path cells of K3D::step and the window cells are all ds_read_i16 at (row, 4 + column - first
+//       column); the built cell is patched there; an env that moved reloads its rows round the new position (mostly L2 hits);
+//   both    the 51 values of an env leave through emit_tile (LDS transposition, 1 KiB stores); the staging tile reuses the
+//       record / scratch LDS, whose values are in registers by then.  Episodic sums by no-return atomics (nothing waits for them).
+// Write-back: the header, the episode counter of an env that was reset, the ONE changed row word / cell (a reset env: its record).
+// Identity rows only (snac_step, snac_step_scalar), canonical layout, N % 4 == 0 and a 16-byte aligned obs; everything else --
+// tree edges with gathered rows, layout variants, N = 1 of the single-env classes -- stays on k_transition2d / 3d / k_transition.
+__device__ __forceinline__ void stat_add(int64_t* p, long long v) {
+    (void)__hip_atomic_fetch_add((unsigned long long*)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool DYN, typename OT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
+    using K = K2D<DYN, 64>;
+    constexpr int E = 64, GE = K::GE;
+    static_assert(E * GE * 4 <= TILE_STG_BYTES, "the records fit the staging tile");
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * TILE_STG_BYTES / 4];
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const int env0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * WPB + wv) * E);
+    if (env0 >= a.n) return;
+    const int nenv = min(E, a.n - env0);
+    const bool active = lane < nenv;
+    const int env = env0 + (active ? lane : 0);
+    uint32_t* const rec = lds_all + wv * (TILE_STG_BYTES / 4);       // [64][20] row words, then the staging tile
+    // ---- every load that does not depend on another: the tile's records (16 bytes per lane), header, episode counter
+    uint4 rv[5];
+    {
+        const uint4* const g4 = (const uint4*)a.grid + (size_t)env0 * 5;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { const int g = i * 64 + lane; rv[i] = g < nenv * 5 ? g4[g] : make_uint4(0u, 0u, 0u, 0u); }
+    }
+    Lane s;
+    s.clear();
+    s.r = 3; s.c = 3;
+    int episode = 0;
+    if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
+    const uint64_t gid = (uint64_t)(a.env_id_base + env);
+    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+    if (a.actions && active) act = (int)a.actions[env];
+    if (a.step_size && active) k = (int)a.step_size[env];
+    k = min(max(k, 1), 3);
+    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+    if (nr) {
+        const int old_pidx = s.pidx, old_tb = s.tb;
+        episode += 1;
+        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    }
+    const uint32_t* const prow = (const uint32_t*)a.plans + (size_t)s.pidx * GE;
+    const int q0 = min(max(s.r - 3, 0), GE - 1), bit = min(max(s.c - 3, 0), 19);
+    const uint32_t pword = prow[q0];                                 // the one dependent load: the plan row under the agent (L2)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) ((uint4*)rec)[i * 64 + lane] = rv[i];
+    uint32_t* const mine = rec + lane * GE;
+    if (nr) {                                                        // a freshly reset board is empty
+#pragma unroll
+        for (int q = 0; q < GE; ++q) mine[q] = 0u;
+    }
+    // ---- K2D::step (DMP_Env_2D_dynamic_usedata_plan.py:85-147) on the agent's row word
+    const uint32_t row0 = mine[q0];
+    const bool was = ((row0 >> bit) & 1u) != 0u, planned = ((pword >> bit) & 1u) != 0u;
+    const bool drop = active && act == 4;
+    const uint32_t newrow = row0 | (1u << bit);                      // += 1 then clamp to 1 (:115, :134-135)
+    s.cs = min(s.cs + 1, CNT_MAX);
+    if (drop) { s.cb = min(s.cb + 1, CNT_MAX); mine[q0] = newrow; }
+    if (act == 0) s.c = max(s.c - k, 3);                             // clip_position :74-83
+    if (act == 1) s.c = min(s.c + k, 22);
+    if (act == 2) s.r = min(s.r + k, 22);                            // "up" is row + k (:100-103)
+    if (act == 3) s.r = max(s.r - k, 3);
+    const bool term = drop && s.cb >= s.tb + a.brick_gt;             // :117-126, tested before the time limit
+    const bool done = active && (term || s.cs >= a.ts_done);
+    const int reward = (drop && !term && !was && planned) ? 5 : 0;   // un-clamped cell vs plan (:129-133)
+    s.ep_ret = clamp16(s.ep_ret + reward);
+    s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    if (active) {
+        if (a.reward) a.reward[env] = (float)reward;
+        if (a.done) a.done[env] = done ? 1 : 0;
+        a.hdr[env] = s.pack();
+        if (nr) {
+            a.episode[env] = episode;
+            uint32_t* const gw = (uint32_t*)a.grid + (size_t)env * GE;
+#pragma unroll
+            for (int q = 0; q < GE; ++q) gw[q] = mine[q];
+        } else if (drop) {
+            ((uint32_t*)a.grid)[(size_t)env * GE + q0] = newrow;
+        }
+    }
+    if (a.stats_on && __builtin_expect(__any(done), 0)) {            // snac_step: episodic sums; the boolean IoU needs board and plan
+        if (done) {
+            int inter = 0, uni = 0;
+            for (int q = 0; q < GE; ++q) { const uint32_t g = mine[q], p = prow[q]; inter += __popc(g & p); uni += __popc(g | p); }
+            const double v = (double)inter / (double)uni;
+            stat_add(a.stat_episodes + env, 1);
+            stat_add(a.stat_return + env, s.ep_ret);
+            stat_add(a.stat_iou_fx + env, __double2ll_rn(v * FX40));
+        }
+    }
+    if (!a.obs) return;
+    // ---- the 7x7 window round the new position as two-bit codes (00 empty / 01 brick / 11 frame), 14 bits per row
+    uint32_t wr[7];
+    {
+        const int sh = s.c - 3;                                      // first window column, bordered: 0..19
+        constexpr uint32_t FRAME26 = 0x3800007u;                     // frame columns 0-2 and 23-25 of an interior row
+        const uint32_t frm = spread16((FRAME26 >> sh) & 0x7Fu) * 3u;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int q = s.r - 6 + i;                               // board row of window row i
+            const bool in = (unsigned)q < (unsigned)GE;
+            const uint32_t g = mine[in ? q : 0];
+            wr[i] = in ? (spread16(((g << 3) >> sh) & 0x7Fu) | frm) : 0x3FFFu;
+        }
+    }
+    const double c0 = (double)s.cb, c1 = (double)s.cs;
+    const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
+    emit_tile<OT>((char*)rec, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv,
+                  [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; }, v0, v1);
+}
+
+typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));   // a 16-byte global access at a 2-byte aligned address
+
+template <bool DYN, typename OT, int WPB, int PAD = 0>
+__global__ __launch_bounds__(WPB * 64) void k_step3d(const KArgs a) {
+    using K = K3D<DYN, 8>;
+    constexpr int E = 64, GE = K::GE;
+    // scratch per lane: 8 bytes of -1, 7 rows of 12 cells [2 x -1][8 loaded cells][2 x -1], 8 bytes of -1.  A window column may lie up
+    // to 3 cells left or 4 right of the loaded block: what a row lacks in pads, its neighbour's pads (or the lane's own leading /
+    // trailing 8 bytes) supply.  184 bytes per lane: 46 dwords, a 2-way bank pattern; the whole scratch is smaller than the staging tile.
+    constexpr int LS = 184, RB = 24, R0 = 8;
+    constexpr int WAVE_BYTES = (E * LS > TILE_STG_BYTES ? E * LS : TILE_STG_BYTES) + PAD;   // PAD: occupancy experiments
+    static_assert(WAVE_BYTES % 16 == 0, "16-byte aligned staging tiles");
+    __shared__ __attribute__((aligned(16))) char lds_all[WPB * WAVE_BYTES];
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const int env0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * WPB + wv) * E);
+    if (env0 >= a.n) return;
+    const int nenv = min(E, a.n - env0);
+    const bool active = lane < nenv;
+    const int env = env0 + (active ? lane : 0);
+    char* const scr = lds_all + wv * WAVE_BYTES;
+    char* const mine = scr + lane * LS;
+    Lane s;
+    s.clear();
+    s.r = 3; s.c = 3;
+    int episode = 0;
+    if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
+    *(uint64_t*)mine = ~0ull;                                        // the pads
+    *(uint64_t*)(mine + R0 + 7 * RB) = ~0ull;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { *(uint32_t*)(mine + R0 + i * RB) = ~0u; *(uint32_t*)(mine + R0 + i * RB + 20) = ~0u; }
+    const uint64_t gid = (uint64_t)(a.env_id_base + env);
+    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+    if (a.actions && active) act = (int)a.actions[env];
+    if (a.step_size && active) k = (int)a.step_size[env];
+    k = min(max(k, 1), 3);
+    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+    if (nr) {
+        const int old_pidx = s.pidx, old_tb = s.tb;
+        episode += 1;
+        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    }
+    const int16_t* const src = (const int16_t*)a.grid + (size_t)env * GE;
+    // the 7 window rows round (r, c) -> scratch; returns the cell index of window column 0 in a scratch row.  Interior column
+    // of window column j: c - 6 + j; 8 cells are loaded from `start` (clamped so that they lie inside the row), to cells 2..9.
+    auto load_window = [&](int r, int c) -> int {
+        const int start = min(max(c - 6, 0), 12);
+        uint4 v[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int q = r - 6 + i;                                 // interior row of window row i
+            const bool in = (unsigned)q < 20u;
+            v[i] = make_uint4(~0u, ~0u, ~0u, ~0u);                   // a frame row
+            if (in) {
+                v[i] = make_uint4(0u, 0u, 0u, 0u);                   // a freshly reset env is empty
+                if (active && !nr) { const u32x4_a2 t = *(const u32x4_a2*)(src + q * 20 + start); v[i] = make_uint4(t.x, t.y, t.z, t.w); }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            uint32_t* const d = (uint32_t*)(mine + R0 + i * RB + 4);
+            d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+        }
+        return 2 + (c - 6) - start;
+    };
+    const int d = act & 3;
+    const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
+    const int tr = s.r + dr - 3, tc = s.c + dc - 3;                  // the build target in plan coordinates
+    const bool inside = (unsigned)tr < 20u && (unsigned)tc < 20u;
+    const int tcell = inside ? tr * 20 + tc : 0;
+    const int pl = ((const int16_t*)a.plans)[(size_t)s.pidx * GE + tcell];
+    const int h0 = load_window(s.r, s.c);
+    constexpr int RC = RB / 2;                                       // cells per scratch row
+    const int16_t* const cen = (const int16_t*)(mine + R0) + 3 * RC + h0 + 3;   // the agent's cell
+    // ---- K3D::step by selects (the formulation of k_transition3d / Roll3D::tick)
+    const int n0 = cen[-1], n1 = cen[1], n2 = cen[RC], n3 = cen[-RC];    // check_sur: left, right, "up" (row + 1), "down"
+    const int dl = dr * RC + dc;
+    const int c2 = cen[2 * dl], c3 = cen[3 * dl];
+    const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
+    const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
+    const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
+    s.cs = min(s.cs + 1, CNT_MAX);
+    const bool can_move = valid && act < 4 && nd == 0;
+    const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;
+    const int old_r = s.r, old_c = s.c;
+    s.r += can_move ? dr * m : 0;
+    s.c += can_move ? dc * m : 0;
+    const bool built = active && is_build && nd != -1;
+    const int newh = min(nd + 1, CNT_MAX);
+    s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
+    s.cross += (built && newh <= pl) ? 1 : 0;
+    const bool limit = s.cb >= s.tb + a.brick_gt;
+    bool done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);
+    int reward = 0;
+    const int rcheck = newh > pl ? -1 : (newh == pl ? 10 : 1);
+    if (DYN) {
+        const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
+        const bool fin = is_build && (boxed_post || limit);
+        reward = is_build ? (boxed_post ? -100 : ((!limit && built) ? rcheck : 0)) : 0;
+        done = fin ? true : ((is_build && built) ? false : done);
+    } else {
+        const bool fin = is_build && (limit || boxed_pre);
+        reward = (is_build && !fin && built) ? rcheck : 0;
+        done = fin ? true : ((is_build && built) ? false : done);
+    }
+    done = done && active;
+    s.ep_ret = clamp16(s.ep_ret + reward);
+    s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    if (built) ((int16_t*)(mine + R0))[(3 + dr) * RC + h0 + 3 + dc] = (int16_t)newh;   // the window shows the built cell
+    if (active) {
+        if (a.reward) a.reward[env] = (float)reward;
+        if (a.done) a.done[env] = done ? 1 : 0;
+        a.hdr[env] = s.pack();
+        if (nr) a.episode[env] = episode;
+        if (built && !nr) ((int16_t*)a.grid)[(size_t)env * GE + tcell] = (int16_t)newh;
+        if (a.stats_on && done) {                                    // snac_step: episodic sums
+            const double v = K::iou(nullptr, s, 0);
+            stat_add(a.stat_episodes + env, 1);
+            stat_add(a.stat_return + env, s.ep_ret);
+            stat_add(a.stat_iou_fx + env, __double2ll_rn(v * FX40));
+        }
+    }
+    for (unsigned long long mk = __ballot(nr); mk; mk &= mk - 1) {   // a reset env's record: empty, but for the cell it built
+        const int e = __ffsll(mk) - 1;
+        const int tp = __builtin_amdgcn_readlane(built ? tcell : -1, e), nh = __builtin_amdgcn_readlane(newh, e);
+        if (lane < 50) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (tp >= 0 && (tp >> 3) == lane) {
+                const int hw = tp & 7;
+                const uint32_t put = ((uint32_t)nh & 0xFFFFu) << ((hw & 1) * 16);
+                if ((hw >> 1) == 0) v.x = put; else if ((hw >> 1) == 1) v.y = put; else if ((hw >> 1) == 2) v.z = put; else v.w = put;
+            }
+            ((uint4*)a.grid)[(size_t)(env0 + e) * 50 + lane] = v;
+        }
+    }
+    if (!a.obs) return;
+    // ---- the window round the NEW position: an env that moved reloads its rows (the neighbours' lines are in L2 by now)
+    int h1 = h0;
+    if (s.r != old_r || s.c != old_c) h1 = load_window(s.r, s.c);
+    int cellv[K::W];
+    {
+        const int16_t* const wp = (const int16_t*)(mine + R0) + h1;
+#pragma unroll
+        for (int el = 0; el < K::W; ++el) { const int i = el / 7, j = el - 7 * i; cellv[el] = wp[i * RC + j]; }
+    }
+    const double c0 = (double)s.cb, c1 = (double)s.cs;
+    const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
+    emit_tile<OT>(scr, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv, [&](int el) { return cellv[el]; }, v0, v1);
+}
+
 // reset(mask, plan_idx_in) / observe / iou on the same tile machinery
 template <class K, typename OT, int WPB, bool VAR>
 __global__ __launch_bounds__(WPB * 64) void k_aux(const KArgs a) {
@@ -2111,6 +2406,7 @@ __global__ __launch_bounds__(256) void k_make_plans(const PArgs g) {
     const int thr = g.sparse ? 20 : 50, amax = KIND == 3 ? 110 : 401;
     uint32_t m = 0;
     int area = 0;
+    bool accepted = false;
     for (int attempt = 0; attempt < 64; ++attempt) {                // the reference redraws without bound; P(64 rejections) ~ 0
         int vx[3], vy[3];
         for (int v = 0; v < 3; ++v) {
@@ -2126,8 +2422,10 @@ __global__ __launch_bounds__(256) void k_make_plans(const PArgs g) {
         m = lane < 20 ? tri_row(lane, vx, vy, !g.sparse) : 0u;
         area = __popc(m);
         for (int off = 32; off > 0; off >>= 1) area += __shfl_xor(area, off);
-        if ((area > thr && area < amax) || g.use_vertices) break;
+        if ((area > thr && area < amax) || g.use_vertices) { accepted = true; break; }
     }
+    // 64 rejections in a row (P ~ 0): the last triangle stands -- with at least one brick, and area_out says so (-area)
+    const int tb_floor = accepted ? 0 : 1;
     if (KIND == 2) {
         if (lane < 20) ((uint32_t*)g.plans)[rowi * 20 + lane] = m;
         if (lane == 0) g.plan_tb[rowi] = (int16_t)max(area, 30);     // the 2D total_brick floor (:45-46)
@@ -2137,9 +2435,9 @@ __global__ __launch_bounds__(256) void k_make_plans(const PArgs g) {
             const uint32_t mr = (uint32_t)__shfl((int)m, r);
             if (lane < 20) dst[r * 20 + lane] = (int16_t)(((mr >> lane) & 1u) * 6);   // plan * z
         }
-        if (lane == 0) g.plan_tb[rowi] = (int16_t)(area * 6);
+        if (lane == 0) g.plan_tb[rowi] = (int16_t)max(area * 6, tb_floor);
     }
-    if (lane == 0 && g.area_out) g.area_out[i] = area;
+    if (lane == 0 && g.area_out) g.area_out[i] = accepted ? area : -area;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2250,6 +2548,7 @@ int check_layout(const snac_env_desc* d) {
     if (d->frame_value == 2 && d->kind == SNAC_ENV_3D) return fail(SNAC_ERR_UNSUPPORTED, "frame_value 2 is a 1D / 2D layout (the 3D rules test the frame for -1)");
     if (d->obs_scalars < SNAC_SCALARS_DEFAULT || d->obs_scalars > SNAC_SCALARS_NORM) return fail(SNAC_ERR_ARG, "unknown obs_scalars");
     if (d->obs_tail & ~(SNAC_TAIL_POSITION | SNAC_TAIL_PLAN | SNAC_TAIL_RECORD)) return fail(SNAC_ERR_ARG, "unknown bits in obs_tail");
+    if (d->reserved != 0) return fail(SNAC_ERR_ARG, "snac_env_desc.reserved must be 0");
     return SNAC_OK;
 }
 int base_obs_dim(int kind) { return kind == SNAC_ENV_1D ? 7 : 51; }
@@ -2402,6 +2701,28 @@ void launch_roll1d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     }
 }
 
+// SNAC_STEP_STAGE=0 keeps snac_step on k_transition2d / k_transition3d (A/B timing, tests of both paths)
+bool step_stage_ok(const KArgs& a) {
+    static const bool off = [] { const char* e = std::getenv("SNAC_STEP_STAGE"); return e && e[0] == '0'; }();
+    return !off && !a.src_index && !a.dst_index && (a.n & 3) == 0 && ((uintptr_t)a.obs & 15) == 0;
+}
+template <int KIND>
+void launch_step_tile(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
+    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
+    const int tiles = (a.n + 63) / 64;
+    const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+    if (KIND == 2) {
+        if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4>), grid, block, 0, s, a); }
+        else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4>), grid, block, 0, s, a); }
+    } else {
+        static const int occ = [] { const char* e = std::getenv("SNAC_STEP3D_OCC"); return e ? std::atoi(e) : 0; }();
+        if (dyn && !f32 && occ == 2) { hipLaunchKernelGGL((k_step3d<true, double, 4, 7168>), grid, block, 0, s, a); return; }
+        if (dyn && !f32 && occ == 1) { hipLaunchKernelGGL((k_step3d<true, double, 4, 14336>), grid, block, 0, s, a); return; }
+        if (dyn) { if (f32) hipLaunchKernelGGL((k_step3d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<true, double, 4>), grid, block, 0, s, a); }
+        else { if (f32) hipLaunchKernelGGL((k_step3d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<false, double, 4>), grid, block, 0, s, a); }
+    }
+}
+
 void launch_trans3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
     const int tiles = (a.n + 31) / 32;
@@ -2453,11 +2774,13 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             if (op == OP_ROLLOUT && a.n <= 16384 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && !a.actions && !a.step_size && !pipeline_off()) { launch_roll1d(d, a, s); break; }
             launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D:
+            if (op == OP_TRANSITION && !a.variant && !pipeline_off() && step_stage_ok(a)) { launch_step_tile<2>(d, a, s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans2d(d, a, s); break; }
             if (op == OP_ROLLOUT && roll2d_ok(a, E)) { launch_roll2d(d, a, s); break; }
             launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
             if (op == OP_ROLLOUT && E == 8 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && !pipeline_off()) { launch_roll3d(d, a, s); break; }
+            if (op == OP_TRANSITION && !a.variant && !pipeline_off() && step_stage_ok(a)) { launch_step_tile<3>(d, a, s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans3d(d, a, s); break; }
             if (E == 8 && a.n < 8192) dyn ? launch_dt<K3D, true, 8, 1>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 1>(op, d->obs_dtype, a, s);
             else if (E == 8) dyn ? launch_dt<K3D, true, 8, 4>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 4>(op, d->obs_dtype, a, s);
@@ -2744,11 +3067,14 @@ int snac_export_grid(const snac_env_desc* d, const snac_state* st, double* out, 
 // slice unless it happens to straddle a boundary, which is all the "fast and slow regions" of the address map ever were.  The
 // virtual-memory API lets ONE contiguous virtual range be backed by 32 MB handles from different slices taking turns; nothing
 // about the tensor changes for its users.  Which slice a handle lies in cannot be asked, so it is measured (traj_alloc_probed
-// below: a pool of handles, each group of 16 timed together with a reference group; 1.5-2.5 s per block).  The fallback when that
-// is not to be had: handles created back to back -- run 0, a gap that brings the distance to 32 GiB, run 1, a gap, run 2 --,
-// virtual chunk j mapped to run j % 3, the gaps released; consecutive handles follow each other in physical memory only on an
-// allocator that has seen no releases, so that layout is a lottery (5.7-7.1 TB/s, tools/wr_vmm.hip) where the probed one is not.
-// The caller owns the block and frees it with snac_traj_free; the library keeps only the bookkeeping needed to unmap it.
+// below: a pool of handles that grows until it holds enough of both kinds, each group of 16 timed together with a reference
+// group).  The fallback when that is not to be had: handles created back to back -- run 0, a gap that brings the distance to
+// 32 GiB, run 1, a gap, run 2 --, virtual chunk j mapped to run j % 3, the gaps released; consecutive handles follow each other
+// in physical memory only on an allocator that has seen no releases, so that layout is a lottery (5.7-7.1 TB/s,
+// tools/wr_vmm.hip) where the probed one is not.
+// This is the one place where the library allocates and keeps state of its own: g_traj maps every live block to the handles
+// that back it (what snac_traj_free needs to unmap it), behind g_traj_mu.  Every block is checked before it is handed out: a
+// pattern written by one kernel, read back by another and -- one word per chunk -- by a copy (traj_verify).
 namespace {
 struct TrajBlock { size_t total, chunk; int device, layout; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_traj_mu;
@@ -2757,30 +3083,87 @@ constexpr int TRAJ_CHUNK_LOG2 = 25;
 constexpr size_t TRAJ_CHUNK = (size_t)1 << TRAJ_CHUNK_LOG2;   // one physical handle per 32 MB: 480 handles for the headline's 16 GB
 constexpr size_t TRAJ_SLICE = (size_t)32 << 30;   // distance between the starts of consecutive runs
 constexpr int TRAJ_RUNS = 3;
-constexpr size_t TRAJ_SPLIT_MIN = (size_t)1 << 30;     // smaller blocks are not worth the two seconds: one run
+constexpr size_t TRAJ_SPLIT_MIN = (size_t)1 << 30;     // smaller blocks are not worth the probe: one run
+constexpr size_t TRAJ_POOL_DEFAULT = (size_t)64 << 30;  // what the pool may hold beyond the block itself
+constexpr size_t TRAJ_MARGIN = (size_t)4 << 30;        // device memory the pool never touches
 
 // Unmap chunk by chunk (each call undoes exactly one hipMemMap), release the physical handles -- and KEEP the address range
-// reserved: a range that is handed out again right after an unmap has been seen to serve stale translations (a fresh block at a
-// recycled address read back zeros after a kernel had filled it, tests/test_gpu_trajmem.py).  Address space is not scarce (the
-// reservation costs no memory); a stale pointer into a freed block faults instead of hitting someone else's data.
+// reserved: a range that was handed out again right after an unmap has been seen to serve stale translations (round 2: a fresh
+// block at a recycled address read back zeros through a copy after a kernel had filled it; tools/vmm_stale.hip tries to provoke
+// it, profiles/r03_vmm_stale.txt).  A reservation costs no memory, and a stale pointer into a freed block faults instead of
+// hitting someone else's data.  The price is address space: every block of 1 GiB or more leaves its own range and the ranges its
+// pool was probed in behind (at most the block + the pool cap per call; 47 bits of address space last for > 1000 headline-sized
+// blocks per process).
 void traj_release(char* va, size_t mapped, size_t chunk, std::vector<hipMemGenericAllocationHandle_t>& hs) {
     for (size_t off = 0; off < mapped; off += chunk) (void)hipMemUnmap(va + off, chunk);
     for (auto h : hs) (void)hipMemRelease(h);
     (void)hipGetLastError();
 }
 
+// ---- the check every block passes before it is handed out --------------------------------------------------------------------
+__device__ __forceinline__ uint64_t traj_word(uint64_t i, uint64_t salt) {
+    uint64_t x = (i + salt) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    return x;
+}
+__global__ __launch_bounds__(256) void k_traj_fill(uint64_t* p, size_t words, uint64_t salt) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = traj_word(i, salt);
+}
+__global__ __launch_bounds__(256) void k_traj_check(const uint64_t* p, size_t words, uint64_t salt, unsigned long long* bad) {
+    unsigned long long n = 0;
+    // the other way round: the last word first, so that no lane meets the lines its own fill left in a cache
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x)
+        n += p[words - 1 - i] != traj_word(words - 1 - i, salt);
+    if (n) atomicAdd(bad, n);
+}
+// 0: every word of the block reads back what was written, through a kernel and (first word of every chunk) through a copy
+int traj_verify(char* va, size_t total, size_t chunk, hipStream_t stream) {
+    const size_t words = total / 8, nchunks = total / chunk;
+    const uint64_t salt = (uint64_t)(uintptr_t)va ^ 0x5AC5AC5ull;
+    unsigned long long* bad = nullptr;
+    hipError_t e = hipMalloc((void**)&bad, sizeof(*bad));
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc (block check)");
+    std::vector<uint64_t> firsts(nchunks, 0);
+    unsigned long long hbad = 0;
+    (void)hipMemsetAsync(bad, 0, sizeof(*bad), stream);
+    hipLaunchKernelGGL(k_traj_fill, dim3(4096), dim3(256), 0, stream, (uint64_t*)va, words, salt);
+    hipLaunchKernelGGL(k_traj_check, dim3(4096), dim3(256), 0, stream, (const uint64_t*)va, words, salt, bad);
+    e = hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, stream);
+    for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) e = hipMemcpyAsync(&firsts[c], va + c * chunk, 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(bad);
+    if (e != hipSuccess) return fail_hip(e, "block check");
+    size_t cbad = 0;
+    for (size_t c = 0; c < nchunks; ++c) {
+        uint64_t x = (c * (chunk / 8) + salt) * 0x9E3779B97F4A7C15ull;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        cbad += firsts[c] != x;
+    }
+    if (hbad || cbad) {
+        std::snprintf(g_err, sizeof(g_err), "trajectory block at %p failed its check: %llu words differ through a kernel, %zu of %zu chunks through a copy",
+                      (void*)va, hbad, cbad, nchunks);
+        return SNAC_ERR_HIP;
+    }
+    return SNAC_OK;
+}
+
 // ---- the probed layout -------------------------------------------------------------------------------------------------------
-// Where a handle lands is the driver's business, so the block is built from what a measurement says: a pool of 32 MB handles
-// (the tensor + 64 GiB, created back to back) is mapped into a scratch range and taken in groups of 16 (512 MB); group 0 is the
-// reference, and every other group is timed TOGETHER with it -- the rollout's own store pattern over the two groups' chunks taking
-// turns, 1 GiB per probe, ~0.17 ms.  Pairs in different slices run at ~7 TB/s, pairs in the same slice at ~5.7: the times fall into
-// two classes, "far" (another slice than the reference) and "near" (its own).  The block then alternates near and far chunks.
-// No contrast (a pool inside one slice, a driver that scatters handles below the group size), too few groups of a class, or
-// no memory for the pool: the caller falls back to the fixed three-run layout.
+// Where a handle lands is the driver's business, so the block is built from what a measurement says: 32 MB handles are created
+// back to back and taken in groups of 16 (512 MB, each mapped into a range of its own); group 0 is the reference, and every
+// other group is timed TOGETHER with it -- the rollout's own store pattern over the two groups' chunks taking turns, 1 GiB per
+// probe, ~0.17 ms.  Pairs in different slices run at ~7 TB/s, pairs in the same slice at ~5.7: the times fall into two classes,
+// "far" (another slice than the reference) and "near" (its own).  The pool starts at the block's own size + 8 GiB and grows by
+// 8 GiB until both classes can carry their half of the block, up to `pool_cap` beyond the block -- never more than half of what
+// is free and never into the last 4 GiB.  The block then alternates near and far chunks.  No contrast (a pool inside one slice, a
+// driver that scatters handles below the group size), too few groups of a class, or no memory for a pool: the caller falls back
+// to the fixed three-run layout.
 constexpr size_t TRAJ_GROUP = 16;                                // chunks per probed group
+constexpr size_t TRAJ_GROW = 16;                                 // groups per pool extension (8 GiB)
 constexpr int PROBE_E = 64, PROBE_D = 51;                        // the rollout's tile: 64 rows of 51 doubles per wave and step
 
-__global__ __launch_bounds__(256) void k_traj_probe(char* a, char* b, int chunk_log2, int chunks_total) {
+// logical chunk c of the probed bytes lies in a (c even) or b (c odd) at chunk index c >> 1; or, for a finished block
+// (b == a + chunk, pair_log2 = chunk_log2 + 1), simply at a + c * chunk
+__global__ __launch_bounds__(256) void k_traj_probe(char* a, char* b, int chunk_log2, int pair_log2, int chunks_total) {
     constexpr size_t TILE = (size_t)PROBE_E * PROBE_D * 8;
     const int lane = threadIdx.x & 63, wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), waves = (int)gridDim.x * 4;
     const size_t total = (size_t)chunks_total << chunk_log2, mask = ((size_t)1 << chunk_log2) - 1;
@@ -2790,88 +3173,128 @@ __global__ __launch_bounds__(256) void k_traj_probe(char* a, char* b, int chunk_
 #pragma unroll 8
         for (int e = 0; e < PROBE_E; ++e)
             if (lane < PROBE_D) {
-                const size_t L = L0 + (size_t)e * (PROBE_D * 8), c = L >> chunk_log2;      // logical chunk c -> a or b in turn
-                *(double*)(((c & 1) ? b : a) + ((c >> 1) << chunk_log2) + (L & mask)) = (double)(t + e);
+                const size_t L = L0 + (size_t)e * (PROBE_D * 8), c = L >> chunk_log2;
+                *(double*)(((c & 1) ? b : a) + ((c >> 1) << pair_log2) + (L & mask)) = (double)(t + e);
             }
     }
 }
 
-// 0: *out holds the block; 1: not applicable / no contrast (nothing allocated: use the fixed layout); < 0: error code
-int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop, size_t gran, void** out) {
+struct TrajPool {
+    size_t chunk, gbytes;
+    hipMemAllocationProp prop;
+    hipMemAccessDesc acc;
+    std::vector<hipMemGenericAllocationHandle_t> h;              // handles in creation order: group g = h[g * TRAJ_GROUP ...]
+    std::vector<char*> gva;                                      // where group g is mapped
+    std::vector<std::pair<char*, size_t>> ranges;                // the reservations the groups live in (kept reserved, see traj_release)
+    size_t groups() const { return gva.size(); }
+    // `n` more groups: handles created back to back, mapped into one new range; returns how many groups were added
+    size_t grow(size_t n, size_t gran) {
+        if (!n) return 0;
+        std::vector<hipMemGenericAllocationHandle_t> fresh;
+        for (size_t i = 0; i < n * TRAJ_GROUP; ++i) {
+            hipMemGenericAllocationHandle_t x;
+            if (hipMemCreate(&x, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+            fresh.push_back(x);
+        }
+        size_t got = fresh.size() / TRAJ_GROUP;
+        while (fresh.size() > got * TRAJ_GROUP) { (void)hipMemRelease(fresh.back()); fresh.pop_back(); }
+        if (!got) return 0;
+        char* va = nullptr;
+        if (hipMemAddressReserve((void**)&va, got * gbytes, gran, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); for (auto x : fresh) (void)hipMemRelease(x); return 0; }
+        size_t mapped = 0;
+        bool ok = true;
+        for (size_t i = 0; i < fresh.size() && ok; ++i) {
+            if (hipMemMap(va + i * chunk, chunk, 0, fresh[i], 0) != hipSuccess) { (void)hipGetLastError(); ok = false; } else mapped += chunk;
+        }
+        if (ok && hipMemSetAccess(va, mapped, &acc, 1) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+        if (!ok) { traj_release(va, mapped, chunk, fresh); return 0; }
+        ranges.emplace_back(va, mapped);
+        for (size_t g = 0; g < got; ++g) gva.push_back(va + g * gbytes);
+        h.insert(h.end(), fresh.begin(), fresh.end());
+        return got;
+    }
+    // unmap everything; release the handles not marked in `keep` (keep == nullptr: all of them)
+    void drop(const std::vector<char>* keep) {
+        for (auto& r : ranges) for (size_t off = 0; off < r.second; off += chunk) (void)hipMemUnmap(r.first + off, chunk);
+        for (size_t i = 0; i < h.size(); ++i) if (!keep || !(*keep)[i]) (void)hipMemRelease(h[i]);
+        (void)hipGetLastError();
+        ranges.clear(); gva.clear();
+    }
+};
+
+// 0: *out holds the block; 1: not applicable / no contrast (nothing allocated: use the fixed layout); < 0: error code.
+// *slow: the finished block timed like a pair of its own groups came out in the "same slice" class
+int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop, size_t gran, size_t pool_cap, hipStream_t stream, void** out, bool* slow) {
     const size_t chunk = TRAJ_CHUNK;
+    *slow = false;
     if (chunk % gran) return 1;
     const size_t k = (bytes + chunk - 1) / chunk, kg = (k + TRAJ_GROUP - 1) / TRAJ_GROUP;
-    const size_t want_groups = kg + (2 * TRAJ_SLICE) / (TRAJ_GROUP * chunk);
     const bool debug = std::getenv("SNAC_TRAJ_DEBUG") != nullptr;
-    std::vector<hipMemGenericAllocationHandle_t> pool;
-    pool.reserve(want_groups * TRAJ_GROUP);
-    for (size_t i = 0; i < want_groups * TRAJ_GROUP; ++i) {
-        hipMemGenericAllocationHandle_t h;
-        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
-        pool.push_back(h);
-    }
-    size_t groups = pool.size() / TRAJ_GROUP;
-    while (pool.size() > groups * TRAJ_GROUP) { (void)hipMemRelease(pool.back()); pool.pop_back(); }
-    auto give_up = [&](char* va, size_t mapped) {
-        traj_release(va, mapped, chunk, pool);
-        return 1;
-    };
-    if (groups < kg + 8) return give_up(nullptr, 0);             // not enough memory for a pool worth probing
-    char* scratch = nullptr;
-    if (hipMemAddressReserve((void**)&scratch, pool.size() * chunk, gran, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return give_up(nullptr, 0); }
-    size_t mapped = 0;
-    for (size_t i = 0; i < pool.size(); ++i) {
-        if (hipMemMap(scratch + i * chunk, chunk, 0, pool[i], 0) != hipSuccess) { (void)hipGetLastError(); return give_up(scratch, mapped); }
-        mapped += chunk;
-    }
-    hipMemAccessDesc acc;
-    std::memset(&acc, 0, sizeof(acc));
-    acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemSetAccess(scratch, mapped, &acc, 1) != hipSuccess) { (void)hipGetLastError(); return give_up(scratch, mapped); }
-    int cur = -1;
-    (void)hipGetDevice(&cur);
-    if (cur != device) (void)hipSetDevice(device);
+    // what the pool may take beyond the block: the caller's cap, half of what would be free next to the block, nothing of the last 4 GiB
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    if (free_b < bytes + TRAJ_MARGIN) return 1;
+    size_t extra = std::min(pool_cap, (free_b - bytes) / 2);
+    extra = std::min(extra, free_b - bytes - TRAJ_MARGIN);
+    const size_t max_groups = kg + extra / (TRAJ_GROUP * chunk);
+    if (max_groups < kg + 8) return 1;                           // not enough memory for a pool worth probing
+    TrajPool pool;
+    pool.chunk = chunk; pool.gbytes = TRAJ_GROUP * chunk; pool.prop = prop;
+    std::memset(&pool.acc, 0, sizeof(pool.acc));
+    pool.acc.location = prop.location; pool.acc.flags = hipMemAccessFlagsProtReadWrite;
+    auto give_up = [&]() { pool.drop(nullptr); return 1; };
+    pool.grow(std::min(max_groups, kg + TRAJ_GROW), gran);
+    if (pool.groups() < kg + 8) return give_up();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-    const size_t gbytes = TRAJ_GROUP * chunk;
-    auto probe = [&](size_t ga, size_t gb, bool timed) -> float {
-        if (timed) (void)hipEventRecord(e0, nullptr);
-        hipLaunchKernelGGL(k_traj_probe, dim3(256), dim3(256), 0, nullptr, scratch + ga * gbytes, scratch + gb * gbytes, TRAJ_CHUNK_LOG2, (int)(2 * TRAJ_GROUP));
+    auto launch_probe = [&](char* pa, char* pb, int pair_log2, bool timed) -> float {
+        if (timed) (void)hipEventRecord(e0, stream);
+        hipLaunchKernelGGL(k_traj_probe, dim3(256), dim3(256), 0, stream, pa, pb, TRAJ_CHUNK_LOG2, pair_log2, (int)(2 * TRAJ_GROUP));
         if (!timed) return 0.f;
-        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventRecord(e1, stream);
         if (hipEventSynchronize(e1) != hipSuccess) { ok = false; return 0.f; }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ok = false;
         return ms;
     };
+    auto probe = [&](size_t ga, size_t gb) -> float {
+        const float t1 = launch_probe(pool.gva[ga], pool.gva[gb], TRAJ_CHUNK_LOG2, true), t2 = launch_probe(pool.gva[ga], pool.gva[gb], TRAJ_CHUNK_LOG2, true);
+        return t1 < t2 ? t1 : t2;
+    };
     std::vector<size_t> order_a, order_b;                        // groups of class A (the reference's slice) / class B, best first
-    size_t na = 0, nb = 0;
+    float thr_final = 0.f;
+    bool found = false;
     if (ok) {
-        for (int i = 0; i < 120; ++i) probe(0, 1, false);        // ~20 ms of the probe itself: the clocks are up before anything is timed
+        for (int i = 0; i < 120; ++i) launch_probe(pool.gva[0], pool.gva[1], TRAJ_CHUNK_LOG2, false);   // ~20 ms of the probe itself: the clocks are up before anything is timed
         if (hipGetLastError() != hipSuccess) ok = false;
-        std::vector<char> todo(groups, 1);                       // groups not yet assigned to a reference's slice
+        std::vector<float> t;                                    // time of group g against the current reference (0: not measured)
+        std::vector<char> aside;                                 // groups of earlier references' slices: class B material
         size_t ref = 0;
         // SNAC_TRAJ_REFINE=0 (tuning): skip the second look below
         const char* rf = std::getenv("SNAC_TRAJ_REFINE");
         bool refined = rf && rf[0] == '0';
-        for (int round = 0; round < 5 && ok; ++round) {
-            std::vector<float> t(groups, 0.f);
+        for (int round = 0; round < 24 && ok && !found; ++round) {
+            t.resize(pool.groups(), 0.f); aside.resize(pool.groups(), 0);
             float lo = 1e30f, hi = 0.f;
-            for (size_t g = 0; g < groups; ++g) {
-                if (g == ref || !todo[g]) continue;
-                const float t1 = probe(ref, g, true), t2 = probe(ref, g, true);
-                t[g] = t1 < t2 ? t1 : t2;
+            for (size_t g = 0; g < pool.groups() && ok; ++g) {
+                if (g == ref || aside[g]) continue;
+                if (t[g] == 0.f) t[g] = probe(ref, g);
                 lo = t[g] < lo ? t[g] : lo; hi = t[g] > hi ? t[g] : hi;
             }
             if (debug) {
-                std::fprintf(stderr, "snac_traj_alloc: probe round %d, reference group %zu, %zu groups, %.3f .. %.3f ms:", round, ref, groups, lo, hi);
-                for (size_t g = 0; g < groups; ++g) std::fprintf(stderr, " %.0f", t[g] * 1000.f);
+                std::fprintf(stderr, "snac_traj_alloc: probe round %d, reference group %zu, %zu groups, %.3f .. %.3f ms:", round, ref, pool.groups(), lo, hi);
+                for (size_t g = 0; g < pool.groups(); ++g) std::fprintf(stderr, " %.0f", t[g] * 1000.f);
                 std::fprintf(stderr, "\n");
             }
-            if (!ok || hi < lo * 1.10f) break;                   // no contrast: every group behaves the same against this reference
+            if (!ok) break;
+            auto extend = [&]() { return pool.groups() < max_groups && pool.grow(std::min(TRAJ_GROW, max_groups - pool.groups()), gran) > 0; };
+            if (hi < lo * 1.10f) {                               // no contrast (yet): every group behaves the same against this reference
+                if (extend()) continue;
+                break;
+            }
             const float thr = 0.5f * (lo + hi);
             std::vector<size_t> near{ref}, far;
-            for (size_t g = 0; g < groups; ++g) if (g != ref && todo[g]) (t[g] >= thr ? near : far).push_back(g);
+            for (size_t g = 0; g < pool.groups(); ++g) if (g != ref && !aside[g]) (t[g] >= thr ? near : far).push_back(g);
             if (!refined && near.size() > 1) {
                 // a second look from a better vantage point: group 0 may itself straddle two stretches of physical memory, which blurs
                 // every time measured against it; its slowest partner lies in its slice for sure -- probe everything against that one
@@ -2879,55 +3302,69 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
                 size_t best = near[1];
                 for (size_t g : near) if (g != ref && t[g] > t[best]) best = g;
                 ref = best;
+                std::fill(t.begin(), t.end(), 0.f);
                 continue;
             }
             // class A = this reference's slice if it can carry half the block, else look at the far groups from one of their own
-            size_t aside = 0;                                    // groups of earlier references' slices: class B material
-            for (size_t g = 0; g < groups; ++g) aside += todo[g] ? 0 : 1;
-            if (near.size() * TRAJ_GROUP >= (k + 1) / 2 && (far.size() + aside) * TRAJ_GROUP >= k / 2) {
+            size_t n_aside = 0;
+            for (size_t g = 0; g < pool.groups(); ++g) n_aside += aside[g] ? 1 : 0;
+            if (near.size() * TRAJ_GROUP >= (k + 1) / 2 && (far.size() + n_aside) * TRAJ_GROUP >= k / 2) {
                 // the clearest cases first: the slowest partners are surest to share the reference's slice, the fastest surest not to
                 // (in-between times are groups that straddle two regions)
                 std::sort(near.begin() + 1, near.end(), [&](size_t x, size_t y) { return t[x] > t[y]; });
                 std::sort(far.begin(), far.end(), [&](size_t x, size_t y) { return t[x] < t[y]; });
                 for (size_t g : near) order_a.push_back(g);
                 for (size_t g : far) order_b.push_back(g);
-                for (size_t g = 0; g < groups; ++g) if (!todo[g]) order_b.push_back(g);    // earlier references' slices: not this one
-                na = nb = 1;
+                for (size_t g = 0; g < pool.groups(); ++g) if (aside[g]) order_b.push_back(g);    // earlier references' slices: not this one
+                thr_final = thr;
+                found = true;
                 break;
             }
+            if (extend()) continue;                              // one class is still short: 8 GiB more, measured against the same reference
             if (far.empty()) break;
-            for (size_t g : near) todo[g] = 0;                   // too small a slice share: set it aside, it will serve as class B
+            for (size_t g : near) aside[g] = 1;                  // too small a slice share: set it aside, it will serve as class B
             ref = far[0];
+            std::fill(t.begin(), t.end(), 0.f);
         }
     }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    (void)hipDeviceSynchronize();
-    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
-    if (!ok || !na || !nb) return give_up(scratch, mapped);
+    if (ok) (void)hipStreamSynchronize(stream);
+    if (!ok || !found) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        return give_up();
+    }
     // the block: chunk j from class A (j even) or B (j odd), groups in pool order
     std::vector<size_t> ca, cb;
     for (size_t g : order_a) for (size_t i = 0; i < TRAJ_GROUP; ++i) ca.push_back(g * TRAJ_GROUP + i);
     for (size_t g : order_b) for (size_t i = 0; i < TRAJ_GROUP; ++i) cb.push_back(g * TRAJ_GROUP + i);
-    if (ca.size() < (k + 1) / 2 || cb.size() < k / 2) return give_up(scratch, mapped);
-    std::vector<char> used(pool.size(), 0);
+    std::vector<char> used(pool.h.size(), 0);
     std::vector<hipMemGenericAllocationHandle_t> hs(k);
-    for (size_t j = 0; j < k; ++j) { const size_t idx = (j & 1) ? cb[j >> 1] : ca[j >> 1]; hs[j] = pool[idx]; used[idx] = 1; }
-    for (size_t off = 0; off < mapped; off += chunk) (void)hipMemUnmap(scratch + off, chunk);   // the scratch range stays reserved, unused
-    for (size_t i = 0; i < pool.size(); ++i) if (!used[i]) (void)hipMemRelease(pool[i]);
-    (void)hipGetLastError();
+    for (size_t j = 0; j < k; ++j) { const size_t idx = (j & 1) ? cb[j >> 1] : ca[j >> 1]; hs[j] = pool.h[idx]; used[idx] = 1; }
+    pool.drop(&used);                                            // the probe ranges stay reserved, unused
     char* va = nullptr;
     const size_t total = k * chunk;
+    auto done_events = [&]() { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); };
     hipError_t e = hipMemAddressReserve((void**)&va, total, gran, nullptr, 0);
-    if (e != hipSuccess) { traj_release(nullptr, 0, chunk, hs); return fail_hip(e, "hipMemAddressReserve"); }
+    if (e != hipSuccess) { done_events(); traj_release(nullptr, 0, chunk, hs); return fail_hip(e, "hipMemAddressReserve"); }
     size_t m2 = 0;
     for (size_t j = 0; j < k; ++j) {
         e = hipMemMap(va + j * chunk, chunk, 0, hs[j], 0);
-        if (e != hipSuccess) { traj_release(va, m2, chunk, hs); return fail_hip(e, "hipMemMap"); }
+        if (e != hipSuccess) { done_events(); traj_release(va, m2, chunk, hs); return fail_hip(e, "hipMemMap"); }
         m2 += chunk;
     }
-    e = hipMemSetAccess(va, total, &acc, 1);
-    if (e != hipSuccess) { traj_release(va, m2, chunk, hs); return fail_hip(e, "hipMemSetAccess"); }
+    e = hipMemSetAccess(va, total, &pool.acc, 1);
+    if (e != hipSuccess) { done_events(); traj_release(va, m2, chunk, hs); return fail_hip(e, "hipMemSetAccess"); }
+    // the finished block under the same pattern: its first 32 chunks (16 of either class) must run like a pair in two slices
+    if (k >= 2 * TRAJ_GROUP) {
+        launch_probe(va, va + chunk, TRAJ_CHUNK_LOG2 + 1, true);
+        float tf = launch_probe(va, va + chunk, TRAJ_CHUNK_LOG2 + 1, true);
+        const float t3 = launch_probe(va, va + chunk, TRAJ_CHUNK_LOG2 + 1, true);
+        tf = t3 < tf ? t3 : tf;
+        *slow = ok && tf >= thr_final;
+        if (debug) std::fprintf(stderr, "snac_traj_alloc: finished block %.0f us per GiB (classes split at %.0f us)%s\n", tf * 1000.f, thr_final * 1000.f, *slow ? " -- SLOW" : "");
+    }
+    done_events();
+    if (!ok) { traj_release(va, m2, chunk, hs); return fail(SNAC_ERR_HIP, "probe of the finished block failed"); }
     {
         std::lock_guard<std::mutex> lk(g_traj_mu);
         g_traj[va] = TrajBlock{total, chunk, device, SNAC_TRAJ_MEASURED, std::move(hs)};
@@ -2935,40 +3372,22 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
     *out = va;
     return 0;
 }
-}  // namespace
 
-int snac_traj_alloc(size_t bytes, int device, void** out) {
-    if (!out) return fail(SNAC_ERR_ARG, "null out");
-    *out = nullptr;
-    if (bytes == 0) return fail(SNAC_ERR_ARG, "bytes must be positive");
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess) return fail_hip(e, "hipGetDeviceCount");
-    if (device < 0 || device >= ndev) return fail(SNAC_ERR_ARG, "device out of range");
-    hipMemAllocationProp prop;
-    std::memset(&prop, 0, sizeof(prop));
-    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
-    size_t gran = 0;
-    e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
-    if (e != hipSuccess) return fail_hip(e, "hipMemGetAllocationGranularity");
-    if (gran < ((size_t)2 << 20)) gran = (size_t)2 << 20;          // whole 2 MB pages whatever the minimum is
-    if (bytes >= TRAJ_SPLIT_MIN) {                                // the measured layout first; 1 = not to be had, take the fixed one
-        const char* off = std::getenv("SNAC_TRAJ_PROBE");
-        if (!(off && off[0] == '0')) {
-            const int rc = traj_alloc_probed(bytes, device, prop, gran, out);
-            if (rc <= 0) return rc;
-        }
-    }
+int traj_alloc_fixed(size_t bytes, int device, const hipMemAllocationProp& prop, size_t gran, void** out) {
     const size_t chunk = bytes >= TRAJ_CHUNK ? ((TRAJ_CHUNK + gran - 1) / gran) * gran : ((bytes + gran - 1) / gran) * gran;
     const size_t k = (bytes + chunk - 1) / chunk, total = k * chunk;
     const int runs = (bytes >= TRAJ_SPLIT_MIN && k >= (size_t)TRAJ_RUNS) ? TRAJ_RUNS : 1;   // run r: chunks r, r + runs, r + 2 runs, ...
     char* va = nullptr;
-    e = hipMemAddressReserve((void**)&va, total, gran, nullptr, 0);
+    hipError_t e = hipMemAddressReserve((void**)&va, total, gran, nullptr, 0);
     if (e != hipSuccess) return fail_hip(e, "hipMemAddressReserve");
     std::vector<hipMemGenericAllocationHandle_t> hs(k), gap;
     std::vector<size_t> made;                                      // chunk indices whose handles exist, in creation order
     made.reserve(k);
     auto drop_gap = [&]() { for (auto g : gap) (void)hipMemRelease(g); gap.clear(); };
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+    // the gaps are transient too: never more than half of what is free next to the block, never the last 4 GiB
+    size_t gap_budget = free_b > bytes + TRAJ_MARGIN ? std::min((free_b - bytes) / 2, free_b - bytes - TRAJ_MARGIN) / chunk : 0;
     for (int r = 0; r < runs; ++r) {
         size_t in_run = 0;
         for (size_t c = (size_t)r; c < k; c += (size_t)runs) {
@@ -2990,7 +3409,9 @@ int snac_traj_alloc(size_t bytes, int device, void** out) {
         }
         if (r + 1 < runs) {
             // the gap: as many handles as bring the next run's start 32 GiB behind this one's; best effort (a full device gets less)
-            const size_t run_bytes = in_run * chunk, want = run_bytes < TRAJ_SLICE ? (TRAJ_SLICE - run_bytes) / chunk : 0;
+            const size_t run_bytes = in_run * chunk;
+            size_t want = run_bytes < TRAJ_SLICE ? (TRAJ_SLICE - run_bytes) / chunk : 0;
+            want = std::min(want, gap_budget > gap.size() ? gap_budget - gap.size() : (size_t)0);
             for (size_t g = 0; g < want; ++g) {
                 hipMemGenericAllocationHandle_t x;
                 if (hipMemCreate(&x, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
@@ -3021,14 +3442,8 @@ int snac_traj_alloc(size_t bytes, int device, void** out) {
     return SNAC_OK;
 }
 
-int snac_traj_layout(const void* ptr) {
-    std::lock_guard<std::mutex> lk(g_traj_mu);
-    auto it = g_traj.find(const_cast<void*>(ptr));
-    return it == g_traj.end() ? fail(SNAC_ERR_ARG, "not a block of snac_traj_alloc") : it->second.layout;
-}
-
-int snac_traj_free(void* ptr) {
-    if (!ptr) return SNAC_OK;
+// take a block out of the registry and give its memory back (the caller has made sure nothing uses it any more)
+int traj_unregister_and_release(void* ptr) {
     TrajBlock b;
     {
         std::lock_guard<std::mutex> lk(g_traj_mu);
@@ -3037,13 +3452,81 @@ int snac_traj_free(void* ptr) {
         b = std::move(it->second);
         g_traj.erase(it);
     }
-    int cur = -1;                                                // nothing may still be writing into the block: its device goes idle
-    (void)hipGetDevice(&cur);
-    if (cur != b.device) (void)hipSetDevice(b.device);
-    (void)hipDeviceSynchronize();
-    if (cur >= 0 && cur != b.device) (void)hipSetDevice(cur);
     traj_release((char*)ptr, b.total, b.chunk, b.handles);
     return SNAC_OK;
+}
+}  // namespace
+
+int snac_traj_alloc_ex(size_t bytes, int device, size_t pool_cap_bytes, void* stream, void** out) {
+    if (!out) return fail(SNAC_ERR_ARG, "null out");
+    *out = nullptr;
+    if (bytes == 0) return fail(SNAC_ERR_ARG, "bytes must be positive");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess) return fail_hip(e, "hipGetDeviceCount");
+    if (device < 0 || device >= ndev) return fail(SNAC_ERR_ARG, "device out of range");
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != device) (void)hipSetDevice(device);
+    struct Restore { int cur, dev; ~Restore() { if (cur >= 0 && cur != dev) (void)hipSetDevice(cur); } } restore{cur, device};
+    hipStream_t s = (hipStream_t)stream;
+    hipMemAllocationProp prop;
+    std::memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+    size_t gran = 0;
+    e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+    if (e != hipSuccess) return fail_hip(e, "hipMemGetAllocationGranularity");
+    if (gran < ((size_t)2 << 20)) gran = (size_t)2 << 20;          // whole 2 MB pages whatever the minimum is
+    const size_t cap = pool_cap_bytes ? pool_cap_bytes : TRAJ_POOL_DEFAULT;
+    const char* off = std::getenv("SNAC_TRAJ_PROBE");
+    bool measured = bytes >= TRAJ_SPLIT_MIN && !(off && off[0] == '0');
+    for (int attempt = 0; attempt < 2 && measured; ++attempt) {   // the measured layout first; a block that times "slow" is built once more
+        bool slow = false;
+        const int rc = traj_alloc_probed(bytes, device, prop, gran, cap, s, out, &slow);
+        if (rc < 0) return rc;
+        if (rc == 1) break;                                      // not to be had: the fixed layout
+        int vr = traj_verify((char*)*out, ((bytes + TRAJ_CHUNK - 1) / TRAJ_CHUNK) * TRAJ_CHUNK, TRAJ_CHUNK, s);
+        if (vr == SNAC_OK && !slow) return SNAC_OK;
+        (void)traj_unregister_and_release(*out);                 // (the stream was synchronised by the check)
+        *out = nullptr;
+        if (vr != SNAC_OK) return vr;                            // a block that does not read back what was written: report, never retry silently
+    }
+    const int rc = traj_alloc_fixed(bytes, device, prop, gran, out);
+    if (rc != SNAC_OK) return rc;
+    size_t total = 0, chunk = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_traj_mu);
+        const TrajBlock& b = g_traj[*out];
+        total = b.total; chunk = b.chunk;
+    }
+    const int vr = traj_verify((char*)*out, total, chunk, s);
+    if (vr != SNAC_OK) { (void)traj_unregister_and_release(*out); *out = nullptr; }
+    return vr;
+}
+
+int snac_traj_alloc(size_t bytes, int device, void** out) { return snac_traj_alloc_ex(bytes, device, 0, nullptr, out); }
+
+int snac_traj_layout(const void* ptr) {
+    std::lock_guard<std::mutex> lk(g_traj_mu);
+    auto it = g_traj.find(const_cast<void*>(ptr));
+    return it == g_traj.end() ? fail(SNAC_ERR_ARG, "not a block of snac_traj_alloc") : it->second.layout;
+}
+
+int snac_traj_free(void* ptr) {
+    if (!ptr) return SNAC_OK;
+    int dev = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_traj_mu);
+        auto it = g_traj.find(ptr);
+        if (it == g_traj.end()) return fail(SNAC_ERR_ARG, "not a block of snac_traj_alloc");
+        dev = it->second.device;
+    }
+    int cur = -1;                                                // nothing may still be writing into the block: its device goes idle
+    (void)hipGetDevice(&cur);
+    if (cur != dev) (void)hipSetDevice(dev);
+    (void)hipDeviceSynchronize();
+    if (cur >= 0 && cur != dev) (void)hipSetDevice(cur);
+    return traj_unregister_and_release(ptr);
 }
 
 }  // extern "C"

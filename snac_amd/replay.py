@@ -22,13 +22,14 @@ def _ptr(t):
 
 
 class ReplayRing:
-    def __init__(self, env, capacity_ticks, layout="ticks", place_candidates=0, memory="auto"):
+    def __init__(self, env, capacity_ticks, layout="ticks", place_candidates=0, memory="malloc"):
         """env: BatchedDMPEnv (already reset); capacity_ticks: ring length in vector steps (>= 2).
         layout "ticks": obs[cap, N, D]; "tiled": obs[ceil(N / 64), cap, 64, D] -- a tile of 64 envs streams through its own
         contiguous region of the ring (SNAC_OBS_TILED: the faster layout to collect into); row(slot, env) and
         obs_at(slot) read either.  memory: where the observation ring lives -- "vmm": a snac_traj_alloc block (one virtual range
-        over chunks from two 32 GiB slices of physical memory: MI355X writes it 15-20 % faster), "malloc":
-        torch.empty, "auto" (default): "vmm" from 1 GiB up.  place_candidates > 1: the ring is placed by env.alloc_trajectory (that many
+        over chunks from two 32 GiB slices of physical memory: MI355X writes it 15-20 % faster; building it
+        holds up to half of the free device memory for about a second and freeing it waits for the device, so it is opt-in),
+        "malloc" (default): torch.empty, "auto": "vmm" from 1 GiB up.  place_candidates > 1: the ring is placed by env.alloc_trajectory (that many
         candidate blocks timed with the rollout itself, the fastest kept: where the driver puts a block's runs still matters)."""
         if capacity_ticks < 2:
             raise ValueError("capacity_ticks must be >= 2")

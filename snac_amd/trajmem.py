@@ -4,7 +4,7 @@ memory from different 32 GiB slices of the address space taking turns (HIP virtu
 On MI355X write streams confined to one slice reach ~5.7 TB/s, spread over two ~7.1 (tools/wr_blocks.hip, DESIGN.md section 3);
 torch.empty() hands out hipMalloc memory -- one physical run -- and PyTorch-ROCm's own virtual-memory mode (expandable segments) is
 not available on this platform.  traj_empty() returns an ordinary torch tensor viewing one block; the block is unmapped and released
-when the tensor's storage dies.  A block of 1 GiB or more takes 1.5-2.5 s to build.  PyTorch is plumbing here: it only learns the pointer.
+when the tensor's storage dies.  A block of 1 GiB or more takes 0.5-1.5 s to build (and is checked: written, read back).  PyTorch is plumbing here: it only learns the pointer.
 """
 import ctypes as C
 
@@ -17,10 +17,12 @@ class _Block:
     """Owner of one snac_traj_alloc block.  torch views it through __cuda_array_interface__ (and keeps this object alive for as
     long as any tensor shares the storage); DLPack is the second route if a build refuses the first."""
 
-    def __init__(self, nbytes, device_index):
+    def __init__(self, nbytes, device_index, pool_cap=0):
         L = _lib.lib()
         p = C.c_void_p()
-        _lib.check(L.snac_traj_alloc(int(nbytes), int(device_index), C.byref(p)))
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the probe and the block's check run on torch's current stream
+        stream = raw(int(device_index)) if raw is not None else torch.cuda.current_stream(int(device_index)).cuda_stream
+        _lib.check(L.snac_traj_alloc_ex(int(nbytes), int(device_index), int(pool_cap), C.c_void_p(stream), C.byref(p)))
         self.ptr, self.nbytes, self.device_index = p.value, int(nbytes), int(device_index)
         self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2,
                                          "strides": None}
@@ -100,9 +102,13 @@ def layout_of(t):
     return LAYOUTS.get(rc)
 
 
-def traj_empty(shape, dtype, device):
-    """torch.empty(shape, dtype=dtype, device=device) on snac_traj_alloc memory (uninitialised, contiguous).  Raises SnacError
-    when the block cannot be allocated and RuntimeError when this PyTorch build cannot view a foreign device pointer."""
+def traj_empty(shape, dtype, device, pool_cap=0):
+    """torch.empty(shape, dtype=dtype, device=device) on snac_traj_alloc memory (contiguous; it holds the pattern of the library's
+    own check, not zeros).  pool_cap: bytes of device memory the slice measurement may hold beyond the block while it runs
+    (0 = 64 GiB, never more than half of what is free; snac_traj_alloc_ex).  Raises SnacError when the block cannot be allocated
+    or fails its check, and RuntimeError when this PyTorch build cannot view a foreign device pointer.  The block is unmapped when
+    the last tensor viewing it dies -- snac_traj_free then waits for the whole device to go idle first, so that garbage collection
+    is where the wait happens."""
     device = torch.device(device)
     if device.type != "cuda":
         raise _lib.SnacError("trajectory memory lives on a ROCm GPU")
@@ -112,7 +118,7 @@ def traj_empty(shape, dtype, device):
         numel *= int(d)
     nbytes = max(1, numel * torch.empty((), dtype=dtype).element_size())
     with torch.cuda.device(index):
-        block = _Block(nbytes, index)
+        block = _Block(nbytes, index, pool_cap)
         try:
             flat = torch.as_tensor(block, device=torch.device("cuda", index))
             if flat.data_ptr() != block.ptr:                     # a copy instead of a view: not what was asked for

@@ -159,3 +159,26 @@ def test_alloc_trajectory_places_the_output_without_stepping_the_batch():
     ob, rb, db = b.rollout(50)
     assert oa.data_ptr() == out.data_ptr()
     assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+
+
+def test_snapshot_carries_the_plan_table_of_generated_plans():
+    """generate_plans() rewrites the device plan table, so a snapshot must carry it -- restored into a fresh batch
+    (which holds the dataset's table) the headers' plan rows would otherwise point into other plans."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    a = BatchedDMPEnv(2, True, 512, seed=11)
+    a.generate_plans(seed=5)
+    a.reset()
+    a.rollout(40, obs=None)
+    sd = a.state_dict()
+    b = BatchedDMPEnv(2, True, 512, seed=11)
+    b.load_state_dict(sd)
+    oa, ra, da = a.rollout(90)
+    ob, rb, db = b.rollout(90)
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    assert torch.equal(a.iou(), b.iou()) and a.episodic_stats() == b.episodic_stats()
+    assert torch.equal(a.input_plan(), b.input_plan())
+    small = BatchedDMPEnv(2, True, 512, plans=a.plans_full[:7], seed=11)
+    with pytest.raises(ValueError):
+        small.load_state_dict(sd)

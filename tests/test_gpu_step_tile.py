@@ -1,0 +1,123 @@
+"""GPU: the tile form of snac_step (k_step2d / k_step3d, round 3: wide loads of the records / window rows, lane-per-env window
+extraction, rows transposed through LDS, 16-byte-per-lane stores, episodic sums by atomics) against the CPU oracle, tick by tick.
+The kernels take 2D / 3D steps on the identity rows when N % 4 == 0: a lone ragged tile, whole tiles, blocks with idle waves and a
+ragged last tile; float64 (two staged halves) and float32; counter-RNG and explicit inputs; auto-reset on and off; no observation;
+short time limits so that every env resets many times (3D random agents also box themselves in every ~22 steps); agents driven to
+every edge of the plan area (the 3D window loads clamp their first column into the record)."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+KINDS = [(2, False), (2, True), (3, False), (3, True)]
+
+
+def _ids(v):
+    return "%dd_%s" % (v[0], "dyn" if v[1] else "sta") if isinstance(v, tuple) else str(v)
+
+
+def _pair(dim, dyn, n, seed, total_step=None, f32=False, base=0):
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(dim, dyn, "dense_train" if dyn else "p0")
+    env = BatchedDMPEnv(dim, dyn, n, plans=table.reshape(len(table), 26, 26), seed=seed, env_id_base=base, total_step=total_step,
+                        obs_dtype=torch.float32 if f32 else torch.float64)
+    orc = helpers.oracle().OracleBatch(dim, dyn, n, table, seed=seed, env_id_base=base)
+    if total_step:
+        orc.set_total_step(total_step)
+    o = orc.reset()
+    assert env.reset().cpu().numpy().tobytes() == (o.astype(np.float32) if f32 else o).tobytes()
+    return env, orc
+
+
+def _end_state(env, orc):
+    st = orc.state()
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(env.num_envs, -1), st["grid"].astype(np.float64))
+    for name, key in (("count_brick", "cb"), ("count_step", "cs"), ("plan_idx", "plan_idx"), ("episode", "episode"), ("episode_return", "ep_return"),
+                      ("total_brick", "tb")):
+        assert np.array_equal(getattr(env, name).cpu().numpy(), st[key]), name
+    assert np.array_equal(env.position.cpu().numpy(), st["pos"])
+    assert np.array_equal(env.need_reset.cpu().numpy().astype(np.uint8), st["need_reset"])
+    s, e = orc.stats(), env.episodic_stats()
+    assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
+    assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("kind", KINDS, ids=_ids)
+@pytest.mark.parametrize("n", [4, 36, 64, 256 + 64 + 12, 4096 + 40])
+def test_counter_rng_steps_with_auto_reset(kind, n, f32):
+    dim, dyn = kind
+    env, orc = _pair(dim, dyn, n, seed=6, total_step=25, f32=f32, base=123456789012)
+    for t in range(70):
+        og, rg, dg = env.step(auto_reset=True)
+        oc, rc, dc = orc.step(t, auto_reset=True, nthreads=8)
+        assert og.cpu().numpy().tobytes() == (oc.astype(np.float32) if f32 else oc).tobytes(), (t, "obs")
+        assert rg.cpu().numpy().tobytes() == rc.tobytes(), (t, "reward")
+        assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc), (t, "done")
+    _end_state(env, orc)
+    assert env.episodic_stats()["episodes"] >= 2 * n
+
+
+@pytest.mark.parametrize("kind", KINDS, ids=_ids)
+def test_explicit_inputs_walk_to_every_edge(kind):
+    """Each env repeats one direction for a while (so that agents reach and lean on all four borders and corners of the plan area),
+    then drops / builds for a while; no auto-reset: envs past `done` keep mutating like the reference."""
+    import torch
+
+    dim, dyn = kind
+    n, A = 512, helpers.DIMS[dim]["A"]
+    env, orc = _pair(dim, dyn, n, seed=8)
+    rng = np.random.default_rng(dim)
+    phase = rng.integers(0, A, size=(12, n))
+    for t in range(12 * 9):
+        a = phase[t // 9].astype(np.int8)
+        if t % 9 >= 6:                                            # the last third of a phase: random actions
+            a = rng.integers(0, A, size=n).astype(np.int8)
+        k = rng.integers(1, 4, size=n).astype(np.int8)
+        og, rg, dg = env.step(torch.from_numpy(a), torch.from_numpy(k))
+        oc, rc, dc = orc.step(t, a, k)
+        assert og.cpu().numpy().tobytes() == oc.tobytes(), (t, "obs")
+        assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
+    _end_state(env, orc)
+    pos = env.position.cpu().numpy()
+    assert pos.min() <= 4 and pos.max() >= 21
+
+
+@pytest.mark.parametrize("kind", KINDS, ids=_ids)
+def test_steps_without_observation_and_reused_outputs(kind):
+    """want_obs=False (no staging at all) interleaved with steps that write into preallocated outputs."""
+    import torch
+
+    dim, dyn = kind
+    n = 1024 + 8
+    env, orc = _pair(dim, dyn, n, seed=9, total_step=20)
+    out = (torch.empty((n, 51), dtype=torch.float64, device=env.device), torch.empty(n, dtype=torch.float32, device=env.device),
+           torch.empty(n, dtype=torch.uint8, device=env.device))
+    for t in range(60):
+        blind = t % 3 == 1
+        og, rg, dg = env.step(auto_reset=True, want_obs=not blind, out=out)
+        oc, rc, dc = orc.step(t, auto_reset=True, nthreads=8)
+        assert (og is None) if blind else og.cpu().numpy().tobytes() == oc.tobytes()
+        assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+    _end_state(env, orc)
+
+
+@pytest.mark.parametrize("kind", [(2, True), (3, True)], ids=_ids)
+def test_large_batch_equals_the_rollout(kind):
+    """N = 65 536 + 36: 80 per-tick steps (the tile step kernels) write the rows one fused rollout of a forked batch writes."""
+    import torch
+
+    dim, dyn = kind
+    n, T = 65536 + 36, 80
+    env, _ = _pair(dim, dyn, n, seed=10, total_step=30)
+    twin = env.fork(torch.arange(n, device=env.device))
+    ot, rt, dt = twin.rollout(T)
+    for t in range(T):
+        og, rg, dg = env.step(auto_reset=True)
+        assert torch.equal(og, ot[t]) and torch.equal(rg, rt[t]) and torch.equal(dg, dt[t]), t
+    assert torch.equal(env._hdr, twin._hdr) and torch.equal(env._grid, twin._grid) and torch.equal(env._stats, twin._stats)
+    assert torch.equal(env._episode, twin._episode)

@@ -149,3 +149,45 @@ def test_fixed_three_run_layout_when_the_measurement_is_switched_off(monkeypatch
     oa, _, _ = a.rollout(60, out=out)
     ob, _, _ = b.rollout(60)
     assert torch.equal(oa, ob)
+
+
+def test_thirty_two_large_blocks_allocated_checked_and_freed_in_turn():
+    """Round 3: every block passes the library's own check (a pattern written by one kernel, read back by another and, one word per
+    chunk, by a copy) before it is handed out; here 32 blocks of 1.0-1.3 GiB are built one after the other on a side stream, filled
+    by torch, read back through a copy and through a kernel, and freed.  Every one has the measured layout or is an explicit
+    fallback, none fails, and building one takes about a second at most (the pool grows only as far as it has to)."""
+    import time
+
+    import torch
+    from snac_amd import trajmem
+
+    side = torch.cuda.Stream()
+    layouts, secs = [], []
+    with torch.cuda.stream(side):
+        for i in range(32):
+            n = (1 << 27) + (i % 5) * (1 << 23)                  # int64 words: 1.0 .. 1.25 GiB
+            t0 = time.perf_counter()
+            t = trajmem.traj_empty((n,), torch.int64, "cuda", pool_cap=16 << 30)
+            secs.append(time.perf_counter() - t0)
+            layouts.append(trajmem.layout_of(t))
+            t.copy_(torch.arange(n, dtype=torch.int64, device="cuda") + i)
+            assert int(t[::65537].sum().item()) == sum(range(i, n + i, 65537)), i
+            host = t[n - 4096:].cpu()
+            assert int(host[0]) == n - 4096 + i and int(host[-1]) == n - 1 + i, i
+            del t, host
+    side.synchronize()
+    assert all(x in ("measured: two slices in turn", "three runs 32 GiB apart") for x in layouts), layouts
+    assert layouts.count("measured: two slices in turn") >= 24, layouts
+    assert sorted(secs)[len(secs) // 2] < 1.5, secs
+
+
+def test_pool_cap_bounds_what_the_measurement_holds():
+    """pool_cap: with 1 GiB of room beyond the block there is nothing worth probing -- the block takes the fixed layout at once and the
+    free-memory figure never dips by more than the block and its gaps."""
+    import torch
+    from snac_amd import trajmem
+
+    blk = trajmem.traj_empty(((1 << 30) + (64 << 20),), torch.uint8, "cuda", pool_cap=1 << 30)
+    assert trajmem.layout_of(blk) == "three runs 32 GiB apart"
+    blk.fill_(7)
+    assert int(blk[-1].item()) == 7 and int(blk[::1 << 20].sum().item()) == 7 * ((blk.numel() + (1 << 20) - 1) >> 20)
