@@ -161,6 +161,17 @@ def _python_loop_rate(kind, dynamic, seed, n=1024, budget=5.0):
     return n * ticks / (time.perf_counter() - t0), ticks
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(kind, dynamic, n, T, seed):
     """The C oracle (oracle/snac_oracle.c) on the same workload, timed on the host: envs x T steps in chunks, float64
     observations of every step written to a reused buffer.  `value` = the best OpenMP thread count (i); also the single
@@ -182,10 +193,14 @@ def cpu_baseline(kind, dynamic, n, T, seed):
         if best is None or rate > best["value"]:
             best = rec
     best["single_thread"] = single
+    best["cpu_model"] = _cpu_model()
+    best["cores_available"] = avail
     rate, ticks = _python_loop_rate(kind, dynamic, seed)
     best["python_loop_n1024"] = dict(
         value=rate, unit="env-steps/s", cores=1,
-        sample="python for-loop over 1024 env objects per vector step (shape of multiprocess.py:24-32), %d vector steps" % ticks)
+        sample="python for-loop over 1024 env objects per vector step (shape of multiprocess.py:24-32), %d vector steps; the env objects "
+               "are the C oracle behind ctypes, so this is an UPPER bound for that loop shape -- the reference's own pure-Python "
+               "classes do 1.1-1.2e5 env-steps/s in it (BASELINE.md section 2)" % ticks)
     return best
 
 
@@ -291,7 +306,8 @@ def main():
     # ~5.7 TB/s, spread over several at ~7.1 -- and a hipMalloc tensor is one physical run.  snac_traj_alloc (snac_amd/trajmem.py) backs
     # ONE virtual range with three runs a slice apart: SNAC_BENCH_MEMORY=vmm (default) | malloc; if such a block cannot be had the run
     # falls back to torch.empty and says so in `placement`.
-    place_n = int(os.environ.get("SNAC_BENCH_PLACE", "3"))
+    # N > 1 ranks: one block per rank (every candidate is an allocation + a probe per rank, inside the driver's time limit)
+    place_n = int(os.environ.get("SNAC_BENCH_PLACE", "3" if world == 1 else "1"))
     memory = os.environ.get("SNAC_BENCH_MEMORY", "vmm")
     traj_alloc = None
     if memory == "vmm":
@@ -410,6 +426,16 @@ def main():
     per_rank[rank] = kern_ms
     per_rank = allreduce_(per_rank).tolist()
     ranks_seen = int(allreduce_(torch.ones(1, dtype=torch.int64, device=dev)).item())
+    # which physical GPU each rank ran on: PCI domain:bus:device packed into one int64 per rank, summed into place
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        packed = (int(getattr(pr, "pci_domain_id", 0)) << 16) | (int(getattr(pr, "pci_bus_id", 0)) << 8) | int(getattr(pr, "pci_device_id", 0))
+    except Exception:
+        packed = -1
+    ids = torch.zeros(world, dtype=torch.int64, device=dev)
+    ids[rank] = packed
+    ranks_devices = ["cuda:%d pci %04x:%02x:%02x" % (i % max(ndev, 1) if backend != "nccl" else i, v >> 16, (v >> 8) & 0xff, v & 0xff) if v >= 0 else None
+                     for i, v in enumerate(allreduce_(ids).tolist())]
 
     # integrity of what the timed passes wrote (after the clock stopped): the last step's rows in the trajectory tensor must be the
     # batch's current observation, read through a different kernel into ordinary memory
@@ -442,8 +468,85 @@ def main():
         return {"layout": "[N/64][T][64][obs_dim] (rollout(obs='tiled'))", "kernel_ms": tms, "value": n * T / (tms * 1e-3), "unit": "env-steps/s per GPU",
                  "written": WRITTEN_BYTES[(args.kind, "f32" if args.obs_f32 else "f64")] * n * T / (tms * 1e-3) / 1e9, "placement": trep}
 
+    # ---- the other BASELINE configs, the float32 rows and the per-tick step(), driver-timed: after the headline clock has stopped,
+    # rank 0 of a one-GPU run only, into the headline's own trajectory block (no further allocation); kernel time from events on the
+    # launch stream, averaged over back-to-back launches.  `frac` prices the bytes the launch must move -- rows + reward + done
+    # written, the state once in and once out (rollouts); SURVEY.md 8d's per-step figure (step(): the state does cross HBM every
+    # tick there) -- against the 8 TB/s peak.
+    def extra_configs():
+        flat = obs.reshape(-1).view(torch.uint8)
+
+        def view(shape, dt):
+            nb = 1
+            for d in shape:
+                nb *= int(d)
+            nb *= 4 if dt == torch.float32 else 8
+            if nb > flat.numel():
+                return None
+            return flat[:nb].view(dt).view(shape)
+
+        def timed(fn, reps):
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(max(3, reps // 4)):
+                fn()
+            a_.record()
+            for _ in range(reps):
+                fn()
+            b_.record()
+            torch.cuda.synchronize()
+            return a_.elapsed_time(b_) / reps
+
+        res = {}
+
+        def rollout_cfg(name, kind, dyn, nn, f32, reps, note=None):
+            dt = torch.float32 if f32 else torch.float64
+            e = BatchedDMPEnv(kind, dyn, nn, device=dev, seed=1, obs_dtype=dt)
+            e.reset()
+            TT = e.total_step
+            buf = view((TT, nn, e.obs_dim), dt)
+            if buf is None:
+                return
+            rw = torch.empty((TT, nn), dtype=torch.float32, device=dev)
+            dn = torch.empty((TT, nn), dtype=torch.uint8, device=dev)
+            ms = timed(lambda: e.rollout(TT, obs="all", out=buf, reward_out=rw, done_out=dn), reps)
+            key = (kind, "f32" if f32 else "f64")
+            algb = WRITTEN_BYTES[key] + 2.0 * STATE_BYTES[kind] / TT
+            gbs = algb * nn * TT / (ms * 1e-3) / 1e9
+            res[name] = {"kernel_ms": ms, "env_steps_per_s": nn * TT / (ms * 1e-3), "written_GBs": WRITTEN_BYTES[key] * nn * TT / (ms * 1e-3) / 1e9,
+                         "alg_bytes_per_env_step": algb, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": reps}
+            if note:
+                res[name]["note"] = note
+
+        def step_cfg(name, kind, nn, reps):
+            e = BatchedDMPEnv(kind, True, nn, device=dev, seed=1)
+            e.reset()
+            out = (view((nn, e.obs_dim), torch.float64), torch.empty(nn, dtype=torch.float32, device=dev), torch.empty(nn, dtype=torch.uint8, device=dev))
+            ms = timed(lambda: e.step(auto_reset=True, out=out), reps)
+            algb = CONTRACT_BYTES[(kind, "f64")]
+            gbs = algb * nn / (ms * 1e-3) / 1e9
+            res[name] = {"us_per_tick": ms * 1e3, "env_steps_per_s": nn / (ms * 1e-3), "alg_bytes_per_env_step": algb, "achieved_GBs": gbs,
+                         "frac": gbs / HBM_PEAK_GBS, "launches": reps,
+                         "note": "device time per tick, launches enqueued back to back" + ("" if nn >= 262144 else "; at this batch size the host's enqueue rate is part of it")}
+
+        rollout_cfg("c2_1d_static_n4096_T750", 1, False, 4096, False, 40,
+                    "latency-bound by construction: 512 waves walk 750 dependent ticks; the pass writes 187 MB")
+        rollout_cfg("c5_3d_dynamic_n16384_T1000", 3, True, 16384, False, 24)
+        rollout_cfg("headline_f32_obs", 2, True, 65536, True, 24)
+        for kind in (2, 3):
+            for nn in (65536, 524288):
+                step_cfg("step_%dd_dynamic_n%d" % (kind, nn), kind, nn, 200)
+        return res
+
+    extras = None
+    if world == 1 and rank == 0 and os.environ.get("SNAC_BENCH_EXTRAS", "1") != "0" and (args.kind, dynamic, n, args.obs_f32) == (2, True, 65536, False) and T == 600:
+        try:
+            extras = extra_configs()
+        except Exception as e:                                   # informational only: never take the headline line down with it
+            sys.stderr.write("bench.py: extra configurations failed (%r)\n" % (e,))
+            extras = {"error": repr(e)}
+
     try:
-        tiled = tiled_extra() if (args.kind == 2 and n % 64 == 0 and not args.static and os.environ.get("SNAC_BENCH_TILED", "1") != "0") else None
+        tiled = tiled_extra() if (world == 1 and args.kind == 2 and n % 64 == 0 and not args.static and os.environ.get("SNAC_BENCH_TILED", "1") != "0") else None
     except Exception as e:                                       # informational only: never take the headline line down with it
         sys.stderr.write("bench.py: tile-major extra measurement failed (%r)\n" % (e,))
         tiled = {"error": repr(e)}
@@ -460,17 +563,27 @@ def main():
         s = stats.tolist()
         # measured HBM bytes per launch (rocprofv3 PMC passes of this same command, tools/profile.sh ->
         # profiles/traffic.json), turned into GB/s with the live launch duration; null for other workloads
-        traffic = None
+        traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         headline = (args.kind, dynamic, n, T, dkey) == (2, True, 65536, 600, "f64")
         if os.path.exists(tfile) and headline:
+            import hashlib
+
             with open(tfile) as fh:
-                traffic = json.load(fh)["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
+                tj = json.load(fh)
+            with open(os.path.join(ROOT, "snac_amd", "csrc", "snac_hip.hip"), "rb") as fh:
+                now = hashlib.sha256(fh.read()).hexdigest()[:16]
+            if tj.get("source_sha16") == now:                    # the counters were taken with THIS kernel source
+                traffic = tj["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
+                traffic_source = "profiles/traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, snac_hip.hip sha256 %s), bytes per launch / the live kernel time" % now
+            else:
+                traffic_source = "none: profiles/traffic.json belongs to kernel source %s, this library was built from %s" % (tj.get("source_sha16"), now)
         written = WRITTEN_BYTES[(args.kind, dkey)] * n * T / (kern_ms * 1e-3) / 1e9
         what = "%dD %s dense" % (args.kind, "dynamic" if dynamic else "static")
         # the kernel this workload dispatches to (snac_hip.hip::launch): the 2D tile kernel, the pipelined 3D rollout, the
         # chain-shaped 1D rollout up to 16 384 envs
-        kernel_name = "k_rollout3d" if args.kind == 3 else ("k_rollout1d" if args.kind == 1 and n <= 16384 else "k_rollout")
+        kernel_name = "k_rollout3d" if args.kind == 3 else ("k_rollout1d" if args.kind == 1 and n <= 16384 else
+                                                            ("k_rollout2d" if args.kind == 2 and n >= 65536 and n % 4 == 0 else "k_rollout"))
         out = {
             "metric": HEADLINE if headline else "env-steps/sec at N=%d envs (%s, %s obs); bit-exact vs CPU" % (n, what, dkey),
             "value": total_steps / dt,
@@ -489,7 +602,7 @@ def main():
                        "envs_per_gpu": n, "vector_steps_per_pass": T, "env_steps_per_pass": n * T * world,
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "frac_traffic": (traffic / HBM_PEAK_GBS) if traffic else None,
                          "peak_measured_write": wpeak,            # hipMemsetAsync, the faster of the two kinds of memory:
                          "peak_measured_write_by_memory": {"malloc": wpeak_malloc, "vmm": wpeak_vmm},
@@ -504,11 +617,13 @@ def main():
             "rccl_ranks": ranks_seen if (world > 1 and backend == "nccl") else None,
             "ranks": ranks_seen,
             "kernel_ms_per_rank": per_rank,
+            "ranks_devices": ranks_devices,                       # every rank's cuda:<local> PCI bus id: N ranks on N distinct GPUs
             "kernel_ms_per_step": [round(x, 4) for x in per_step_ms],   # rank 0's launches, in order
             "preroll_passes": preroll_passes,                     # untimed, before the W warm-up passes (clock ramp)
             "trajectory_check": traj_ok,                          # obs[T - 1] == observe() after the timed passes
             "placement": placement_report,                        # rank 0's choice among SNAC_BENCH_PLACE candidate tensors
             "tiled_layout": tiled,                                # rank 0, informational: the build's own trajectory layout
+            "extra": {"configs": extras},                         # rank 0, one GPU: the other configs / dtypes / step(), driver-timed
             "episodic": {"episodes": s[0], "mean_return": (s[1] / s[0]) if s[0] else None,
                          "mean_iou": (s[2] / 2.0 ** 40 / s[0]) if s[0] else None},
         }

@@ -21,6 +21,11 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+# the per-tick fast path of step(): torch's raw accessors (no Stream / device objects are built)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_current_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
+
 class BatchedDMPEnv:
     """N envs of one kind.
 
@@ -116,6 +121,10 @@ class BatchedDMPEnv:
                                  self._stats[1].data_ptr(), self._stats[2].data_ptr())
         self.t = 0  # tick: number of vector steps taken (keys the counter RNG)
         self._was_reset = False
+        self._fast = None                                            # step(): the argument set validated by the previous call
+        self._dev_index = self.device.index
+        self._desc_ref, self._state_ref = C.byref(self._desc), C.byref(self._state)
+        self._snac_step = self._lib.snac_step
         self._host_ok = None                                         # the new_host_obs() row validated last
         self._mapped = {}                                            # page-locked host tensors seen by _is_mapped
 
@@ -206,10 +215,24 @@ class BatchedDMPEnv:
     def step(self, actions=None, step_size=None, auto_reset=False, want_obs=True, out=None):
         """One vector step.  actions int[N] (None: counter RNG), step_size int[N] in {1,2,3} (None: counter RNG).
         out: optional preallocated (obs [N, obs_dim] obs_dtype, reward [N] float32, done [N] uint8) reused every tick -- a
-        training loop that steps small batches is bound by host time, and three allocations are a third of it.
+        training loop that steps small batches is bound by host time, and three allocations are a third of it.  A call that
+        passes the SAME tensor objects as the call before (out, actions, step_size -- the per-tick loop of a trainer) skips the
+        argument checks: the validated pointers are kept and only compared with the tensors' current data_ptr().
         Inputs and outputs may also be page-locked HOST tensors (torch.empty(..., pin_memory=True); new_host_obs()): the kernel
         reads / writes them over the bus and the caller only waits (sync()) -- what VectorizedEnvWrapper does.
         Returns (obs [N, obs_dim], reward float32 [N], done bool [N])."""
+        f = self._fast
+        if f is not None and out is not None and f[0] is out and f[1] is actions and f[2] is step_size and f[3] == want_obs \
+                and _current_device() == self._dev_index:
+            o, r, d = out
+            if (o.data_ptr() if want_obs else 0) == f[4] and r.data_ptr() == f[5] and d.data_ptr() == f[6] \
+                    and (actions is None or actions.data_ptr() == f[7]) and (step_size is None or step_size.data_ptr() == f[8]):
+                rc = self._snac_step(self._desc_ref, self._state_ref, self.t & 0xFFFFFFFF, f[7], f[8], 1 if auto_reset else 0,
+                                     f[4] or None, f[5], f[6], _raw_stream(self._dev_index))
+                if rc:
+                    _lib.check(rc)
+                self.t += 1
+                return f[9]
         if not self._was_reset:
             raise _lib.SnacError("step() before reset()")
         N = self.num_envs
@@ -231,7 +254,15 @@ class BatchedDMPEnv:
             with torch.cuda.device(self.device):
                 _lib.check(self._lib.snac_step(*args, self._stream()))
         self.t += 1
-        return obs, reward, done.view(torch.bool)
+        ret = (obs, reward, done.view(torch.bool))
+        # remember a call whose tensors were all taken as they are (nothing converted or copied): the next call with the same
+        # objects goes straight to the launch
+        if out is not None and a is actions and k is step_size and _raw_stream is not None:
+            self._fast = (out, actions, step_size, bool(want_obs), obs.data_ptr() if obs is not None else 0, reward.data_ptr(), done.data_ptr(),
+                          a.data_ptr() if a is not None else None, k.data_ptr() if k is not None else None, ret)
+        else:
+            self._fast = None
+        return ret
 
     def step_scalar(self, action, step_size, auto_reset=False, out=None):
         """step() with ONE action and ONE step size for every env, passed by value (snac_step_scalar): no host-to-device copy

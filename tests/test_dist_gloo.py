@@ -43,7 +43,7 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_stats_reduce_to_the_unsharded_result(world, tmp_path):
     import torch.multiprocessing as mp
 

@@ -52,6 +52,9 @@ def test_bench_line_and_two_rank_path():
     assert two["ranks"] == 2 and len(two["kernel_ms_per_rank"]) == 2 and min(two["kernel_ms_per_rank"]) > 0
     cb = one["cpu_baseline"]
     assert cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0 and cb["python_loop_n1024"]["value"] > 0
+    assert cb["cpu_model"] and "upper bound" in cb["python_loop_n1024"]["sample"].lower()
+    assert one["extra"]["configs"] is None                            # the extras belong to the headline shape (N = 65 536, T = 600)
+    assert one["ranks_devices"] and one["ranks_devices"][0].startswith("cuda:0 pci ")
     assert r["peak_measured_write"] is None or 1000 < r["peak_measured_write"] < 8000
 
 
@@ -69,6 +72,21 @@ def test_gpus_flag_starts_the_ranks_itself():
     one = _run(cmd + ["--envs", "8192"])
     assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["backend"] == "gloo"
     assert two["episodic"] == one["episodic"]
+    assert len(two["ranks_devices"]) == 2 and all(d and d.startswith("cuda:") for d in two["ranks_devices"])
+    assert two["extra"]["configs"] is None and two["tiled_layout"] is None          # N > 1: the headline only
+    # four ranks (the GPU box admits six processes on its card: this test process, its launcher -- which never touches the GPU --
+    # and four ranks; BASELINE config 4's eight ranks on one card would trip that guard, the 8-way split itself runs on CPU in
+    # tests/test_dist_gloo.py): 4 x 2048 envs == 1 x 8192, inside a wall-time bound that a per-rank start-up of seconds would break
+    import time
+
+    t0 = time.perf_counter()
+    out = subprocess.run(cmd + ["--gpus", "4", "--envs", "2048"], cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    assert out.returncode == 0, out.stderr[-2000:]
+    four = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert four["n_gpus"] == 4 and four["ranks"] == 4 and len(four["kernel_ms_per_rank"]) == 4 and len(four["ranks_devices"]) == 4
+    assert four["episodic"] == one["episodic"] and four["config"]["env_steps_per_pass"] == 4 * 2048 * 120
+    assert wall < 240, wall
     # RCCL needs one GPU per rank: two RCCL ranks on a one-GPU box must fail loudly, not report a 1-GPU number
     if __import__("torch").cuda.device_count() == 1:
         env["SNAC_BENCH_BACKEND"] = "nccl"

@@ -179,3 +179,39 @@ def test_four_million_envs_in_one_launch_equal_their_shards(kind):
     before = big._hdr[N - 4096:].clone()
     o1, _, _ = big.transition(acts, None, src, src)
     assert o1.shape == (4096, 51) and not torch.equal(big._hdr[N - 4096:], before)
+
+
+def _one_launch(dim, dyn, n, T, slab, tag):
+    """ONE rollout launch of T ticks into a trajectory block, compared with the oracle on the device in slabs of `slab` ticks."""
+    import torch
+    from snac_amd import trajmem
+
+    env, orc = _pair(dim, dyn, n, tag)
+    nt = _threads()
+    assert env.reset().cpu().numpy().tobytes() == orc.reset().tobytes()
+    buf = trajmem.traj_empty((T, n, env.obs_dim), torch.float64, env.device)
+    og, rg, dg = env.rollout(T, out=buf)                          # the launch bench.py times
+    assert og.data_ptr() == buf.data_ptr()
+    t = 0
+    while t < T:
+        c = min(slab, T - t)
+        oc, rc, dc = orc.rollout(c, t0=t, nthreads=nt)
+        assert torch.equal(og[t:t + c], torch.from_numpy(oc).to(env.device)), ("obs", t)
+        assert torch.equal(rg[t:t + c], torch.from_numpy(rc).to(env.device)), ("reward", t)
+        assert torch.equal(dg[t:t + c].view(torch.uint8), torch.from_numpy(dc).to(env.device)), ("done", t)
+        t += c
+    s, e = orc.stats(), env.episodic_stats()
+    assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
+    assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+    assert env.observe().cpu().numpy().tobytes() == og[T - 1].cpu().numpy().tobytes()
+
+
+def test_config3_headline_pass_as_one_launch():
+    """The exact launch of the headline measurement: rollout(600) of 65 536 2D dynamic dense envs, one launch, 16 GB of rows in a
+    trajectory block -- all 39 321 600 rows, rewards and done flags equal the oracle's."""
+    _one_launch(2, True, 65536, 600, 40, "dense_train")
+
+
+def test_config5_3d_pass_as_one_launch():
+    """BASELINE configs[4] as one launch of the pipelined 3D kernel: rollout(1000) of 16 384 envs."""
+    _one_launch(3, True, 16384, 1000, 125, "dense_train")

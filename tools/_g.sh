@@ -1,18 +1,16 @@
 mkdir -p gpurun_out
-timeout -k 10 120 tools/vmm_stale 300 64 > gpurun_out/r03_vmm_stale.txt 2>&1; echo "rc=$?" >> gpurun_out/r03_vmm_stale.txt
+timeout -k 10 120 tools/vmm_stale 200 64 > gpurun_out/r03_vmm_stale.txt 2>&1; echo "rc=$?" >> gpurun_out/r03_vmm_stale.txt
 cat gpurun_out/r03_vmm_stale.txt
-SNAC_TRAJ_DEBUG=1 timeout -k 10 300 python -m pytest tests/test_gpu_trajmem.py -x -q > gpurun_out/r3_t4.log 2>&1; echo "rc=$?" >> gpurun_out/r3_t4.log
-grep -v "probe round" gpurun_out/r3_t4.log | tail -15
-timeout -k 10 120 python - > gpurun_out/r3_traj16.txt 2>&1 <<'PY'
-import time, torch, os
-os.environ["SNAC_TRAJ_DEBUG"]="1"
-from snac_amd import trajmem
-for i in range(4):
-    t0=time.perf_counter()
-    t=trajmem.traj_empty((600,65536,51), torch.float64, "cuda")
-    print("16 GB block %d: %.2f s, layout %s, free %.1f GB" % (i, time.perf_counter()-t0, trajmem.layout_of(t), torch.cuda.mem_get_info()[0]/1e9), flush=True)
-    del t
+timeout -k 10 1000 python -m pytest tests/test_hindsight_2d_dynamic.py tests/test_gpu_fullsize.py tests/test_gpu_robust.py tests/test_gpu_bench.py tests/test_gpu_parity.py tests/test_gpu_facade.py tests/test_gpu_property.py -m gpu -x -q > gpurun_out/r3_t5.log 2>&1; echo "rc=$?" >> gpurun_out/r3_t5.log
+tail -12 gpurun_out/r3_t5.log
+timeout -k 10 120 python tools/step_overhead.py > gpurun_out/r03_step_overhead.txt 2>&1
+cat gpurun_out/r03_step_overhead.txt | grep -v amdgpu
+timeout -k 10 600 python bench.py > gpurun_out/r3_bench1.json 2> gpurun_out/r3_bench1.err; echo "bench rc=$?"
+tail -3 gpurun_out/r3_bench1.err
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r3_bench1.json").read().strip().splitlines()[-1])
+print("value %.4e ms_per_step %.4f kernel_ms %.4f frac %.4f traffic_source %s" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["roofline"]["traffic_source"]))
+print(json.dumps(d["extra"], indent=1)[:3000])
+print(d["cpu_baseline"]["cpu_model"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["value"], d["ranks_devices"], d["placement"])
 PY
-grep -v "probe round" gpurun_out/r3_traj16.txt | tail
-timeout -k 10 900 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_trajmem.py > gpurun_out/r3_full.log 2>&1; echo "rc=$?" >> gpurun_out/r3_full.log
-tail -8 gpurun_out/r3_full.log

@@ -8,6 +8,7 @@
 # SNAC_BENCH_TILED=0: bench.py's extra passes into the tile-major layout use the same kernel symbol and would mix their (shorter)
 # launches into the per-kernel average; the profiled launches are the headline's own (candidates, pre-roll, warm-up, timed).
 export SNAC_BENCH_TILED=0
+export SNAC_BENCH_EXTRAS=0   # the secondary configurations of the bench line are measured un-profiled; here only the headline's launches count
 TAG=${1:-r1}
 shift
 ARGS="$@"

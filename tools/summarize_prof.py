@@ -68,9 +68,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             for row in csv.DictReader(fh):
                 if row["Counter_Name"] != c:
                     continue
-                for fam in ("k_rollout", "k_transition"):
+                for fam in ("k_rollout", "k_transition", "k_step"):
                     if fam in row["Kernel_Name"]:
-                        dim = "K3D" if "K3D" in row["Kernel_Name"] or "rollout3d" in row["Kernel_Name"] else ("K2D" if "K2D" in row["Kernel_Name"] else "K1D")
+                        nm = row["Kernel_Name"]
+                        dim = "K3D" if ("K3D" in nm or "rollout3d" in nm or "step3d" in nm or "transition3d" in nm) else (
+                            "K2D" if ("K2D" in nm or "rollout2d" in nm or "step2d" in nm or "transition2d" in nm) else "K1D")
                         per[fam + ":" + dim].append(float(row["Counter_Value"]))
         for fam, v in per.items():
             vals[fam][c] = sum(v) / len(v)
@@ -80,6 +82,10 @@ for fam, v in sorted(vals.items()):
                  hbm_bytes_per_launch=(2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0,
                  note="2*FETCH_SIZE + WRITE_SIZE (KiB) per launch; separate --pmc passes; gfx950 read correction x2")
         if fam.startswith("k_rollout"):
+            # which kernel source the counters belong to: bench.py drops `roofline.traffic` when the library has changed since
+            import hashlib
+            src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "snac_amd", "csrc", "snac_hip.hip")
+            t["source_sha16"] = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
             with open(os.path.join(out, "traffic.json"), "w") as fh:
                 json.dump(t, fh, indent=1)
         print("== traffic:", t)

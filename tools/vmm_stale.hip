@@ -5,6 +5,7 @@
 //   A  reserve -> create -> map -> fill -> check -> unmap -> release -> hipMemAddressFree; the next reserve asks for the SAME address
 //   B  one range reserved once; every round maps FRESH handles there (unmap + release in between, no synchronisation beyond the copy)
 //   C  as A, but with hipDeviceSynchronize before the unmap and other allocations (hipMalloc / hipFree) in between
+//   D  as A, with the hipDeviceSynchronize only          E  as A, with the hipMalloc / hipFree only
 // Prints one line per mode: rounds, rounds whose address was recycled, mismatching rounds (copy / kernel).
 //   hipcc --offload-arch=gfx950 -O2 -o tools/vmm_stale tools/vmm_stale.hip && tools/vmm_stale [iters] [MB]
 #include <hip/hip_runtime.h>
@@ -37,7 +38,7 @@ int main(int argc, char** argv) {
     unsigned long long* bad = nullptr;
     CK(hipMalloc((void**)&bad, 8));
     std::vector<uint64_t> host(words);
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
         char* fixed = nullptr;
         if (mode == 1) CK(hipMemAddressReserve((void**)&fixed, bytes, chunk, nullptr, 0));
         char* last = nullptr;
@@ -60,8 +61,8 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
             if (mism) { if (!bad_copy) std::printf("mode %c round %d: %zu of %zu words differ through the copy (first word %llx, wanted %llx)\n", 'A' + mode, it, mism, words, (unsigned long long)host[0], (unsigned long long)v); ++bad_copy; }
             if (hb) ++bad_kernel;
-            if (mode == 2) {
-                CK(hipDeviceSynchronize());
+            if (mode == 2 || mode == 3) CK(hipDeviceSynchronize());
+            if (mode == 2 || mode == 4) {
                 void* spare = nullptr;
                 CK(hipMalloc(&spare, (size_t)(3 + it % 5) << 20));
                 CK(hipFree(spare));
