@@ -442,6 +442,26 @@ def main():
     traj_ok = bool(torch.equal(obs[T - 1], env.observe()))
     if not traj_ok:
         sys.stderr.write("bench.py: the trajectory tensor's last step differs from observe() -- the measurement is INVALID\n")
+    # ... and every row of one more pass against a SECOND kernel: a twin of the batch rolls out through the tile kernel k_rollout
+    # (an output that is not 16-byte aligned cannot take k_rollout2d's 16-byte stores, snac_hip.hip roll2d_ok) into ordinary memory;
+    # all T x N rows, rewards and done flags of the two passes must be equal.  After the clock has stopped; one GPU, rank 0.
+    full_check = None
+    if world == 1 and os.environ.get("SNAC_BENCH_FULLCHECK", "1") != "0":
+        try:
+            twin = env.fork(torch.arange(n, device=dev))
+            raw = torch.empty(T * n * env.obs_dim + 1, dtype=env.obs_dtype, device=dev)
+            o1, r1, d1 = env.rollout(T, obs="all", out=obs)
+            o2, r2, d2 = twin.rollout(T, obs="all", out=raw[1:].view(T, n, env.obs_dim))
+            full_check = bool(o2.data_ptr() % 16 != 0 and torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+                              and torch.equal(env._hdr, twin._hdr) and torch.equal(env._grid, twin._grid))
+            del twin, raw, o2, r2, d2, o1, r1, d1
+            torch.cuda.empty_cache()
+            if not full_check:
+                traj_ok = False
+                sys.stderr.write("bench.py: a full pass differs between the two rollout kernels -- the measurement is INVALID\n")
+        except Exception as e:
+            sys.stderr.write("bench.py: full-pass check could not run (%r)\n" % (e,))
+            full_check = "not run: %r" % (e,)
 
     # the same workload into the tile-major trajectory layout (obs="tiled": [N / 64][T][64][D], SNAC_OBS_TILED) -- reported
     # beside the headline, never as `value`: 2D only, after the clock stopped; its tensor is placed like the headline's (the
@@ -620,7 +640,8 @@ def main():
             "ranks_devices": ranks_devices,                       # every rank's cuda:<local> PCI bus id: N ranks on N distinct GPUs
             "kernel_ms_per_step": [round(x, 4) for x in per_step_ms],   # rank 0's launches, in order
             "preroll_passes": preroll_passes,                     # untimed, before the W warm-up passes (clock ramp)
-            "trajectory_check": traj_ok,                          # obs[T - 1] == observe() after the timed passes
+            "trajectory_check": traj_ok,                          # obs[T - 1] == observe() after the timed passes, and:
+            "trajectory_full_pass_check": full_check,             # one more pass == the same pass by the tile kernel, all T x N rows
             "placement": placement_report,                        # rank 0's choice among SNAC_BENCH_PLACE candidate tensors
             "tiled_layout": tiled,                                # rank 0, informational: the build's own trajectory layout
             "extra": {"configs": extras},                         # rank 0, one GPU: the other configs / dtypes / step(), driver-timed
