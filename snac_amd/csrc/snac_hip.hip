@@ -953,9 +953,9 @@ constexpr int TB_MAX = 2048;   // plan_tb rows staged in LDS per block
 // per wave) stage 16 steps per block in LDS and write whole runs (WPB = 8: 256 B and 64 B).  Two stage halves: ONE barrier per
 // 16 steps (a wave has flushed half A before it meets the barrier that releases half B's flush).  Called by every wave of the
 // block at the same steps, idle waves included.  benv: the block's first env.
-template <int WPB, int EW = 8>
+template <int WPB>
 __device__ void flush_stage(const KArgs& a, const float* srew, const uint8_t* sdone, int tp, int benv, int wv, int lane) {
-    constexpr int BE = WPB * EW;                                     // envs per block (EW per wave), at most 64
+    constexpr int BE = WPB * 8;
     __syncthreads();
     const int t0 = tp & ~15, rows = tp - t0 + 1;
     const int env = benv + lane;
@@ -1259,235 +1259,6 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout3d(const KArgs a) {
     int8_t* sin = (int8_t*)(lds_all + WPB * K::LDS_WORDS + TB_MAX / 2 + STAGE_WORDS) + wv * 512;
     if (nenv == 8) { Roll3D<DYN, OT, WPB, EXPL, true> r(a, lds, tbtab, srew, sdone, sin, lane, env0, nenv, wv); r.run(); }
     else { Roll3D<DYN, OT, WPB, EXPL, false> r(a, lds, tbtab, srew, sdone, sin, lane, env0, nenv, wv); r.run(); }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 3D fused rollout on 16-env tiles (round 3).  What bounds k_rollout3d at BASELINE config 5 (N = 16 384: 64 envs per CU) is
-// instruction issue: its lane-per-env transition keeps 8 of 64 lanes busy, and the two 8-env waves of a SIMD fill 94 % of its
-// issue cycles (profiles/r03_3d_summary.txt).  Sixteen envs per wave halve that work -- but then a SIMD holds ONE wave, and
-// k_rollout3d's tick is max(transition, store latency): its one vmcnt wait (the plan cell of the build target) also covers the
-// row burst issued before it, ~1.2 us under load, which a lone wave cannot hide.  So this kernel has no global load in its loop:
-//   * the plan table lies once per block in LDS as BIT rows ([P][20] words) -- every plan the reference ships or generates is
-//     {0, z}-valued (z = 6: footprint x height), a table that is not (hindsight relabels of arbitrary heights) is detected while
-//     the block builds its copy and served by a plain load per build instead;
-//   * with the plan cell at hand the reward and the running sum for iou() are resolved in the tick itself: none of k_rollout3d's
-//     deferral;
-//   * the rows of step t - 1 are read from LDS before step t changes the map and stored after it (as in k_rollout3d), reward /
-//     done leave in whole runs per 64-env block (flush_stage), the counter RNG hashes 4 ticks at once in all 64 lanes.
-// Semantics are K3D::step's (the select formulation of k_step3d).  Counter-RNG rollouts (a load of the caller's action bytes in the
-// loop would bring the wait back: k_rollout3d stages those a window ahead behind its own wait), batches of 16 384 envs and more,
-// launches of 16 ticks and more (every block reads the plan table once), the canonical layout, every observation written, at most
-// P3D_MAX plans: everything else stays on k_rollout3d / the tile kernel.
-constexpr int P3D_MAX = 512;
-
-template <bool DYN, typename OT, int WPB>
-__global__ __launch_bounds__(WPB * 64) void k_rollout3dw(const KArgs a) {
-    constexpr int E = 16, BE = WPB * E;
-    using K = K3D<DYN, E>;
-    static_assert(BE == 64, "reward / done runs of one 64-env block");
-    constexpr int STAGE_WORDS = (2 * 16 * BE * 5 + 3) / 4;           // reward float + done byte, two halves of 16 steps
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[P3D_MAX * 20 + P3D_MAX / 2 + 4 + STAGE_WORDS + WPB * K::LDS_WORDS];
-    uint32_t* const tab = lds_all;                                   // plan bit rows [P][20]
-    int16_t* const tbtab = (int16_t*)(lds_all + P3D_MAX * 20);       // plan_tb
-    int* const vstat = (int*)(lds_all + P3D_MAX * 20 + P3D_MAX / 2); // [0] largest cell of the table, [1] smallest non-zero cell
-    float* const srew = (float*)(lds_all + P3D_MAX * 20 + P3D_MAX / 2 + 4);
-    uint8_t* const sdone = (uint8_t*)(srew + 2 * 16 * BE);
-    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
-    // ---- the block's copy of the plan table: bit rows, and whether bits are all there is to it
-    if (threadIdx.x == 0) { vstat[0] = 0; vstat[1] = 32767; }
-    for (int i = (int)threadIdx.x; i < a.num_plans; i += WPB * 64) tbtab[i] = a.plan_tb[i];
-    __syncthreads();
-    {
-        int vmax = 0, vmin = 32767;
-        const uint2* const rows = (const uint2*)a.plans;             // a row of 20 int16 cells = five 8-byte pieces
-        for (int i = (int)threadIdx.x; i < a.num_plans * 20; i += WPB * 64) {
-            uint32_t bits = 0;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const uint2 w = rows[(size_t)i * 5 + q];
-                const int c0 = (int)(int16_t)(w.x & 0xffff), c1 = (int)(int16_t)(w.x >> 16), c2 = (int)(int16_t)(w.y & 0xffff), c3 = (int)(int16_t)(w.y >> 16);
-                bits |= ((c0 != 0 ? 1u : 0u) | (c1 != 0 ? 2u : 0u) | (c2 != 0 ? 4u : 0u) | (c3 != 0 ? 8u : 0u)) << (4 * q);
-                vmax = max(max(vmax, max(c0, c1)), max(c2, c3));
-                vmin = min(vmin, min(min(c0 != 0 ? c0 : 32767, c1 != 0 ? c1 : 32767), min(c2 != 0 ? c2 : 32767, c3 != 0 ? c3 : 32767)));
-            }
-            tab[i] = bits;
-        }
-        atomicMax(&vstat[0], vmax);
-        atomicMin(&vstat[1], vmin);
-    }
-    __syncthreads();
-    const int zval = vstat[0];
-    const bool bits_ok = zval == 0 || zval == vstat[1];              // every cell is 0 or zval: a plan cell is (bit ? zval : 0)
-    const int chunk = ((int)gridDim.x + 7) >> 3;                     // an XCD owns a contiguous eighth of the env range
-    const int blk = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
-    const int env0 = __builtin_amdgcn_readfirstlane((blk * WPB + wv) * E);
-    if (env0 >= a.n) {                                               // a wave without envs keeps its block's flushes company
-        if (blk * BE < a.n)
-            for (int tp = 0; tp < a.T; ++tp)
-                if ((tp & 15) == 15 || tp == a.T - 1) flush_stage<WPB, E>(a, srew, sdone, tp, blk * BE, wv, lane);
-        return;
-    }
-    const int nenv = min(E, a.n - env0);
-    const bool active = lane < nenv, full = nenv == E;
-    const int env = env0 + (active ? lane : 0);
-    uint32_t* const lds = lds_all + P3D_MAX * 20 + P3D_MAX / 2 + 4 + STAGE_WORDS + wv * K::LDS_WORDS;
-    Lane s;
-    s.clear();
-    s.r = 3; s.c = 3;                                                // idle lanes keep an in-range position and plan row 0
-    int episode = 0;
-    if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
-    // the episode counter is first USED in the (rare) reset branch of the loop: without this the compiler parks the wait for its
-    // load there, as `s_waitcnt vmcnt(0)` -- and every reset would wait for all the rows stored before it
-    asm volatile("" : "+v"(episode));
-    K::load_grid(lds, a, env0, nenv, lane);
-    const EnvKeys pk = env_keys(a.key_plan, (uint64_t)(a.env_id_base + env));
-    const EnvKeys sk = env_keys(a.key_step, (uint64_t)(a.env_id_base + env0 + (lane & 15)));   // every lane hashes for env (lane & 15)
-    double dtb = (double)s.tb, rtb = 1.0 / dtb;                      // cb / tb, cs / T by the exact reciprocal form of Roll3D
-    const double dT = (double)a.total_step, rT = 1.0 / dT;
-    int d_eps = 0, d_ret = 0;
-    long long d_iou = 0;
-    const bool tl = a.obs_mode == SNAC_OBS_TILED;
-    OT* const obs = (OT*)a.obs + (tl ? (((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)a.tiled_t0) * 64 + (size_t)(env0 & 63)) * K::D
-                                     : (size_t)env0 * K::D) + lane;
-    const size_t tstride = tl ? (size_t)64 * K::D : (size_t)a.n * K::D;
-    // phase-2 lane constants: lanes 0..48 one window cell, lanes 49 / 50 the scalar slots
-    const int wl = lane < K::W ? lane : 0, wi = wl / 7, wj = wl - 7 * wi;
-    const char* const wbase = (const char*)lds + (wi * 26 + wj) * 2;
-    const double* const scp = K::sc(lds) + (lane >= K::W ? min(lane - K::W, 1) : 0);
-    const bool is_win = lane < K::W;
-    int pv[E];                                                       // rows in flight: one window cell per lane and env ...
-    double psv[E];                                                   // ... and the scalar slot of lanes 49 / 50
-    uint32_t wq = 0;                                                 // counter-RNG words of 4 ticks: lane e + 16 j holds (env e, tick + j)
-    for (int t = 0; t <= a.T; ++t) {
-        // ---- A: the rows of step t - 1, read before step t changes map and scalar slots (LDS operations of a wave execute in order)
-        if (t > 0) {
-            const int k0 = K::key0(s);
-#pragma unroll
-            for (int u = 0; u < E; ++u) {
-                pv[u] = *(const int16_t*)(wbase + (u * K::ES * 2 + __builtin_amdgcn_readlane(k0, u)));
-                psv[u] = scp[2 * u];
-            }
-        }
-        if (t < a.T) {
-            const size_t row = (size_t)t * (size_t)a.n + (size_t)env0;
-            // ---- R: auto-reset (rare, wave-uniform): total_brick from the LDS copy of plan_tb
-            const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
-            if (__builtin_expect(__any(nr), 0)) {
-                if (nr) {
-                    episode += 1;
-                    const int old_pidx = s.pidx;
-                    const int pidx = pick_plan<K>(a, pk, episode, old_pidx);
-                    if (pidx != old_pidx) { s.pidx = pidx; s.tb = tbtab[pidx]; dtb = (double)s.tb; rtb = 1.0 / dtb; }
-                    s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
-                }
-                for (unsigned long long m = __ballot(nr); m; m &= m - 1) K::clear(lds, __ffsll(m) - 1, lane);
-            }
-            // ---- B: step t (K3D::step by selects)
-            if ((t & 3) == 0) wq = rng_word(sk, a.t0 + (uint32_t)t + (uint32_t)(lane >> 4));
-            const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & 15) + 16 * (t & 3)) << 2, (int)wq);
-            const int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
-            const int slot = lane & (E - 1);                         // idle lanes only READ some env's map
-            int16_t* const h = K::hmap(lds) + slot * K::ES + s.r * 26 + s.c;
-            const int d = act & 3;
-            const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
-            const int dl = dr * 26 + dc;
-            const int n0 = h[-1], n1 = h[1], n2 = h[26], n3 = h[-26];    // check_sur: left, right, "up" (row + 1), "down"
-            const int c2 = h[2 * dl], c3 = h[3 * dl];                    // within the frame: |offset| <= 3 cells
-            const int tr = s.r + dr - 3, tc = s.c + dc - 3;              // the build target in plan coordinates
-            const bool inside = (unsigned)tr < 20u && (unsigned)tc < 20u;
-            int pl = ((tab[s.pidx * 20 + (inside ? tr : 0)] >> (inside ? tc : 0)) & 1u) ? zval : 0;
-            if (__builtin_expect(!bits_ok, 0)) {
-                // the slow path keeps its wait to itself: consumed inside the branch, or the compiler parks one `s_waitcnt vmcnt(0)`
-                // behind the join -- and every tick of every table would wait for the rows stored before it
-                int pg = ((const int16_t*)a.plans)[(size_t)s.pidx * K::GE + (inside ? tr * 20 + tc : 0)];
-                asm volatile("" : "+v"(pg));
-                pl = pg;
-            }
-            const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
-            const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
-            const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
-            const bool first = s.cs == 0;
-            s.cs = min(s.cs + 1, CNT_MAX);
-            const bool can_move = valid && act < 4 && nd == 0;           // check[act] == 0
-            const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;   // move_step: consecutive free cells, <= k
-            s.r += can_move ? dr * m : 0;
-            s.c += can_move ? dc * m : 0;
-            const bool built = active && is_build && nd != -1;           // check[act] == 0 for act in 4..7
-            const int newh = min(nd + 1, CNT_MAX);
-            if (built) h[dl] = (int16_t)newh;
-            s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
-            s.cross += (built && newh <= pl) ? 1 : 0;                    // running sum of min(height, plan) for iou()
-            const bool limit = s.cb >= s.tb + a.brick_gt;
-            bool done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);      // moves, blocked moves, blocked builds
-            int reward = 0;
-            const int rcheck = newh > pl ? -1 : (newh == pl ? 10 : 1);   // reward_check on the built cell
-            if (DYN) {
-                // neighbours re-evaluated AFTER the build: the built cell now blocks its direction
-                const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
-                const bool fin = is_build && (boxed_post || limit);
-                reward = is_build ? (boxed_post ? -100 : ((!limit && built) ? rcheck : 0)) : 0;
-                done = fin ? true : ((is_build && built) ? false : done);
-            } else {
-                const bool fin = is_build && (limit || boxed_pre);
-                reward = (is_build && !fin && built) ? rcheck : 0;
-                done = fin ? true : ((is_build && built) ? false : done);
-            }
-            done = done && active;
-            s.ep_ret = clamp16(s.ep_ret + reward);
-            s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
-            if (__builtin_expect(__any(done), 0)) {                      // iou (:257-276) = sum(min(g, plan)) / (tb + cb - sum)
-                if (done) {
-                    const double v = (double)s.cross / (double)(s.tb + s.cb - s.cross);
-                    d_eps += 1; d_ret += s.ep_ret; d_iou += __double2ll_rn(v * FX40);
-                }
-            }
-            {   // the two scalar observation slots -> LDS
-                const double c0 = (double)s.cb, c1 = (double)s.cs;
-                double v0 = c0, v1 = c1;
-                if (DYN) {
-                    const double q0 = c0 * rtb, q1 = c1 * rT;
-                    v0 = __builtin_fma(__builtin_fma(-q0, dtb, c0), rtb, q0);
-                    v1 = __builtin_fma(__builtin_fma(-q1, dT, c1), rT, q1);
-                    if (__builtin_expect(__any(active && s.tb <= 0), 0)) {   // only a hand-made header; the asm keeps it a branch
-                        asm volatile("" ::: "memory");
-                        v0 = c0 / dtb;
-                    }
-                }
-                if (lane < E) { double2 v; v.x = v0; v.y = v1; *(double2*)(K::sc(lds) + 2 * lane) = v; }
-            }
-            if (lane < E) {                                              // idle lanes of a ragged tile stage values nobody writes out
-                const int st = (t & 31) * BE + wv * E + lane;
-                srew[st] = (float)reward;
-                sdone[st] = done ? 1 : 0;
-            }
-            if (active) {
-                if (a.actions_out) a.actions_out[row + lane] = (int8_t)act;
-                if (a.step_size_out) a.step_size_out[row + lane] = (int8_t)k;
-                if (a.plan_idx_out) a.plan_idx_out[row + lane] = (int16_t)s.pidx;
-                if (a.first_out) a.first_out[row + lane] = first ? 1 : 0;
-            }
-        }
-        // ---- S: the rows of step t - 1
-        if (t > 0) {
-            OT* const prev = obs + (size_t)(t - 1) * tstride;
-#pragma unroll
-            for (int u = 0; u < E; ++u) {
-                const double val = is_win ? (double)pv[u] : psv[u];
-                if (lane < K::D && (full || u < nenv)) prev[u * K::D] = (OT)val;
-            }
-        }
-        if (t < a.T && ((t & 15) == 15 || t == a.T - 1)) flush_stage<WPB, E>(a, srew, sdone, t, env0 - wv * E, wv, lane);
-    }
-    K::store_grid(lds, a, env0, nenv, lane);
-    if (active) {
-        a.hdr[env] = s.pack();
-        a.episode[env] = episode;
-        if (d_eps) {
-            a.stat_episodes[env] += d_eps;
-            a.stat_return[env] += d_ret;
-            a.stat_iou_fx[env] += d_iou;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2878,24 +2649,8 @@ void launch_roll3d_w(const KArgs& a, hipStream_t s) {
     if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout3d<DYN, OT, WPB, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_rollout3d<DYN, OT, WPB, false>), grid, block, 0, s, a);
 }
-// 16-env tiles with the plan bits in LDS: from one such wave per SIMD (N = 16 384) up; SNAC_3D_WIDE=0 keeps k_rollout3d (A/B timing)
-bool roll3dw_ok(const KArgs& a) {
-    static const bool off = [] { const char* e = std::getenv("SNAC_3D_WIDE"); return e && e[0] == '0'; }();
-    return !off && a.n >= 16384 && a.T >= 16 && a.num_plans <= P3D_MAX && !a.actions && !a.step_size;
-}
-template <bool DYN, typename OT>
-void launch_roll3dw_w(const KArgs& a, hipStream_t s) {
-    const int blocks = (a.n + 63) / 64;
-    const dim3 grid((unsigned)(((blocks + 7) / 8) * 8)), block(256);   // a multiple of 8: the XCD remap covers every tile
-    hipLaunchKernelGGL((k_rollout3dw<DYN, OT, 4>), grid, block, 0, s, a);
-}
 void launch_roll3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
-    if (roll3dw_ok(a)) {
-        if (dyn) f32 ? launch_roll3dw_w<true, float>(a, s) : launch_roll3dw_w<true, double>(a, s);
-        else f32 ? launch_roll3dw_w<false, float>(a, s) : launch_roll3dw_w<false, double>(a, s);
-        return;
-    }
     if (a.n < 8192) {   // one-wave blocks reach every CU with small batches
         if (dyn) f32 ? launch_roll3d_w<true, float, 1>(a, s) : launch_roll3d_w<true, double, 1>(a, s);
         else f32 ? launch_roll3d_w<false, float, 1>(a, s) : launch_roll3d_w<false, double, 1>(a, s);
@@ -3022,7 +2777,9 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
         case SNAC_ENV_2D:
             if (op == OP_TRANSITION && !a.variant && !pipeline_off() && step_stage_ok(a)) { launch_step_tile<2>(d, a, s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans2d(d, a, s); break; }
-            if (op == OP_ROLLOUT && roll2d_ok(a, E)) { launch_roll2d(d, a, s); break; }
+            // float32 rows from N = 32 768: 512 staged waves (1.05 -> 0.74 ms per 600 ticks); float64 rows there are level (1.26-1.60 ms
+            // by box for either kernel) and stay on 32-env tiles
+            if (op == OP_ROLLOUT && roll2d_ok(a, (d->obs_dtype == SNAC_OBS_F32 && a.n >= 32768) ? 64 : E)) { launch_roll2d(d, a, s); break; }
             launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
             if (op == OP_ROLLOUT && E == 8 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && !pipeline_off()) { launch_roll3d(d, a, s); break; }

@@ -67,6 +67,27 @@ def test_tiles_dtypes_and_launch_lengths(dyn, n, f32):
     _compare(env, orc, 3, t0, f32)                                # the records written back by the launches above carry on
 
 
+@pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
+def test_float32_rows_take_the_staged_kernel_from_32768_envs(dyn):
+    """With float32 rows the staged kernel pays from N = 32 768 (512 waves of 64 envs); float64 rows of the same batch stay on 32-env
+    tiles of the tile kernel -- both against the oracle, and against each other."""
+    import torch
+
+    n = 32768 + 36
+    env, orc = _pair(dyn, n, seed=6, total_step=30, obs_dtype=torch.float32)
+    ref, _ = _pair(dyn, n, seed=6, total_step=30)
+    t0 = 0
+    for T in (1, 37):
+        og, rg, dg = env.rollout(T)
+        o2, r2, d2 = ref.rollout(T)
+        oc, rc, dc = orc.rollout(T, t0=t0, nthreads=16)
+        assert og.cpu().numpy().tobytes() == oc.astype(np.float32).tobytes() and o2.cpu().numpy().tobytes() == oc.tobytes()
+        assert rg.cpu().numpy().tobytes() == rc.tobytes() and torch.equal(rg, r2) and torch.equal(dg, d2)
+        t0 += T
+    _end_state(env, orc)
+    assert torch.equal(env._hdr, ref._hdr) and torch.equal(env._grid, ref._grid) and torch.equal(env._stats, ref._stats)
+
+
 @pytest.mark.parametrize("rules", [(False, False), (True, False), (False, True), (True, True)], ids=str)
 def test_episodes_end_by_bricks_and_by_time(rules):
     """Sparse plans (total_brick floored at 30) and drop-heavy explicit actions: episodes end at count_brick >= (>) total_brick
