@@ -1998,7 +1998,7 @@ __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
 
 typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));   // a 16-byte global access at a 2-byte aligned address
 
-template <bool DYN, typename OT, int WPB, int PAD = 0>
+template <bool DYN, typename OT, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_step3d(const KArgs a) {
     using K = K3D<DYN, 8>;
     constexpr int E = 64, GE = K::GE;
@@ -2006,7 +2006,7 @@ __global__ __launch_bounds__(WPB * 64) void k_step3d(const KArgs a) {
     // to 3 cells left or 4 right of the loaded block: what a row lacks in pads, its neighbour's pads (or the lane's own leading /
     // trailing 8 bytes) supply.  184 bytes per lane: 46 dwords, a 2-way bank pattern; the whole scratch is smaller than the staging tile.
     constexpr int LS = 184, RB = 24, R0 = 8;
-    constexpr int WAVE_BYTES = (E * LS > TILE_STG_BYTES ? E * LS : TILE_STG_BYTES) + PAD;   // PAD: occupancy experiments
+    constexpr int WAVE_BYTES = E * LS > TILE_STG_BYTES ? E * LS : TILE_STG_BYTES;
     static_assert(WAVE_BYTES % 16 == 0, "16-byte aligned staging tiles");
     __shared__ __attribute__((aligned(16))) char lds_all[WPB * WAVE_BYTES];
     const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
@@ -2054,7 +2054,11 @@ __global__ __launch_bounds__(WPB * 64) void k_step3d(const KArgs a) {
             v[i] = make_uint4(~0u, ~0u, ~0u, ~0u);                   // a frame row
             if (in) {
                 v[i] = make_uint4(0u, 0u, 0u, 0u);                   // a freshly reset env is empty
-                if (active && !nr) { const u32x4_a2 t = *(const u32x4_a2*)(src + q * 20 + start); v[i] = make_uint4(t.x, t.y, t.z, t.w); }
+                if (active && !nr) {
+                    // nontemporal: the rows are streamed once per tick (100.2 against 103.8 us per tick at N = 524 288, three runs each)
+                    const u32x4_a2 t = __builtin_nontemporal_load((const u32x4_a2*)(src + q * 20 + start));
+                    v[i] = make_uint4(t.x, t.y, t.z, t.w);
+                }
             }
         }
 #pragma unroll
@@ -2716,9 +2720,6 @@ void launch_step_tile(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4>), grid, block, 0, s, a); }
     } else {
-        static const int occ = [] { const char* e = std::getenv("SNAC_STEP3D_OCC"); return e ? std::atoi(e) : 0; }();
-        if (dyn && !f32 && occ == 2) { hipLaunchKernelGGL((k_step3d<true, double, 4, 7168>), grid, block, 0, s, a); return; }
-        if (dyn && !f32 && occ == 1) { hipLaunchKernelGGL((k_step3d<true, double, 4, 14336>), grid, block, 0, s, a); return; }
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step3d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<true, double, 4>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step3d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<false, double, 4>), grid, block, 0, s, a); }
     }
