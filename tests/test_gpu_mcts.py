@@ -369,3 +369,38 @@ def test_default_policy_evaluation_matches_the_reference_loop(dim, dyn):
         assert np.float64(est[i].item()).tobytes() == np.float64(estimate).tobytes(), (dim, dyn, i)
         assert int(steps[i]) == t
     assert n_term > 0 or dim == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
+def test_large_waves_of_2d_edges(dyn, f32):
+    """A wave of 65 536 + 36 edges on a pool of 2^18 rows (the 32-edge tiles of k_transition2d; round 3 also tried 64-edge tiles whose
+    rows leave through emit_tile -- parity-green with this test, 6 % slower: 0.105 against 0.099 ms per 655 360 edges, not kept):
+    shared random parents from the lower half, distinct children in the upper half, some edges in place; against the oracle, and a
+    second wave on the children."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    pool, m = 1 << 18, 65536 + 36
+    table = helpers.plan_table(2, dyn, "dense_train" if dyn else "p0")
+    env = BatchedDMPEnv(2, dyn, pool, plans=table.reshape(len(table), 26, 26), seed=21, obs_dtype=torch.float32 if f32 else torch.float64)
+    orc = helpers.oracle().OracleBatch(2, dyn, pool, table, seed=21)
+    env.reset(); orc.reset()
+    env.rollout(25, obs=None); orc.rollout(25, obs=None, nthreads=16)
+    rng = np.random.default_rng(5)
+    for wave in range(2):
+        dst = (pool // 2 + rng.choice(pool // 2, m, replace=False)).astype(np.int32)
+        src = rng.integers(0, pool // 2, m).astype(np.int32)
+        inplace = rng.random(m) < 0.1
+        src = np.where(inplace, dst, src).astype(np.int32)
+        acts = rng.integers(0, 5, m).astype(np.int8)
+        ks = rng.integers(1, 4, m).astype(np.int8) if wave == 0 else None
+        o, r, d = env.transition(acts, ks, src, dst, t=wave)
+        oo, ro, do = orc.transition(acts, ks, src, dst, t=wave)
+        assert o.cpu().numpy().tobytes() == (oo.astype(np.float32) if f32 else oo).tobytes(), wave
+        assert r.cpu().numpy().tobytes() == ro.tobytes() and np.array_equal(d.cpu().numpy().astype(np.uint8), do), wave
+    assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+    idx = np.arange(0, pool, 1031)
+    cb = env.count_brick.cpu().numpy()
+    assert [int(cb[i]) for i in idx] == [int(orc.b.contents.envs[int(i)].cb) for i in idx]
