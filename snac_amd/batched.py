@@ -429,6 +429,38 @@ class BatchedDMPEnv:
         self._plans_stale = True                               # the host copy (plans_full) no longer mirrors the device table
         return area
 
+    def generate_plans_numpy(self, first=0, count=None, sparse=False):
+        """Rows [first, first + count) of the device plan table drawn THE WAY THE REFERENCE DRAWS THEM, from numpy's global stream, one
+        row after the other -- so that a script that calls np.random.seed(s) gets the plans the reference's create_plan() would give it:
+          2D / 3D  Env/2D/DMP_Env_2D_dynamic_hindsight_replay_usedata.py:37-59: per attempt x = np.random.randint(0, 20, size=3), then
+                   y likewise; the triangle is rasterised on the device with explicit vertices (snac_make_plans: cv2's rules restated,
+                   the 2000 dataset plans reproduced bit for bit) and redrawn while the area is <= 50 (dense) / 20 (sparse) -- 3D also
+                   while it is >= 110 (script/HumanPlayerGUI/env/Env3D.py:360-364, how the 3D datasets were drawn);
+          1D       Env/1D/DMP_Env_1D_dynamic_hindsight_replay.py:29-42 through plans.random_sin_plan() (numpy's own sine, on the host).
+        generate_plans() is the batched form (counter RNG, one launch for all rows); this one is for seed-level parity and costs a
+        launch and a wait per attempt.  Returns the areas (1D: total_brick) as a list of ints."""
+        count = self.num_plans - first if count is None else int(count)
+        if first < 0 or count < 0 or first + count > self.num_plans:
+            raise ValueError("plan rows out of range")
+        areas = []
+        if self.kind == 1:
+            for r in range(first, first + count):
+                y, area, _ = _plans.random_sin_plan()
+                self.set_plan_row(r, y, update_tb=True)
+                areas.append(int(area))
+            return areas
+        lo, hi = (20 if sparse else 50), (110 if self.kind == 3 else 401)
+        for r in range(first, first + count):
+            while True:
+                x = np.random.randint(0, 20, size=3)
+                y = np.random.randint(0, 20, size=3)
+                v = np.array([[x[0], y[0], x[1], y[1], x[2], y[2]]], np.int8)
+                area = int(self.generate_plans(r, 1, sparse=sparse, vertices=v).item())
+                if lo < area < hi:
+                    break
+            areas.append(area)
+        return areas
+
     def _sync_plans_full(self):
         """Decode the device plan table back into the reference's host format after generate_plans()."""
         if not getattr(self, "_plans_stale", False):

@@ -96,3 +96,39 @@ def test_generated_plans_hip_vs_oracle_and_rollouts_on_them(dim, sparse, P):
     assert og.cpu().numpy().tobytes() == oc.tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes()
     assert np.array_equal(dg.cpu().numpy().astype(np.uint8), dc) and env.iou().cpu().numpy().tobytes() == ob.iou().tobytes()
     assert torch.equal(env.total_brick.cpu(), torch.from_numpy(ob.state()["tb"].astype(np.int64)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,sparse", [(2, 0), (2, 1), (3, 0), (3, 1), (1, 0)])
+def test_plans_from_numpys_stream_equal_the_reference_draw_order(dim, sparse):
+    """generate_plans_numpy(): same np.random seed -> the plans the reference's create_plan() would draw, row after row (two
+    randint(0, 20, size=3) per attempt, redrawn while the area fails the bounds; 1D: uniform, randint, uniform).  A RandomState twin
+    that consumes the stream that way -- with the oracle's rasteriser deciding the redraws -- lands on the same rows, and on the same
+    next word of the global stream."""
+    from snac_amd import BatchedDMPEnv
+
+    orc = helpers.oracle()
+    P, seed = 24, 123 + 10 * dim + sparse
+    env = BatchedDMPEnv(dim, True, 8, plans=np.zeros((P, 30) if dim == 1 else (P, 26, 26)) + (20 if dim == 1 else 0), seed=3)
+    np.random.seed(seed)
+    areas = env.generate_plans_numpy(2, P - 2, sparse=bool(sparse))
+    after = int(np.random.randint(0, 1 << 30))
+    env._sync_plans_full()
+    st = np.random.RandomState(seed)
+    for r in range(2, P):
+        if dim == 1:
+            k1 = st.uniform(3, 12); k2 = st.randint(1, 4); ph = st.uniform(-1, 1) * np.pi
+            y = np.round(k1 * np.sin(2 * np.pi / 30 * (k2 * np.arange(30) + ph)) + 20)
+            assert np.array_equal(env.plans_full[r], y) and areas[r - 2] == int(y.sum())
+            continue
+        while True:
+            x, y = st.randint(0, 20, size=3), st.randint(0, 20, size=3)
+            img, a = orc.raster_triangle(x, y, sparse)
+            if (20 if sparse else 50) < a < (110 if dim == 3 else 401):
+                break
+        assert areas[r - 2] == a
+        assert np.array_equal(env.plans_full[r][3:23, 3:23], img * (6 if dim == 3 else 1)), r
+    assert int(st.randint(0, 1 << 30)) == after
+    tb = env._plan_tb.cpu().numpy()[2:].astype(np.int64)
+    want = np.asarray(areas) if dim == 1 else (np.maximum(np.asarray(areas), 30) if dim == 2 else 6 * np.asarray(areas))
+    assert np.array_equal(tb, want)
