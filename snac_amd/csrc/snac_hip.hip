@@ -1903,8 +1903,16 @@ __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
     uint4 rv[5];
     {
         const uint4* const g4 = (const uint4*)a.grid + (size_t)env0 * 5;
+        // nontemporal, like k_step3d's window rows: read once per tick, and kept out of the way of the row stores' lines in L2
+        // (46.1 against 48.4 us per tick at N = 524 288, three runs each; the tree-edge kernels, whose parents are shared by
+        // their children, lose 15-25 % with it and keep plain loads)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { const int g = i * 64 + lane; rv[i] = g < nenv * 5 ? g4[g] : make_uint4(0u, 0u, 0u, 0u); }
+        for (int i = 0; i < 5; ++i) {
+            const int g = i * 64 + lane;
+            rv[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (g < nenv * 5) { const u32x4 t = __builtin_nontemporal_load((const u32x4*)(g4 + g)); rv[i] = make_uint4(t.x, t.y, t.z, t.w); }
+        }
     }
     Lane s;
     s.clear();

@@ -1,17 +1,8 @@
-mkdir -p gpurun_out; rm -f gpurun_out/r3_ab11.txt
-for rep in 1 2 3; do
-for l in a b c; do
-  echo "lib=$l (a: all window loads nontemporal; b: first pass plain, reload nontemporal; c: all plain)" >> gpurun_out/r3_ab11.txt
-  SNAC_HIP_LIB=$PWD/ab/libsnac_$l.so timeout -k 10 120 python tools/step_time.py 3 524288 200 f64 >> gpurun_out/r3_ab11.txt 2>&1
-done
-done
-grep -v amdgpu gpurun_out/r3_ab11.txt | grep -v "^lib" | awk '{print (NR-1)%3, $0}' | sort -n | cut -c1-100
-cd /tmp && export TMPDIR=/tmp
-for l in a b c; do
-  SNAC_HIP_LIB=$OLDPWD/ab/libsnac_$l.so timeout 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OLDPWD/gpurun_out/pmcnt_$l -o pmc -- python3 $OLDPWD/tools/step_time.py 3 524288 20 f64 > /dev/null 2>&1
-  python3 - <<PY
-import csv,glob
-v=[float(r["Counter_Value"]) for f in glob.glob("$OLDPWD/gpurun_out/pmcnt_$l/**/*counter_collection.csv", recursive=True) for r in csv.DictReader(open(f)) if "k_step3d" in r["Kernel_Name"]]
-print("lib $l FETCH_SIZE avg KiB", sum(v)/max(len(v),1), len(v))
-PY
-done
+mkdir -p gpurun_out
+timeout -k 10 600 python -m pytest tests/test_gpu_step_tile.py tests/test_gpu_parity.py tests/test_gpu_facade.py tests/test_gpu_trajmem.py -x -q > gpurun_out/r3_t9.log 2>&1; echo "rc=$?" >> gpurun_out/r3_t9.log
+tail -3 gpurun_out/r3_t9.log
+bash tools/profile.sh r03 > gpurun_out/r03_profile.log 2>&1
+tail -1 gpurun_out/r03_profile.log | cut -c1-220
+PROG=tools/prof_step.py bash tools/profile.sh r03_step > gpurun_out/r03_step_profile.log 2>&1
+find gpurun_out/prof_r03_step -name "*.csv" ! -name "*kernel_stats.csv" -delete
+grep "k_step" gpurun_out/prof_r03_step/summary.txt | grep "n=50 avg=.*us" | cut -c1-120
