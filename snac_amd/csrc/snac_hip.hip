@@ -764,8 +764,9 @@ __device__ __forceinline__ void emit_tile(char* stg, char* g, int lane, int nenv
 //   * cb / tb and cs / T by the exact reciprocal form of Roll3D (one division per episode instead of two per tick);
 //   * EXPL: the caller's action / step-size bytes of tick t + 1 are requested a tick ahead (their latency is hidden; the wait for
 //     them is still a `vmcnt(0)` across the loop's back edge, i.e. one drain of the rows per tick, as in the tile kernel).
-// Full tiles of 64 envs (N >= 65 536 by pick_tile), N % 4 == 0 and a 16-byte aligned obs (the 16-byte stores), canonical layout,
-// every observation written (SNAC_OBS_ALL / SNAC_OBS_TILED), at most P2D_MAX plans: everything else stays on k_rollout.
+// Tiles of 64 envs -- N >= 65 536 (pick_tile), float32 rows already from N = 32 768 (launch()) --, N % 4 == 0 and a 16-byte aligned obs
+// (the 16-byte stores), canonical layout, every observation written (SNAC_OBS_ALL / SNAC_OBS_TILED), at most P2D_MAX plans:
+// everything else stays on k_rollout.
 constexpr int P2D_MAX = 512;
 
 template <bool DYN, typename OT, int WPB, bool EXPL>
