@@ -105,3 +105,28 @@ def test_record_outputs_and_the_tile_kernel_agree(n):
     done = da.cpu().numpy()
     assert first[0].all() and np.array_equal(first[1:], done[:-1].astype(np.uint8))   # auto-reset: a step opens an episode iff the last one ended one
     assert np.array_equal(rec["plan_idx"][-1].cpu().numpy(), a.plan_idx.cpu().numpy())   # an env is reset by its NEXT step
+
+
+@pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
+@pytest.mark.parametrize("total_step,time_gt", [(1, False), (5, False), (7, True), (63, False), (64, False), (65, True)])
+def test_time_parallel_kernel_segments_inside_a_chunk(dyn, total_step, time_gt):
+    """Round 3: up to 8192 envs a 1D rollout runs on k_rollout1dt -- one wavefront per env, lane = tick, 64 ticks per chunk.  An
+    episode that ends inside a chunk splits it into segments (the reset happens in the wave's uniform state): time limits of 1
+    (every lane its own episode), 5 and 7 (a dozen segments per chunk), and 63 / 64 / 65 (ends on, just before and just behind the
+    chunk border); launches of 1, 64, 65 and 200 ticks; both dtypes; explicit inputs on the last launch."""
+    import torch
+
+    for f32 in (False, True):
+        env, orc = _pair(dyn, 37, seed=8, total_step=total_step, obs_dtype=torch.float32 if f32 else None, time_gt=time_gt)
+        t0 = 0
+        for T in (1, 64, 65, 200):
+            _compare(env, orc, T, t0, f32)
+            t0 += T
+        rng = np.random.default_rng(total_step)
+        acts = rng.integers(0, 3, size=(70, 37)).astype(np.int8)
+        ks = rng.integers(1, 4, size=(70, 37)).astype(np.int8)
+        og, rg, dg = env.rollout(70, actions=acts, step_size=ks)
+        oc, rc, dc = orc.rollout(70, t0=t0, actions=acts, step_size=ks, nthreads=8)
+        assert og.cpu().numpy().tobytes() == (oc.astype(np.float32) if f32 else oc).tobytes()
+        assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+        _end_state(env, orc)
