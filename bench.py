@@ -549,8 +549,8 @@ def main():
                          "note": "device time per tick, launches enqueued back to back" + ("" if nn >= 262144 else "; at this batch size the host's enqueue rate is part of it")}
 
         rollout_cfg("c2_1d_static_n4096_T750", 1, False, 4096, False, 40,
-                    "time-parallel kernel k_rollout1dt (one wave per env, lane = tick: 0.29 -> 0.11 ms); the pass writes only 187 MB, in 56-byte rows "
-                    "that are N x 56 bytes apart per env, so it is bound by that store pattern, not by the HBM rate")
+                    "time-parallel kernel k_rollout1dt (one wave per env, lane = tick, the rows of 16 envs through an LDS tile as 896-byte runs: "
+                    "0.29 -> 0.05 ms); the pass writes only 187 MB and is bound by instruction issue (~9 per env-step), not by the HBM rate")
         rollout_cfg("c5_3d_dynamic_n16384_T1000", 3, True, 16384, False, 24)
         rollout_cfg("headline_f32_obs", 2, True, 65536, True, 24)
         for kind in (2, 3):
@@ -601,9 +601,9 @@ def main():
                 traffic_source = "none: profiles/traffic.json belongs to kernel source %s, this library was built from %s" % (tj.get("source_sha16"), now)
         written = WRITTEN_BYTES[(args.kind, dkey)] * n * T / (kern_ms * 1e-3) / 1e9
         what = "%dD %s dense" % (args.kind, "dynamic" if dynamic else "static")
-        # the kernel this workload dispatches to (snac_hip.hip::launch): the 2D tile kernel, the pipelined 3D rollout, the
-        # chain-shaped 1D rollout up to 16 384 envs
-        kernel_name = "k_rollout3d" if args.kind == 3 else ("k_rollout1dt" if args.kind == 1 and n <= 8192 else "k_rollout1d" if args.kind == 1 and n <= 16384 else
+        # the kernel this workload dispatches to (snac_hip.hip::launch): the staged 2D rollout, the pipelined 3D rollout, the
+        # time-parallel 1D rollout up to 49 152 envs (float32 rows: 65 536), the tile kernel otherwise
+        kernel_name = "k_rollout3d" if args.kind == 3 else ("k_rollout1dt" if args.kind == 1 and n <= (65536 if args.obs_f32 else 49152) else
                                                             ("k_rollout2d" if args.kind == 2 and n >= 65536 and n % 4 == 0 else "k_rollout"))
         out = {
             "metric": HEADLINE if headline else "env-steps/sec at N=%d envs (%s, %s obs); bit-exact vs CPU" % (n, what, dkey),

@@ -13,7 +13,7 @@
 // Integer / indexing work only -- no MFMA; the bound is HBM (observation writes).
 // Besides the tile kernels (k_rollout, k_transition, k_aux) four kernels are shaped round what bounds their case, each with the
 // tile kernel behind it for everything else: k_rollout3d (3D rollouts: one late vmcnt wait per step, reward / done in whole runs),
-// k_rollout1d (1D rollouts up to two waves per SIMD: lane = (env, observation element), control chain independent of the heights),
+// k_rollout1dt (1D rollouts up to ~50 000 envs: a wave takes one env and 64 TICKS, the control chain as scans and ballots),
 // k_transition2d / k_transition3d (single steps and tree edges without LDS images).  Rollout outputs are [T][N][D] or, with
 // SNAC_OBS_TILED, tile-major [N / 64][T][64][D] (a tile streams through its own region: 6.9 instead of 6.0 TB/s of writes).
 #include <hip/hip_runtime.h>
@@ -950,8 +950,8 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
 constexpr int TB_MAX = 2048;   // plan_tb rows staged in LDS per block
 
 // reward [T][N] float and done [T][N] uint8 of one wave's 8 envs are 32-byte and 8-byte pieces: written per tick they cost
-// 15 % of a whole 3D pass (sub-64-byte writes, tools/wr_shape3d.hip).  The pipelined rollouts (k_rollout3d, k_rollout1d: 8 envs
-// per wave) stage 16 steps per block in LDS and write whole runs (WPB = 8: 256 B and 64 B).  Two stage halves: ONE barrier per
+// 15 % of a whole 3D pass (sub-64-byte writes, tools/wr_shape3d.hip).  The pipelined rollout (k_rollout3d: 8 envs
+// per wave) stages 16 steps per block in LDS and write whole runs (WPB = 8: 256 B and 64 B).  Two stage halves: ONE barrier per
 // 16 steps (a wave has flushed half A before it meets the barrier that releases half B's flush).  Called by every wave of the
 // block at the same steps, idle waves included.  benv: the block's first env.
 template <int WPB>
@@ -1263,217 +1263,6 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout3d(const KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 1D fused rollout (counter RNG, every observation written), built round the dependency chain instead of the tile machinery.
-// BASELINE config 2 (1D static, N = 4096) is 512 waves walking 750 dependent ticks: with the generic kernel a tick costs
-// 0.59 us (hash, LDS round trips for the cell, the scalar slots and the 7-value rows, one after the other) while the whole
-// pass writes only 187 MB.  Two facts shorten the chain:
-//   * in 1D (DMP_Env_1D_static.py:85-136) position, count_brick, count_step, done and the auto-reset depend on the ACTIONS
-//     only, never on the heights: the control chain of a tick is a dozen VALU instructions; the heights enter the reward and
-//     the window, and both can be resolved a tick later;
-//   * a wave's 64 lanes are laid out as (env e, observation element el): lane 7 e + el, 8 envs = 56 lanes.  The 7 lanes of an
-//     env run the same control chain redundantly, so every lane already knows where ITS element lives -- window lanes read
-//     one height from LDS, lanes 5 / 6 compute their scalar slot -- and the tile's 8 rows leave as one 448-byte store with no
-//     cross-lane traffic at all.  Lane el = 2 (the window centre = the agent's cell) owns the env: it adds the brick
-//     (ds_add, no read-modify-write round trip; heights saturate on read), resolves the reward and keeps the episodic sums.
-// A tick issues its LDS reads and finishes the PREVIOUS tick (reward, row store, staged reward / done) while they fly; two
-// register sets alternate so that no copy waits for them.  The counter RNG hashes 8 ticks at once in all 64 lanes (lane
-// e + 8 j: env e, tick t + j), a tick fetches its word with one bpermute.  reward / done: whole runs per block (flush_stage).
-// Semantics are K1D::step's; explicit inputs, layout variants, OBS_LAST / OBS_NONE stay on the generic kernel.
-template <bool DYN, typename OT, int WPB>
-__global__ __launch_bounds__(WPB * 64) void k_rollout1d(const KArgs a) {
-    using K = K1D<DYN, 8>;
-    constexpr int BE = WPB * 8;
-    constexpr bool STAGE = WPB >= 4;
-    constexpr int H_WORDS = 8 * 34, P_WORDS = 8 * 32;                // heights int32 [8][34] with the frame, plans int32 [8][32] (no
-                                                                     // conversion behind a read: its first use is a tick later)
-    constexpr int WAVE_WORDS = H_WORDS + P_WORDS;
-    constexpr int STAGE_WORDS = STAGE ? (2 * 16 * BE * 5 + 3) / 4 : 0;
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * WAVE_WORDS + STAGE_WORDS + 1];
-    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
-    const int chunk = ((int)gridDim.x + 7) >> 3;                     // an XCD owns a contiguous eighth of the env range
-    const int blk = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
-    const int env0 = __builtin_amdgcn_readfirstlane((blk * WPB + wv) * 8);
-    float* srew = (float*)(lds_all + WPB * WAVE_WORDS);
-    uint8_t* sdone = (uint8_t*)(srew + (STAGE ? 2 * 16 * BE : 0));
-    if (env0 >= a.n) {                                               // a wave without envs keeps its block's flushes company
-        if constexpr (STAGE) {
-            if (blk * BE < a.n)
-                for (int tp = 0; tp < a.T; ++tp)
-                    if ((tp & 15) == 15 || tp == a.T - 1) flush_stage<WPB>(a, srew, sdone, tp, blk * BE, wv, lane);
-        }
-        return;
-    }
-    const int nenv = min(8, a.n - env0);
-    int* const H = (int*)(lds_all + wv * WAVE_WORDS);
-    int* const PL = H + H_WORDS;
-    const int e = min(lane / 7, 7), el = lane < 56 ? lane - 7 * e : 0;
-    const bool live = lane < 56 && e < nenv;                         // this lane has an observation element
-    const bool own = live && el == 2;                                // ... and owns its env
-    const int env = env0 + (e < nenv ? e : 0);
-    Lane s;
-    s.unpack(a.hdr[env]);
-    int episode = a.episode[env];
-    {   // records -> LDS: heights with their frame, the envs' plans
-        const int16_t* g16 = (const int16_t*)a.grid;
-        for (int i = lane; i < 8 * 34; i += 64) {
-            const int ee = i / 34, c = i - ee * 34;
-            int v = -1;
-            if (c >= 2 && c < 32) v = ee < nenv ? (int)g16[(size_t)(env0 + ee) * K::GE + (c - 2)] : 0;
-            H[i] = v;
-        }
-        for (int i = lane; i < 8 * 32; i += 64) {
-            const int ee = i >> 5, c = i & 31;
-            const int pe = __shfl(s.pidx, 7 * ee);                   // lane 7 ee holds env ee's header
-            PL[i] = (int)((const int16_t*)a.plans)[(size_t)pe * K::GE + c];
-        }
-    }
-    const EnvKeys pk = env_keys(a.key_plan, (uint64_t)(a.env_id_base + env));
-    const EnvKeys sk = env_keys(a.key_step, (uint64_t)(a.env_id_base + env0 + (lane & 7)));   // producer layout: env (lane & 7)
-    // cb / tb and cs / T without a division per tick (Roll3D: correctly rounded for 0 <= n <= 32767, 1 <= d <= 32767)
-    double dtb = (double)s.tb, rtb = 1.0 / dtb;
-    const double dT = (double)a.total_step, rT = 1.0 / dT;
-    int d_eps = 0, d_ret = 0;
-    long long d_iou = 0;
-    uint32_t wq = rng_word(sk, a.t0 + (uint32_t)(lane >> 3));        // the words of steps 0..7
-    uint32_t wnext = (uint32_t)__builtin_amdgcn_ds_bpermute(e << 2, (int)wq);   // step 0's, fetched a step ahead from now on
-    // what a tick leaves open for the next one to finish: two sets in rotation
-    struct Open { int v, pl, ret; double sc; long long iou_fx; bool drop, term, done, first; int act, k, pidx; };
-    Open o[2];
-    o[0] = Open{0, 0, 0, 0.0, 0, false, false, false, false, 0, 1, 0};
-    o[1] = o[0];
-    const bool tl = a.obs_mode == SNAC_OBS_TILED;                    // [T][N][D], or tile-major [ceil(N / 64)][tiled_T][64][D]
-    OT* const obs = (OT*)a.obs + (tl ? (((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)a.tiled_t0) * 64 + (size_t)(env0 & 63)) * K::D
-                                     : (size_t)env0 * K::D) + lane;
-    const size_t tstride = tl ? (size_t)64 * K::D : (size_t)a.n * K::D;
-    int* const hrow = H + e * 34;
-    const int* const prow = PL + e * 32;
-
-    const bool rec = a.actions_out || a.step_size_out || a.plan_idx_out || a.first_out;
-    // finish step tp: reward, episodic sums, the row, staged reward / done
-    auto finish = [&](const Open& q, int tp, bool was_reset) {
-        const int hv = min(q.v, CNT_MAX);                            // heights saturate (on read: LDS holds the raw count)
-        const int reward = (q.drop && !q.term) ? (hv > q.pl ? -1 : (hv == q.pl ? 10 : 1)) : 0;   // :117-123, the owner's hv is the agent's cell
-        const int tot = clamp16(q.ret + reward);
-        if (!was_reset) s.ep_ret = tot;
-        if (own && q.done) { d_eps += 1; d_ret += tot; d_iou += q.iou_fx; }
-        const double val = el < K::W ? (double)hv : q.sc;
-        if (live) obs[(size_t)tp * tstride] = (OT)val;
-        const size_t prw = (size_t)tp * (size_t)a.n + (size_t)env;
-        if constexpr (STAGE) {
-            if (lane < 56 && el == 2) {                              // idle envs of a ragged tile stage values nobody writes out
-                const int slot = (tp & 31) * BE + wv * 8 + e;
-                srew[slot] = (float)reward;
-                sdone[slot] = q.done ? 1 : 0;
-            }
-        }
-        if (own) {
-            if constexpr (!STAGE) {
-                if (a.reward) a.reward[prw] = (float)reward;
-                if (a.done) a.done[prw] = q.done ? 1 : 0;
-            }
-            if (__builtin_expect(rec, 0)) {                          // snac_rollout_rec only
-                if (a.actions_out) a.actions_out[prw] = (int8_t)q.act;
-                if (a.step_size_out) a.step_size_out[prw] = (int8_t)q.k;
-                if (a.plan_idx_out) a.plan_idx_out[prw] = (int16_t)q.pidx;
-                if (a.first_out) a.first_out[prw] = q.first ? 1 : 0;
-            }
-        }
-        if constexpr (STAGE) {
-            if ((tp & 15) == 15 || tp == a.T - 1) flush_stage<WPB>(a, srew, sdone, tp, env0 - wv * 8, wv, lane);
-        }
-    };
-    // step t into `cur`; the previous step (`prev`) is finished on the way
-    auto tick = [&](int t, Open& cur, const Open& prev) {
-        const bool was_reset = a.auto_reset && prev.done && t > 0;
-        const bool nr = lane < 56 && e < nenv && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
-        if (__builtin_expect(__any(nr), 0)) {                        // rare: all 7 lanes of the env reset it together
-            if (nr) {
-                const int old_pidx = s.pidx, old_tb = s.tb;
-                episode += 1;
-                const int pidx = pick_plan<K>(a, pk, episode, old_pidx);
-                K::reset(a, s, pidx == old_pidx ? -1 : pidx);
-                if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
-                dtb = (double)s.tb; rtb = 1.0 / dtb;
-                for (int c = el; c < 30; c += 7) {
-                    hrow[2 + c] = 0;
-                    if (pidx != old_pidx) PL[e * 32 + c] = (int)((const int16_t*)a.plans)[(size_t)pidx * K::GE + c];
-                }
-            }
-        }
-        const uint32_t w = wnext;
-        const int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
-        const int pos0 = s.r;
-        const bool drop = act == 2;
-        cur.first = s.cs == 0;
-        s.cs = min(s.cs + 1, CNT_MAX);
-        if (drop) s.cb = min(s.cb + 1, CNT_MAX);
-        if (drop && own) __hip_atomic_fetch_add(hrow + pos0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_add: the brick
-        if (act == 0) s.r = max(pos0 - k, 2);                        // clip_position :57-64
-        if (act == 1) s.r = min(pos0 + k, 31);
-        const bool term = drop && s.cb >= s.tb + a.brick_gt;         // :107-114, before the time limit
-        const bool done = term || s.cs >= a.ts_done;
-        s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
-        // the next step's RNG word, asked for a whole step ahead (every 8th step all 64 lanes hash the next 8 words first)
-        if (((t + 1) & 7) == 0) wq = rng_word(sk, a.t0 + (uint32_t)(t + 1) + (uint32_t)(lane >> 3));
-        wnext = (uint32_t)__builtin_amdgcn_ds_bpermute((e + 8 * ((t + 1) & 7)) << 2, (int)wq);
-        // this step's LDS reads: the lane's window cell around the new position, the plan cell under the agent
-        cur.v = hrow[s.r - 2 + min(el, K::W - 1)];
-        cur.pl = prow[pos0 - 2];
-        {
-            const double c0 = (double)s.cb, c1 = (double)s.cs;
-            double v0 = c0, v1 = c1;
-            if (DYN) {
-                const double q0 = c0 * rtb, q1 = c1 * rT;
-                v0 = __builtin_fma(__builtin_fma(-q0, dtb, c0), rtb, q0);
-                v1 = __builtin_fma(__builtin_fma(-q1, dT, c1), rT, q1);
-                if (__builtin_expect(__any(live && s.tb <= 0), 0)) { // never in practice; the asm keeps it a branch (no if-conversion)
-                    asm volatile("" ::: "memory");
-                    v0 = c0 / dtb;
-                }
-            }
-            cur.sc = el == K::W ? v0 : v1;
-        }
-        cur.iou_fx = 0;
-        if (__builtin_expect(__any(own && done), 0)) {               // iou :138-151 of the finished episode, before the reset clears the row
-            if (own && done) {
-                int a1 = 0, a2 = 0, kk = 0;
-                for (int i = 0; i < 30; ++i) {
-                    const int g = min(hrow[2 + i], CNT_MAX), pp = prow[i];
-                    a1 += pp; a2 += g; kk += max(g - pp, 0);
-                }
-                const int cross = a2 - kk;
-                cur.iou_fx = __double2ll_rn(((double)cross / (double)(a1 + a2 - cross)) * FX40);
-            }
-        }
-        cur.drop = drop; cur.term = term; cur.done = done; cur.act = act; cur.k = k; cur.pidx = s.pidx;
-        if (t > 0) finish(prev, t - 1, was_reset);
-        cur.ret = s.ep_ret;                                          // the running return without this step's reward
-    };
-    for (int t = 0; t < a.T; t += 2) {                               // two steps per trip: the register sets alternate
-        tick(t, o[0], o[1]);
-        if (t + 1 < a.T) tick(t + 1, o[1], o[0]);
-    }
-    if ((a.T - 1) & 1) finish(o[1], a.T - 1, false);
-    else finish(o[0], a.T - 1, false);
-    {   // LDS -> records
-        int16_t* g16 = (int16_t*)a.grid;
-        for (int i = lane; i < nenv * K::GE; i += 64) {
-            const int ee = i >> 5, c = i & 31;
-            g16[(size_t)(env0 + ee) * K::GE + c] = c < 30 ? (int16_t)min(H[ee * 34 + 2 + c], CNT_MAX) : (int16_t)0;
-        }
-    }
-    if (own) {
-        a.hdr[env] = s.pack();
-        a.episode[env] = episode;
-        if (d_eps) {
-            a.stat_episodes[env] += d_eps;
-            a.stat_return[env] += d_ret;
-            a.stat_iou_fx[env] += d_iou;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // 1D fused rollout, TIME-parallel (round 3).  Every other rollout kernel walks the ticks one after the other and is, for 1D, bound
 // by that chain: BASELINE config 2 (N = 4096, T = 750) writes 187 MB -- 30 us of HBM time -- in 0.29 ms.  But in 1D
 // (DMP_Env_1D_static.py:85-136) the whole control of an episode depends on the ACTIONS alone: count_step counts ticks, count_brick
@@ -1492,15 +1281,27 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1d(const KArgs a) {
 // ~4 instructions per env-step instead of ~14, and nothing waits for the tick before.  The price: a lane writes its own 56-byte
 // row (rows of one env are N x 56 bytes apart); neighbouring envs' rows are neighbouring waves' stores and meet in L2.
 // Semantics are K1D::step's; counter-RNG or explicit inputs; SNAC_OBS_ALL / SNAC_OBS_TILED, the canonical layout.
-template <bool DYN, typename OT, int WPB, bool EXPL>
-__global__ __launch_bounds__(WPB * 64) void k_rollout1dt(const KArgs a) {
+// data-parallel primitives: lanes without a source (or outside ROWS) receive `idv`.  0x110 + n: row_shr n; 0x142 / 0x143: lane 15 / 31
+// of the rows before to the whole next row(s); 0x138: the wave shifted up by one lane
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ int dpp_from(int idv, int v) { return __builtin_amdgcn_update_dpp(idv, v, CTRL, ROWS, 0xf, false); }
+
+template <bool DYN, typename OT, int EB, bool EXPL>
+__global__ __launch_bounds__(EB * 64, 16 / EB) void k_rollout1dt(const KArgs a) {                // 16 waves per CU either way: <= 128 VGPRs
     using K = K1D<DYN, 8>;
     constexpr int D = K::D;
-    __shared__ int sH[WPB][32], sP[WPB][32];
-    __shared__ unsigned long long sM[WPB][32];
-    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
-    const int env = (int)blockIdx.x * WPB + wv;
-    if (env >= a.n) return;
+    constexpr int ROWB = D * (int)sizeof(OT);                        // 56 / 28 bytes per row
+    constexpr int TSTR = EB * ROWB + 16;                             // staging bytes per tick (+16: the lanes' row writes spread over the banks)
+    __shared__ int sH[EB][32], sP[EB][32];
+    __shared__ unsigned long long sM[EB][32];
+    __shared__ __align__(16) char stage[64 * TSTR];                  // [tick][env of the block][D]: what 64 ticks of the block's envs write
+    __shared__ float sR[64][EB + 1];
+    __shared__ __align__(16) uint8_t sD[64][EB];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int env0 = (int)blockIdx.x * EB;
+    const int nenv = min(EB, a.n - env0);                            // block-uniform; > 0 by the grid
+    const bool own = wv < nenv;                                      // waves past the batch only keep the barriers company
+    const int env = env0 + (own ? wv : 0);
     int* const H = sH[wv];                                           // heights of the 30 interior cells as the current segment found them
     int* const P = sP[wv];                                           // the env's plan
     unsigned long long* const M = sM[wv];                            // per cell: the lanes that dropped a brick on it in this segment
@@ -1516,14 +1317,23 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1dt(const KArgs a) {
     const EnvKeys sk = env_keys(a.key_step, gid), pk = env_keys(a.key_plan, gid);
     // wave-uniform env state (every lane holds the same values)
     int pos0 = s.r, cb0 = s.cb, cs0 = s.cs, ret0 = s.ep_ret, tb = s.tb, pidx = s.pidx;
+    asm volatile("" : "+v"(tb));                                     // the header has arrived HERE: no vector-memory wait inside the loop,
+                                                                     // where it would also wait for the chunk before's stores
+    double dtb = (double)tb, rtb = 1.0 / dtb;                        // once per episode (Roll3D, tests/native/recip_check.c)
     bool need_reset = a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
     bool flag_done = (s.flags & SNAC_FLAG_NEED_RESET) != 0;
     int d_eps = 0, d_ret = 0;
     long long d_iou = 0;
     const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);      // lanes <= this one
     const bool tl = a.obs_mode == SNAC_OBS_TILED;
+    const double dT = (double)a.total_step, rT = 1.0 / dT;
+    // the block's rows of one tick are one run of nenv x ROWB bytes; 16-byte pieces when every run starts and ends on 16 bytes
+    const size_t ostr = (tl ? (size_t)64 : (size_t)a.n) * ROWB;      // bytes from one tick's run to the next
+    const bool vec = ((((uintptr_t)a.obs) | (uintptr_t)ostr | (uintptr_t)((size_t)nenv * ROWB)) & 15) == 0;
+    const bool dvec = EB == 16 && a.done && nenv == EB && ((((uintptr_t)a.done) | (uintptr_t)a.n) & 15) == 0;
     for (int t0 = 0; t0 < a.T; t0 += 64) {
         const int nl = min(64, a.T - t0);
+        if (own) {
         const bool valid = lane < nl;
         const int t = t0 + lane;
         const size_t row = (size_t)t * (size_t)a.n + (size_t)env;
@@ -1540,6 +1350,8 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1dt(const KArgs a) {
                 const int np = pick_plan<K>(a, pk, episode, pidx);
                 if (np != pidx) {
                     pidx = np; tb = (int)a.plan_tb[np];
+                    asm volatile("" : "+v"(tb));
+                    dtb = (double)tb; rtb = 1.0 / dtb;
                     if (lane < 32) P[lane] = lane < 30 ? (int)((const int16_t*)a.plans)[(size_t)np * K::GE + lane] : 0;
                 }
                 if (lane < 32) H[lane] = 0;
@@ -1551,7 +1363,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1dt(const KArgs a) {
             // ---- counters and the segment's end
             const int cs = min(cs0 + (lane - first_lane + 1), CNT_MAX);
             const unsigned long long dropm = __ballot(drop);
-            const int cb = min(cb0 + __popcll(dropm & le), CNT_MAX);
+            const int cb = min(cb0 + (int)__popcll(dropm & le), CNT_MAX);
             const bool term = drop && cb >= tb + a.brick_gt;         // :107-114, before the time limit
             const bool done = seg && (term || cs >= a.ts_done);
             const unsigned long long donem = __ballot(done);
@@ -1560,16 +1372,20 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1dt(const KArgs a) {
             // ---- positions: inclusive scan of x -> min(max(x + d, 2), 31)
             int sa = 0, slo = -4096, shi = 4096;
             if (in) { sa = act == 0 ? -k : (act == 1 ? k : 0); slo = 2; shi = 31; }
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const int pa = __shfl_up(sa, dd), plo = __shfl_up(slo, dd), phi = __shfl_up(shi, dd);
-                if (lane >= dd) {                                    // the earlier ticks first, then this lane's function
-                    const int nlo = min(max(plo + sa, slo), shi), nhi = min(max(phi + sa, slo), shi);
-                    sa += pa; slo = nlo; shi = nhi;
-                }
-            }
+            // Hillis-Steele inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then the rows' last lanes to the rows behind them; a
+            // lane without a source composes with the identity (0, -4096, 4096), so no step is conditional
+            auto compose = [&](int pa, int plo, int phi) {               // the earlier ticks first, then this lane's function
+                const int nlo = min(max(plo + sa, slo), shi), nhi = min(max(phi + sa, slo), shi);
+                sa += pa; slo = nlo; shi = nhi;
+            };
+            compose(dpp_from<0x111>(0, sa), dpp_from<0x111>(-4096, slo), dpp_from<0x111>(4096, shi));
+            compose(dpp_from<0x112>(0, sa), dpp_from<0x112>(-4096, slo), dpp_from<0x112>(4096, shi));
+            compose(dpp_from<0x114>(0, sa), dpp_from<0x114>(-4096, slo), dpp_from<0x114>(4096, shi));
+            compose(dpp_from<0x118>(0, sa), dpp_from<0x118>(-4096, slo), dpp_from<0x118>(4096, shi));
+            compose(dpp_from<0x142, 0xa>(0, sa), dpp_from<0x142, 0xa>(-4096, slo), dpp_from<0x142, 0xa>(4096, shi));
+            compose(dpp_from<0x143, 0xc>(0, sa), dpp_from<0x143, 0xc>(-4096, slo), dpp_from<0x143, 0xc>(4096, shi));
             const int pos = min(max(pos0 + sa, slo), shi);           // after the tick
-            const int prev = __shfl_up(pos, 1);
+            const int prev = dpp_from<0x138>(pos0, pos);
             const int posb = lane == first_lane ? pos0 : prev;       // before the tick: where a drop lands
             // ---- the drops as per-cell lane masks
             if (lane < 32) M[lane] = 0ull;
@@ -1580,7 +1396,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1dt(const KArgs a) {
             for (int i = 0; i < K::W; ++i) {
                 const int ci = pos - 4 + i;                          // interior cell index: -2 .. 31
                 const int cc = min(max(ci, 0), 31);
-                const int h = min(H[cc] + __popcll(M[cc] & le), CNT_MAX);
+                const int h = min(H[cc] + (int)__popcll(M[cc] & le), CNT_MAX);
                 win[i] = (ci < 0 || ci > 29) ? -1 : h;
             }
             const int hnew = win[2];                                 // a drop does not move: the agent's cell after the brick
@@ -1589,28 +1405,34 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1dt(const KArgs a) {
             // running return: rewards are -1 / 1 / 10, three ballots
             const unsigned long long inm = __ballot(in);
             const unsigned long long r10 = __ballot(in && reward == 10), r1 = __ballot(in && reward == 1), rm = __ballot(in && reward == -1);
-            const int ret = clamp16(ret0 + 10 * __popcll(r10 & le) + __popcll(r1 & le) - __popcll(rm & le));
-            // ---- outputs of the segment's lanes
+            const int ret = clamp16(ret0 + 10 * (int)__popcll(r10 & le) + (int)__popcll(r1 & le) - (int)__popcll(rm & le));
+            // ---- outputs of the segment's lanes: into the block's staging tile
             if (in) {
                 const double c0 = (double)cb, c1 = (double)cs;
-                const double v0 = DYN ? c0 / (double)tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
-                const size_t orow = tl ? ((size_t)(env >> 6) * (size_t)a.tiled_T + (size_t)(a.tiled_t0 + t)) * 64 + (size_t)(env & 63) : row;
-                OT* const o = (OT*)a.obs + orow * D;
+                double v0 = c0, v1 = c1;
+                if (DYN) {                                           // cb / tb, cs / T: correctly rounded (Roll3D, tests/native/recip_check.c)
+                    const double q0 = c0 * rtb, q1 = c1 * rT;
+                    v0 = tb > 0 ? __builtin_fma(__builtin_fma(-q0, dtb, c0), rtb, q0) : c0 / dtb;
+                    v1 = __builtin_fma(__builtin_fma(-q1, dT, c1), rT, q1);
+                }
+                OT* const o = (OT*)(stage + lane * TSTR + wv * ROWB);
 #pragma unroll
                 for (int i = 0; i < K::W; ++i) o[i] = (OT)(double)win[i];
                 o[K::W] = (OT)v0; o[K::W + 1] = (OT)v1;
-                if (a.reward) a.reward[row] = (float)reward;
-                if (a.done) a.done[row] = (lane == last && donem) ? 1 : 0;
+                sR[lane][wv] = (float)reward;
+                sD[lane][wv] = (lane == last && donem) ? 1 : 0;
                 if (a.actions_out) a.actions_out[row] = (int8_t)act;
                 if (a.step_size_out) a.step_size_out[row] = (int8_t)k;
                 if (a.plan_idx_out) a.plan_idx_out[row] = (int16_t)pidx;
                 if (a.first_out) a.first_out[row] = cs == 1 ? 1 : 0;
             }
             // ---- the segment's end: the cells take their bricks, the uniform state moves on
-            if (lane < 32) H[lane] = min(H[lane] + __popcll(M[lane] & inm), CNT_MAX);
-            pos0 = __shfl(pos, last); cb0 = __shfl(cb, last); cs0 = __shfl(cs, last); ret0 = __shfl(ret, last);
+            if (lane < 32) H[lane] = min(H[lane] + (int)__popcll(M[lane] & inm), CNT_MAX);
+            pos0 = __builtin_amdgcn_readlane(pos, last); cb0 = __builtin_amdgcn_readlane(cb, last);     // `last` is uniform
+            cs0 = __builtin_amdgcn_readlane(cs, last); ret0 = __builtin_amdgcn_readlane(ret, last);
             flag_done = donem != 0ull;
             if (donem) {                                             // iou :138-151 of the finished episode, episodic sums
+                asm volatile("" ::: "memory");                       // once per episode: stays a branch (18 cross-lane steps otherwise run every segment)
                 int g = lane < 30 ? H[lane] : 0, pp = lane < 30 ? P[lane] : 0, over = max(g - pp, 0);
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) { g += __shfl_xor(g, off); pp += __shfl_xor(pp, off); over += __shfl_xor(over, off); }
@@ -1621,8 +1443,47 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1dt(const KArgs a) {
             }
             first_lane = last + 1;
         }
+        }
+        __syncthreads();
+        // ---- the tile leaves: per tick one run of the block's rows, the threads of the block across the runs
+        {
+            int t0v = t0, wq = wv, lq = lane;
+            asm volatile("" : "+s"(t0v), "+v"(wq), "+v"(lq));        // addresses from scratch every chunk: a dozen running 64-bit pointers
+                                                                     // and offsets kept across the loop cost more registers than there are
+            const size_t row0 = tl ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)(a.tiled_t0 + t0v)) * 64 + (size_t)(env0 & 63)
+                                   : (size_t)t0v * (size_t)a.n + (size_t)env0;
+            char* const ob = (char*)a.obs + row0 * ROWB;
+            constexpr int TPW = 64 / EB;                             // ticks per wave
+            if (vec) {
+                // 16-byte pieces: a tick's run has pt <= LPT of them, LPT lanes per tick, 64 / LPT ticks per store instruction
+                constexpr int PTMAX = EB * ROWB / 16, LPT = PTMAX > 32 ? 64 : (PTMAX > 16 ? 32 : (PTMAX > 8 ? 16 : 8)), TPI = 64 / LPT;
+                const int pt = nenv * ROWB / 16, pc = lq & (LPT - 1);
+#pragma unroll
+                for (int i = 0; i < TPW / TPI; ++i) {
+                    const int tk = wq * TPW + i * TPI + lq / LPT;
+                    if (pc < pt && tk < nl) *(uint4*)(ob + (size_t)tk * ostr + pc * 16) = *(const uint4*)(stage + tk * TSTR + pc * 16);
+                }
+            } else {
+                const int pe = nenv * D;                             // ragged or unaligned: element by element, still in runs
+                for (int i = 0; i < TPW; ++i) {
+                    const int tk = wq * TPW + i;
+                    if (tk < nl)
+                        for (int el = lq; el < pe; el += 64) ((OT*)(ob + (size_t)tk * ostr))[el] = ((const OT*)(stage + tk * TSTR))[el];
+                }
+            }
+            // reward / done: 64 / EB ticks x EB envs per wave, one instruction each
+            const size_t r0 = (size_t)t0v * (size_t)a.n + (size_t)env0;
+            const int tk = wq * TPW + lq / EB, e = lq & (EB - 1);
+            const bool mine = tk < nl && e < nenv;
+            if (a.reward && mine) a.reward[r0 + (size_t)tk * (size_t)a.n + e] = sR[tk][e];
+            if (dvec) {
+                if (tid < nl) *(uint4*)(a.done + r0 + (size_t)tid * (size_t)a.n) = *(const uint4*)sD[tid];
+            } else if (a.done && mine) a.done[r0 + (size_t)tk * (size_t)a.n + e] = sD[tk][e];
+        }
+        __syncthreads();
     }
     // ---- the env's record
+    if (!own) return;
     if (lane < 32) ((int16_t*)a.grid)[(size_t)env * K::GE + lane] = lane < 30 ? (int16_t)H[lane] : (int16_t)0;
     if (lane == 0) {
         s.r = pos0; s.c = 0; s.cb = cb0; s.cs = cs0; s.ep_ret = ret0; s.tb = tb; s.pidx = pidx; s.cross = 0;
@@ -2862,39 +2723,32 @@ void launch_roll2d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     else f32 ? launch_roll2d_w<false, float>(a, s) : launch_roll2d_w<false, double>(a, s);
 }
 
-template <bool DYN, typename OT, int WPB>
-void launch_roll1d_w(const KArgs& a, hipStream_t s) {
-    const int tiles = (a.n + 7) / 8, blocks = (tiles + WPB - 1) / WPB;
-    const dim3 grid((unsigned)(((blocks + 7) / 8) * 8)), block(WPB * 64);   // a multiple of 8: the XCD remap covers every tile
-    hipLaunchKernelGGL((k_rollout1d<DYN, OT, WPB>), grid, block, 0, s, a);
-}
-// time-parallel 1D rollouts (one wave per env, lane = tick); SNAC_1D_TP=0 keeps the tick-by-tick kernels (A/B timing)
-bool roll1dt_ok(const KArgs& a) {
+// time-parallel 1D rollouts (one wave per env, lane = tick).  Its rate levels off at 6-7e10 env-steps/s (instruction issue: ~9 per
+// env-step), the tile kernel's keeps growing with the batch: float64 rows 49 152 envs 0.54 against 0.68 ms per 750 ticks, 65 536
+// 0.72-0.87 against 0.72; float32 rows 65 536 envs 0.65 against 0.73, 131 072 1.35 against 0.94 (profiles/r03_1d_time_parallel.txt).
+// SNAC_1D_TP=0 keeps every 1D rollout on the tile kernel (A/B timing)
+bool roll1dt_ok(const KArgs& a, bool f32) {
     static const bool off = [] { const char* e = std::getenv("SNAC_1D_TP"); return e && e[0] == '0'; }();
-    static const int nmax = [] { const char* e = std::getenv("SNAC_1D_TP_MAX"); return e ? std::atoi(e) : 8192; }();   // (tuning)
-    return !off && a.n <= nmax && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && !pipeline_off();
+    static const int nmax = [] { const char* e = std::getenv("SNAC_1D_TP_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
+    const int lim = nmax ? nmax : (f32 ? 65536 : 49152);
+    return !off && a.n <= lim && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && !pipeline_off();
+}
+template <bool DYN, typename OT, int EB>
+void launch_roll1dt_e(const KArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)((a.n + EB - 1) / EB)), block(EB * 64);
+    if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout1dt<DYN, OT, EB, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_rollout1dt<DYN, OT, EB, false>), grid, block, 0, s, a);
 }
 template <bool DYN, typename OT>
 void launch_roll1dt_w(const KArgs& a, hipStream_t s) {
-    const dim3 grid((unsigned)((a.n + 3) / 4)), block(256);
-    if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, false>), grid, block, 0, s, a);
+    static const int emin = [] { const char* e = std::getenv("SNAC_1D_TP_EB16"); return e ? std::atoi(e) : 2048; }();   // (tuning)
+    if (a.n >= emin) launch_roll1dt_e<DYN, OT, 16>(a, s);      // 16 envs per block: runs of 896 / 448 bytes per tick
+    else launch_roll1dt_e<DYN, OT, 4>(a, s);                        // small batches: more blocks than CUs first
 }
 void launch_roll1dt(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
     if (dyn) f32 ? launch_roll1dt_w<true, float>(a, s) : launch_roll1dt_w<true, double>(a, s);
     else f32 ? launch_roll1dt_w<false, float>(a, s) : launch_roll1dt_w<false, double>(a, s);
-}
-
-void launch_roll1d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
-    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
-    if (a.n < 8192) {   // one-wave blocks reach every CU with small batches
-        if (dyn) f32 ? launch_roll1d_w<true, float, 1>(a, s) : launch_roll1d_w<true, double, 1>(a, s);
-        else f32 ? launch_roll1d_w<false, float, 1>(a, s) : launch_roll1d_w<false, double, 1>(a, s);
-    } else {            // 64 envs per block: reward / done leave as whole 256-byte / 64-byte runs
-        if (dyn) f32 ? launch_roll1d_w<true, float, 8>(a, s) : launch_roll1d_w<true, double, 8>(a, s);
-        else f32 ? launch_roll1d_w<false, float, 8>(a, s) : launch_roll1d_w<false, double, 8>(a, s);
-    }
 }
 
 // SNAC_STEP_STAGE=0 keeps snac_step on k_transition2d / k_transition3d (A/B timing, tests of both paths)
@@ -2962,10 +2816,8 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     const int E = pick_tile(d->kind, a.n);
     switch (d->kind) {
         case SNAC_ENV_1D:
-            // up to two waves per SIMD (N <= 16 384) a 1D pass is bound by its dependency chain: the chain-shaped kernel; beyond,
-            // by instruction issue: the tile kernel (lane-per-env transition) needs fewer instructions per env-step
-            if (op == OP_ROLLOUT && roll1dt_ok(a)) { launch_roll1dt(d, a, s); break; }
-            if (op == OP_ROLLOUT && a.n <= 16384 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && !a.actions && !a.step_size && !pipeline_off()) { launch_roll1d(d, a, s); break; }
+            // rollouts that write every row: the time-parallel kernel while its rate beats the tile kernel's (lane-per-env transition)
+            if (op == OP_ROLLOUT && roll1dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { launch_roll1dt(d, a, s); break; }
             launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D:
             if (op == OP_TRANSITION && !a.variant && !pipeline_off() && step_stage_ok(a)) { launch_step_tile<2>(d, a, s); break; }

@@ -1,7 +1,9 @@
-"""GPU: the chain-shaped 1D rollout kernel (k_rollout1d: counter RNG, every observation written, N <= 16 384) against the
-CPU oracle -- one-wave blocks and 64-env blocks, ragged tiles and blocks with idle waves, odd / tiny tick counts (the two
-register sets alternate per step), episodes that end by count_brick and by the time limit, the `>` rule bits, float32
-observations, the per-step record outputs, and equality with the generic tile kernel (explicit inputs take that one)."""
+"""GPU: 1D rollouts against the CPU oracle.  Rollouts that write every row run on the time-parallel kernel (k_rollout1dt, round 3:
+one wavefront per env, lane = tick, blocks of 4 or 16 envs whose rows leave through an LDS staging tile as whole runs per tick) up
+to 49 152 envs (float32 rows: 65 536), on the tile kernel beyond: batches on either side of every switch, ragged blocks and blocks
+with idle waves, rows that can and cannot leave as 16-byte pieces (odd N, unaligned outputs), canonical and tile-major layouts,
+odd / tiny tick counts, episodes that end by count_brick and by the time limit (several per chunk of 64 ticks), the `>` rule
+bits, float32 observations, the per-step record outputs and explicit inputs."""
 import numpy as np
 import pytest
 
@@ -51,10 +53,11 @@ def _end_state(env, orc):
 
 
 @pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
-@pytest.mark.parametrize("n", [1, 13, 4100, 8200, 16384])
+@pytest.mark.parametrize("n", [1, 13, 2047, 2049, 4100, 8200, 16384])
 def test_batch_shapes_and_tick_counts(dyn, n):
-    """n = 1 / 13: a lone ragged tile; 4100: one-wave blocks, last tile ragged; 8200: 64-env blocks, the last block holds one
-    full tile and seven waves without envs; 16 384: the largest batch the kernel takes.  Launches of 1, 2, 37 and 80 steps."""
+    """n = 1 / 13 / 2047: blocks of 4 envs, the last one ragged, odd N (rows leave element by element); 2049: blocks of 16, the last
+    holds one env and fifteen idle waves; 4100 / 8200: a last block of 4 / 8 envs; 16 384: full blocks only.  Launches of 1, 2, 37
+    and 80 steps."""
     env, orc = _pair(dyn, n, seed=5, total_step=60)
     t0 = 0
     for T in (1, 2, 37, 80):
@@ -83,17 +86,21 @@ def test_float32_observations():
     _compare(env, orc, 33, 750, f32=True)
 
 
-@pytest.mark.parametrize("n", [40, 9000])
-def test_record_outputs_and_the_tile_kernel_agree(n):
+@pytest.mark.parametrize("n", [40, 9000, 50000])
+def test_record_outputs_fed_back_as_explicit_inputs(n):
     """The record outputs (action taken, step size used, plan row, first-step flag) of a counter-RNG rollout, fed back as
-    explicit inputs -- which the generic tile kernel handles -- must reproduce observations, rewards and done flags."""
+    explicit inputs (the time-parallel kernel's prefetch-free EXPL variant; the tile kernel at n = 50 000), must reproduce
+    observations, rewards and done flags -- which equal the oracle's."""
     import torch
     from snac_amd import BatchedDMPEnv
 
-    _, full = _tables(True)
+    table, full = _tables(True)
     T = 130
     a = BatchedDMPEnv(1, True, n, plans=full, seed=21, total_step=50)
     b = BatchedDMPEnv(1, True, n, plans=full, seed=21, total_step=50)
+    orc = helpers.oracle().OracleBatch(1, True, n, table, seed=21, env_id_base=0)
+    orc.set_total_step(50)
+    orc.reset()
     a.reset()
     b.reset()
     rec = {"actions": torch.empty((T, n), dtype=torch.int8, device="cuda"), "step_size": torch.empty((T, n), dtype=torch.int8, device="cuda"),
@@ -101,6 +108,9 @@ def test_record_outputs_and_the_tile_kernel_agree(n):
     oa, ra, da = a.rollout(T, record=rec)
     ob, rb, db = b.rollout(T, actions=rec["actions"], step_size=rec["step_size"])
     assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    oc, rc, dc = orc.rollout(T, t0=0, nthreads=8)
+    assert oa.cpu().numpy().tobytes() == oc.tobytes() and ra.cpu().numpy().tobytes() == rc.tobytes()
+    assert np.array_equal(da.cpu().numpy().view(np.uint8), dc)
     first = rec["first"].cpu().numpy()
     done = da.cpu().numpy()
     assert first[0].all() and np.array_equal(first[1:], done[:-1].astype(np.uint8))   # auto-reset: a step opens an episode iff the last one ended one
@@ -110,7 +120,7 @@ def test_record_outputs_and_the_tile_kernel_agree(n):
 @pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
 @pytest.mark.parametrize("total_step,time_gt", [(1, False), (5, False), (7, True), (63, False), (64, False), (65, True)])
 def test_time_parallel_kernel_segments_inside_a_chunk(dyn, total_step, time_gt):
-    """Round 3: up to 8192 envs a 1D rollout runs on k_rollout1dt -- one wavefront per env, lane = tick, 64 ticks per chunk.  An
+    """k_rollout1dt: one wavefront per env, lane = tick, 64 ticks per chunk.  An
     episode that ends inside a chunk splits it into segments (the reset happens in the wave's uniform state): time limits of 1
     (every lane its own episode), 5 and 7 (a dozen segments per chunk), and 63 / 64 / 65 (ends on, just before and just behind the
     chunk border); launches of 1, 64, 65 and 200 ticks; both dtypes; explicit inputs on the last launch."""
@@ -130,3 +140,30 @@ def test_time_parallel_kernel_segments_inside_a_chunk(dyn, total_step, time_gt):
         assert og.cpu().numpy().tobytes() == (oc.astype(np.float32) if f32 else oc).tobytes()
         assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
         _end_state(env, orc)
+
+
+@pytest.mark.parametrize("n,f32", [(2050, False), (2051, False), (4100, True), (4102, True), (49152, False), (49168, False), (65536, True), (65552, True)])
+def test_staged_rows_alignments_layouts_and_the_switch_to_the_tile_kernel(n, f32):
+    """Rows of a block leave as 16-byte pieces when every run of a tick starts and ends on 16 bytes (float64: even N; float32:
+    N % 4 = 0) and element by element otherwise -- also when the output itself is not 16-byte aligned; tile-major outputs hold the
+    same rows at [env // 64, t, env % 64].  49 152 / 65 536 are the largest batches of the time-parallel kernel (float64 / float32
+    rows), 16 envs more run on the tile kernel: the same rows either way."""
+    import torch
+
+    dt = torch.float32 if f32 else torch.float64
+    T = 70
+    env, orc = _pair(True, n, seed=3, total_step=40, obs_dtype=dt)
+    twin = env.fork(torch.arange(n, device=env.device))
+    third = env.fork(torch.arange(n, device=env.device))
+    oc, rc, dc = orc.rollout(T, t0=0, nthreads=16)
+    want = (oc.astype(np.float32) if f32 else oc).tobytes()
+    og, rg, dg = env.rollout(T)
+    assert og.cpu().numpy().tobytes() == want and rg.cpu().numpy().tobytes() == rc.tobytes()
+    assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+    ot, rt, dtt = twin.rollout(T, obs="tiled")
+    assert twin.untile(ot).cpu().numpy().tobytes() == want and torch.equal(rt, rg) and torch.equal(dtt, dg)
+    raw = torch.empty(T * n * 7 + 1, dtype=dt, device=env.device)
+    ou, ru, du = third.rollout(T, out=raw[1:].view(T, n, 7))
+    assert ou.data_ptr() % 16 != 0 and ou.cpu().numpy().tobytes() == want and torch.equal(ru, rg) and torch.equal(du, dg)
+    _end_state(env, orc)
+    assert torch.equal(env._hdr, twin._hdr) and torch.equal(env._hdr, third._hdr) and torch.equal(env._grid, third._grid)
