@@ -1,0 +1,154 @@
+"""GPU: the block-cooperative 3D rollout kernel (k_rollout3db, round 3: 64 envs per block, one stepper wave with an env per lane,
+eight writer waves that own the height maps, one barrier per tick, the stepper's reads patched for the tick they lag) against the
+CPU oracle.  The kernel takes 3D rollouts of N >= 8192 envs (N % 4 = 0, 16-byte aligned output) that write every observation: full
+blocks and a ragged last block (down to one writer wave with 4 envs), float64 and float32 rows, static and dataset plans,
+[T][N][D] and tile-major outputs, launches of 1 / 2 / 37 steps, explicit actions / step sizes, the `>` rule bits, time limits of
+1 .. 3 (an env starts over every tick: the stepper then reads no map at all for it, or a map that is a tick behind), the record
+outputs -- and, bit for bit, the rows k_rollout3d writes for the same batch (forced by an unaligned output)."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+N0 = 8192
+
+
+def _pair(dyn, n, seed, tag=None, total_step=None, obs_dtype=None, brick_gt=False, time_gt=False, base=0):
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(3, dyn, tag or ("dense_train" if dyn else "p1"))
+    env = BatchedDMPEnv(3, dyn, n, plans=table.reshape(len(table), 26, 26), seed=seed, env_id_base=base, total_step=total_step,
+                        obs_dtype=obs_dtype or torch.float64, brick_gt=brick_gt, time_gt=time_gt)
+    orc = helpers.oracle().OracleBatch(3, dyn, n, table, seed=seed, env_id_base=base)
+    if total_step:
+        orc.set_total_step(total_step)
+    orc.set_rules(brick_gt, time_gt)
+    o = orc.reset()
+    assert env.reset().cpu().numpy().tobytes() == (o.astype(np.float32) if obs_dtype == torch.float32 else o).tobytes()
+    return env, orc
+
+
+def _compare(env, orc, T, t0, f32=False, actions=None, step_size=None):
+    import torch
+
+    a = None if actions is None else torch.from_numpy(actions).to(env.device)
+    k = None if step_size is None else torch.from_numpy(step_size).to(env.device)
+    og, rg, dg = env.rollout(T, actions=a, step_size=k)
+    oc, rc, dc = orc.rollout(T, t0=t0, actions=actions, step_size=step_size, nthreads=16)
+    want = oc.astype(np.float32) if f32 else oc
+    assert og.cpu().numpy().tobytes() == want.tobytes(), "observations"
+    assert rg.cpu().numpy().tobytes() == rc.tobytes(), "rewards"
+    assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc), "done flags"
+
+
+def _end_state(env, orc):
+    s, e = orc.stats(), env.episodic_stats()
+    assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
+    assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+    st = orc.state()
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(env.num_envs, -1), st["grid"].astype(np.float64))
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
+@pytest.mark.parametrize("n", [N0, N0 + 36, N0 + 64 + 4])
+def test_blocks_dtypes_and_launch_lengths(dyn, n, f32):
+    """n = 8192: full blocks only; + 36: a last block of 36 envs (four full writer waves, one with 4 envs, three idle); + 68: a last
+    block of 4 envs.  Launches of 1, 2 and 37 steps; random 3D agents box themselves in every ~22 steps, so every launch of 37 has
+    envs that start over, some of them twice."""
+    import torch
+
+    env, orc = _pair(dyn, n, seed=5, obs_dtype=torch.float32 if f32 else None, base=11)
+    t0 = 0
+    for T in (1, 2, 37):
+        _compare(env, orc, T, t0, f32)
+        t0 += T
+    _end_state(env, orc)
+    _compare(env, orc, 3, t0, f32)                                # the records written back by the launches above carry on
+
+
+@pytest.mark.parametrize("total_step,time_gt", [(1, False), (1, True), (2, False), (3, False)])
+def test_envs_that_start_over_every_tick(total_step, time_gt):
+    """A time limit of 1: every env starts over at every tick, so the stepper never reads a map (cells by coordinates only) and the
+    writers clear every map every tick; 2 (or 1 with the `>` rule): an env's second step reads a map that may not be cleared yet
+    and carries the cell of its first step only as a patch; 3: the third step is the first to read its own episode's map."""
+    n = N0 + 36
+    env, orc = _pair(True, n, seed=9, total_step=total_step, time_gt=time_gt)
+    rng = np.random.default_rng(total_step)
+    acts = rng.choice(np.arange(8, dtype=np.int8), size=(24, n), p=[0.05, 0.05, 0.05, 0.05, 0.2, 0.2, 0.2, 0.2])   # builds mostly
+    _compare(env, orc, 24, 0, actions=acts)
+    _compare(env, orc, 25, 24)
+    _end_state(env, orc)
+
+
+@pytest.mark.parametrize("rules", [(False, False), (True, False), (False, True), (True, True)], ids=str)
+def test_episodes_end_by_bricks_boxed_in_and_by_time(rules):
+    """Sparse plans and build-heavy explicit actions: episodes end at count_brick >= (>) total_brick, boxed in (-100) and by the
+    time limit 45 (> with the rule bit)."""
+    n, T = N0 + 36, 120
+    env, orc = _pair(True, n, seed=9, tag="sparse_train", total_step=45, brick_gt=rules[0], time_gt=rules[1])
+    rng = np.random.default_rng(3)
+    acts = rng.choice(np.arange(8, dtype=np.int8), size=(T, n), p=[0.1, 0.1, 0.1, 0.1, 0.15, 0.15, 0.15, 0.15])
+    _compare(env, orc, T, 0, actions=acts)                        # explicit actions, counter-RNG step sizes
+    _end_state(env, orc)
+    assert env.episodic_stats()["episodes"] > 2 * n
+
+
+def test_explicit_inputs_loaded_two_ticks_ahead():
+    """actions only, step sizes only, both; out-of-range step sizes are clamped into {1, 2, 3}; launches of one and two steps have
+    nothing (or one tick) to prefetch."""
+    n = N0 + 36
+    env, orc = _pair(True, n, seed=2, total_step=50)
+    rng = np.random.default_rng(7)
+    t0 = 0
+    for T, use_a, use_k in ((1, True, True), (2, True, True), (23, True, False), (23, False, True), (40, True, True)):
+        acts = rng.integers(0, 8, size=(T, n)).astype(np.int8) if use_a else None
+        ks = rng.integers(0, 6, size=(T, n)).astype(np.int8) if use_k else None
+        orc_k = None if ks is None else np.clip(ks, 1, 3)
+        og, rg, dg = env.rollout(T, actions=acts, step_size=ks)
+        oc, rc, dc = orc.rollout(T, t0=t0, actions=acts, step_size=orc_k, nthreads=16)
+        assert og.cpu().numpy().tobytes() == oc.tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes()
+        assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+        t0 += T
+    _end_state(env, orc)
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+def test_tile_major_output_record_and_the_eight_env_kernel(f32):
+    """rollout(obs="tiled") holds the same rows at [env // 64, t, env % 64]; the record outputs (action, step size, plan row,
+    first-step flag), the rows and the final records equal what k_rollout3d (8 envs per wave) gives for an identical batch -- which
+    an output that is not 16-byte aligned selects."""
+    import torch
+
+    n, T = N0 + 36, 33
+    dt = torch.float32 if f32 else torch.float64
+    a, orc = _pair(True, n, seed=4, total_step=20, obs_dtype=dt)
+    b = a.fork(torch.arange(n, device=a.device))
+    kinds = {"actions": torch.int8, "step_size": torch.int8, "plan_idx": torch.int16, "first": torch.uint8}
+    ra = {k: torch.empty((T, n), dtype=v, device=a.device) for k, v in kinds.items()}
+    rb = {k: torch.empty((T, n), dtype=v, device=a.device) for k, v in kinds.items()}
+    ot, rt, dtt = a.rollout(T, obs="tiled", record=ra)
+    raw = torch.empty(T * n * 51 + 1, dtype=dt, device=a.device)
+    ob, rwb, db = b.rollout(T, out=raw[1:].view(T, n, 51), record=rb)
+    assert ob.data_ptr() % 16 != 0
+    assert torch.equal(a.untile(ot), ob) and torch.equal(rt, rwb) and torch.equal(dtt, db)
+    for k in kinds:
+        assert torch.equal(ra[k], rb[k]), k
+    oc, rc, dc = orc.rollout(T, t0=0, nthreads=16)
+    assert ob.cpu().numpy().tobytes() == (oc.astype(np.float32) if f32 else oc).tobytes()
+    assert torch.equal(a._hdr, b._hdr) and torch.equal(a._grid, b._grid) and torch.equal(a._stats, b._stats) and torch.equal(a._episode, b._episode)
+
+
+def test_a_pending_reset_carried_into_the_next_launch():
+    """A launch that ends on a done step leaves the flag in the header: the next launch starts the env over at its first tick (the
+    stepper applies the scalars before the loop, the writers clear the map at tick 0)."""
+    n = N0
+    env, orc = _pair(True, n, seed=6, total_step=5)
+    t0 = 0
+    for T in (5, 1, 4, 5, 7):                                     # launches that end exactly on the time limit, and ones that do not
+        _compare(env, orc, T, t0)
+        t0 += T
+    _end_state(env, orc)
