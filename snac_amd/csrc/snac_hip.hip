@@ -1274,20 +1274,22 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout3d(const KArgs a) {
 //       early) -- waits for loads only.  It never WRITES a map either;
 //   waves 1-8, the writers (8 envs each, lane = (env, window row 0 .. 6 or the two scalar slots)) own the maps of their envs: behind
 //       the tick's barrier they bring them up to date (the map of an env that started over is cleared, the built cell written),
-//       gather the 7x7 window round the published position, convert, put the wave's 8 rows into its slice of the staging tile and
-//       write that slice as one run of 8 x 408 bytes, 16 bytes per lane (a wave's own LDS operations are ordered: no further
-//       barrier); the tick's reward / done runs; IoU and sums of episodes that ended.
+//       gather the 7x7 window round the published position into the wave's slice of a staging tile of int16 cells (one aligned
+//       16-byte write per lane and window row), read it back in store order, convert on the way out and write the 8 rows as one run
+//       of 8 x 408 bytes, 16 bytes per lane (a wave's own LDS operations are ordered: no further barrier); the tick's reward / done
+//       runs; IoU and sums of episodes that ended.
 // ONE barrier per tick: the stepper computes tick t + 1 while the writers apply, gather and write tick t.  So the maps the stepper
 // reads lag by one tick: it patches the cell it built a tick ago into what it reads, and takes the cells of an env that started
 // over (now, or a tick ago: its map may not be cleared yet) from their coordinates -- an empty map is 0 inside, -1 on the frame.
 // What a writer applies at tick t was published before barrier t; the stepper reads the maps for tick t + 2 behind barrier t + 1,
-// which the writers reach after they are done with tick t.  tick = max(stepper, slowest writer) + one barrier: 2540 cycles at
-// N = 16 384 (stepper 1940 -- 1000 when it runs alone --, barrier 460), 1.08 ms per 1000 ticks against 1.27 for k_rollout3d;
-// what was tried on the way (two barriers with the stepper writing the maps, four writers of 16 envs, a scratch-spilled flush, idle
-// waves on the stepper's SIMD, wave priorities) is in profiles/r03_3d_block_kernel.txt.
+// which the writers reach after they are done with tick t.  tick = max(stepper, slowest writer) + one barrier: ~2500 cycles at
+// N = 16 384 (stepper 1940 -- 1000 when it runs alone --, barrier 460), 1.06 ms per 1000 ticks against 1.27 for k_rollout3d
+// (float32 rows 0.98 against 1.25); what was tried on the way (two barriers with the stepper writing the maps, four writers of
+// 16 envs, a scratch-spilled flush, idle waves on the stepper's SIMD, wave priorities, the staging tile as float64 / misaligned
+// int16 / none) is in profiles/r03_3d_block_kernel.txt.
 // Semantics are K3D::step's, formulated as in k_step3d / Roll3D::tick.  Conditions: every row written (SNAC_OBS_ALL /
 // SNAC_OBS_TILED), canonical layout, <= TB_MAX plans, N % 4 = 0 and a 16-byte aligned output, N >= 8192 (below, k_rollout3d's
-// one-wave blocks are faster: 4096 envs 1.02 against 1.06 ms); the rest stays on k_rollout3d.
+// one-wave blocks are faster: 4096 envs 1.02 against 1.04 ms); the rest stays on k_rollout3d.
 
 // A barrier between waves that exchange data through LDS only (no wait for the writers' global stores).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -1295,9 +1297,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <bool DYN, typename OT, bool EXPL>
 __global__ __launch_bounds__(576) void k_rollout3db(const KArgs a) {
     using K = K3D<DYN, 64>;
-    constexpr int D = K::D, ROWB = D * (int)sizeof(OT), TILEB = 64 * ROWB, GE = K::GE, NT = 576;
+    constexpr int D = K::D, ROWB = D * (int)sizeof(OT), GE = K::GE, NT = 576;
     __shared__ __attribute__((aligned(16))) uint32_t hm[64 * K::ES / 2];      // 64 bordered height maps, 1356 bytes apart (odd dword stride)
-    __shared__ __attribute__((aligned(16))) char stg[TILEB];
+    __shared__ __attribute__((aligned(16))) int16_t stg16[64 * 56];           // the tick's 64 windows as int16 cells: [env][window row][8], a row = one 16-byte write
     __shared__ double rtab[TB_MAX];                                  // 1 / total_brick per plan row: no division in the stepper
     __shared__ int16_t tbtab[TB_MAX];
     __shared__ double ssc[2][64][2];
@@ -1477,10 +1479,24 @@ __global__ __launch_bounds__(576) void k_rollout3db(const KArgs a) {
     const bool tl = a.obs_mode == SNAC_OBS_TILED;
     char* const obs0 = (char*)a.obs + ((tl ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)a.tiled_t0) * 64 : (size_t)env0) + (size_t)e0) * ROWB;
     const size_t tstride = (tl ? (size_t)64 : (size_t)a.n) * ROWB;
-    char* const st = stg + e0 * ROWB;                                // the wave's slice of the staging tile
-    OT* const orow = (OT*)(stg + we * ROWB) + qt * 7;
+    int16_t* const srow = stg16 + we * 56 + min(qt, 6) * 8;          // where this lane's window row goes (part 7: nowhere)
     int16_t* const hme = K::hmap(hm) + we * K::ES;
     const int16_t* const hq = hme + (min(qt, 6) - 3) * 26 - 3;
+    // The wave's 8 rows leave as NP 16-byte pieces of VP values, piece lane + 64 q in lane's q-th store.  Value g of the slice is
+    // element g % 51 of env g / 51: a window cell (an int16 of the staging tile, converted on the way out) or one of the two scalar
+    // slots (a float64 the stepper published).  Where each of a lane's values comes from does not change from tick to tick:
+    constexpr int VP = 16 / (int)sizeof(OT), NP = 8 * ROWB / 16, NQ = (NP + 63) / 64, NV = NQ * VP;
+    int src[NV];                                                     // byte offset into stg16, or into the tick's ssc half
+    unsigned scal = 0;                                               // bit i: value i is a scalar slot
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int u = 0; u < VP; ++u) {
+            const int pc = min(lane + 64 * q, NP - 1), g = pc * VP + u, e = g / 51, x = g - 51 * e;
+            src[q * VP + u] = x < 49 ? ((e0 + e) * 56 + (x / 7) * 8 + x % 7) * 2 : ((e0 + e) * 2 + (x - 49)) * 8;
+            scal |= x < 49 ? 0u : 1u << (q * VP + u);
+        }
+    const int npieces = rows * ROWB / 16;
     int d_eps = 0, d_ret = 0;
     long long d_iou = 0;
     for (int t = 0; t < a.T; ++t) {
@@ -1505,25 +1521,38 @@ __global__ __launch_bounds__(576) void k_rollout3db(const KArgs a) {
         int cv[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) cv[j] = (int)corner[j];              // part 7 reads a row it does not use
-        const double2 sv = *(const double2*)ssc[par][we];
-        if (qt < 7) {
-#pragma unroll
-            for (int j = 0; j < 7; ++j) orow[j] = (OT)cv[j];
-        } else {
-            orow[0] = (OT)sv.x; orow[1] = (OT)sv.y;
+        if (qt < 7) {                                                    // one aligned 16-byte write (a misaligned 14-byte row, then read back
+            uint4 w;                                                     // cell by cell, cost 0.45 us per tick: 1.52 instead of 1.08 ms)
+            w.x = (uint32_t)(cv[0] & 0xffff) | ((uint32_t)cv[1] << 16); w.y = (uint32_t)(cv[2] & 0xffff) | ((uint32_t)cv[3] << 16);
+            w.z = (uint32_t)(cv[4] & 0xffff) | ((uint32_t)cv[5] << 16); w.w = (uint32_t)(cv[6] & 0xffff);
+            *(uint4*)srow = w;
         }
         // the wave's rows leave: its own LDS writes are visible to its own reads in order
         {
             char* const g = obs0 + (size_t)t * tstride;
-            if (rows == 8) {
-                constexpr int NP = 8 * ROWB / 16, NQ = (NP + 63) / 64;
-                uint4 v[NQ];
+            const char* const cells = (const char*)stg16;
+            const char* const scs = (const char*)ssc[par];
+            int ci[NV];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) v[q] = *(const uint4*)(st + min(lane + q * 64, NP - 1) * 16);   // unconditional: the array stays in registers
+            for (int i = 0; i < NV; ++i) ci[i] = (int)*(const int16_t*)(cells + ((scal >> i) & 1u ? 0 : src[i]));
+            double sc[NV];                                               // all reads of the tile before anything waits: a lane without a
+#pragma unroll                                                           // scalar slot at position i reads slot 0 (a broadcast)
+            for (int i = 0; i < NV; ++i) sc[i] = *(const double*)(scs + ((scal >> i) & 1u ? src[i] : 0));
+            OT val[NV];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) { const int pc = lane + q * 64; if (pc < NP) *(uint4*)(g + pc * 16) = v[q]; }
-            } else {
-                for (int pc = lane; pc < rows * ROWB / 16; pc += 64) *(uint4*)(g + pc * 16) = *(const uint4*)(st + pc * 16);
+            for (int i = 0; i < NV; ++i) val[i] = (scal >> i) & 1u ? (OT)sc[i] : (OT)ci[i];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int pc = lane + 64 * q;
+                if (pc < npieces) {
+                    if constexpr (VP == 2) {
+                        double2 o; o.x = val[2 * q]; o.y = val[2 * q + 1];
+                        *(double2*)(g + pc * 16) = o;
+                    } else {
+                        float4 o; o.x = val[4 * q]; o.y = val[4 * q + 1]; o.z = val[4 * q + 2]; o.w = val[4 * q + 3];
+                        *(float4*)(g + pc * 16) = o;
+                    }
+                }
             }
         }
         const size_t row = (size_t)t * (size_t)a.n + (size_t)env0;
