@@ -213,5 +213,5 @@ def test_config3_headline_pass_as_one_launch():
 
 
 def test_config5_3d_pass_as_one_launch():
-    """BASELINE configs[4] as one launch of the pipelined 3D kernel: rollout(1000) of 16 384 envs."""
+    """BASELINE configs[4] as one launch of the 3D block kernel (k_rollout3db): rollout(1000) of 16 384 envs."""
     _one_launch(3, True, 16384, 1000, 125, "dense_train")
