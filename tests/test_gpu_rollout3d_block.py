@@ -152,3 +152,44 @@ def test_a_pending_reset_carried_into_the_next_launch():
         _compare(env, orc, T, t0)
         t0 += T
     _end_state(env, orc)
+
+
+def test_replay_rings_filled_by_the_block_kernel():
+    """ReplayRing.collect on a 3D batch of block-kernel size: the tick ring ([ring_ticks][N][51] rows + record outputs) and the
+    tile-major ring (snac_rollout_tiled: a launch writes its ticks at an offset of the ring, wrapping) hold the same rows, records
+    and samples; the tick ring's rows equal the oracle's."""
+    import torch
+    from snac_amd import BatchedDMPEnv, ReplayRing
+
+    n = N0 + 36
+    table = helpers.plan_table(3, True, "dense_train")
+    envs = [BatchedDMPEnv(3, True, n, plans=table.reshape(len(table), 26, 26), seed=12, total_step=40) for _ in range(2)]
+    orc = helpers.oracle().OracleBatch(3, True, n, table, seed=12)
+    orc.set_total_step(40)
+    orc.reset()
+    orc.rollout(13, t0=0, obs=None, nthreads=16)
+    rings = []
+    for e, layout in zip(envs, ("ticks", "tiled")):
+        e.reset()
+        e.rollout(13, obs=None)                                       # attach in mid-episode
+        rings.append(ReplayRing(e, 48, layout=layout))
+    t0 = 13
+    for T in (20, 30, 48, 7):
+        for r in rings:
+            r.collect(T)
+        oc, rc, dc = orc.rollout(T, t0=t0, nthreads=16)
+        t0 += T
+    a, b = rings
+    for slot in range(48):
+        assert torch.equal(a.obs_at(slot), b.obs_at(slot)), slot
+    for name in ("reward", "done", "action", "step_size", "plan_idx", "first"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    # the last launch wrote 7 ticks: its rows are the oracle's last 7
+    assert a.head == b.head == (20 + 30 + 48 + 7) % 48                # the ring slot after the last written one
+    for i in range(7):
+        slot = (a.head - 7 + i) % 48
+        assert a.obs_at(slot).cpu().numpy().tobytes() == oc[i].tobytes(), i
+    ga, gb = torch.Generator(device="cuda"), torch.Generator(device="cuda")
+    ga.manual_seed(3); gb.manual_seed(3)
+    sa, sb = a.sample(300, generator=ga), b.sample(300, generator=gb)
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
