@@ -167,3 +167,42 @@ def test_staged_rows_alignments_layouts_and_the_switch_to_the_tile_kernel(n, f32
     assert ou.data_ptr() % 16 != 0 and ou.cpu().numpy().tobytes() == want and torch.equal(ru, rg) and torch.equal(du, dg)
     _end_state(env, orc)
     assert torch.equal(env._hdr, twin._hdr) and torch.equal(env._hdr, third._hdr) and torch.equal(env._grid, third._grid)
+
+
+def test_replay_rings_filled_by_the_time_parallel_kernel():
+    """ReplayRing.collect on a 1D batch whose rollouts run on k_rollout1dt in blocks of 16 envs (a ragged last block): the tick ring
+    and the tile-major ring (launches that write at an offset of the ring and wrap) hold the same rows, records and samples; the last
+    launch's rows equal the oracle's."""
+    import torch
+    from snac_amd import BatchedDMPEnv, ReplayRing
+
+    n = 4100
+    table, full = _tables(True)
+    envs = [BatchedDMPEnv(1, True, n, plans=full, seed=12, total_step=40) for _ in range(2)]
+    orc = helpers.oracle().OracleBatch(1, True, n, table, seed=12)
+    orc.set_total_step(40)
+    orc.reset()
+    orc.rollout(13, t0=0, obs=None, nthreads=8)
+    rings = []
+    for e, layout in zip(envs, ("ticks", "tiled")):
+        e.reset()
+        e.rollout(13, obs=None)                                       # attach in mid-episode
+        rings.append(ReplayRing(e, 100, layout=layout))
+    t0 = 13
+    for T in (70, 90, 100, 7):                                        # 64-tick chunks that straddle the ring's end
+        for r in rings:
+            r.collect(T)
+        oc, rc, dc = orc.rollout(T, t0=t0, nthreads=8)
+        t0 += T
+    a, b = rings
+    for slot in range(100):
+        assert torch.equal(a.obs_at(slot), b.obs_at(slot)), slot
+    for name in ("reward", "done", "action", "step_size", "plan_idx", "first"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert a.head == b.head == (70 + 90 + 100 + 7) % 100
+    for i in range(7):
+        assert a.obs_at((a.head - 7 + i) % 100).cpu().numpy().tobytes() == oc[i].tobytes(), i
+    ga, gb = torch.Generator(device="cuda"), torch.Generator(device="cuda")
+    ga.manual_seed(3); gb.manual_seed(3)
+    sa, sb = a.sample(300, generator=ga), b.sample(300, generator=gb)
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
