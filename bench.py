@@ -550,7 +550,7 @@ def main():
 
         rollout_cfg("c2_1d_static_n4096_T750", 1, False, 4096, False, 40,
                     "time-parallel kernel k_rollout1dt (one wave per env, lane = tick, the rows of 16 envs through an LDS tile as 896-byte runs: "
-                    "0.29 -> 0.05 ms); the pass writes only 187 MB and is bound by instruction issue (~9 per env-step), not by the HBM rate")
+                    "0.29 -> 0.05 ms); the pass writes only 187 MB and is bound by instruction issue (7.3 per env-step by the counters), not by the HBM rate")
         rollout_cfg("c5_3d_dynamic_n16384_T1000", 3, True, 16384, False, 24)
         rollout_cfg("headline_f32_obs", 2, True, 65536, True, 24)
         for kind in (2, 3):
