@@ -1,5 +1,5 @@
 """GPU: 1D rollouts against the CPU oracle.  Rollouts that write every row run on the time-parallel kernel (k_rollout1dt, round 3:
-one wavefront per env, lane = tick, blocks of 4 or 16 envs whose rows leave through an LDS staging tile as whole runs per tick) up
+one wavefront per env, lane = tick, blocks of 4 (below 3584 envs) or 16 envs whose rows leave through an LDS staging tile as whole runs per tick) up
 to 49 152 envs (float32 rows: 65 536), on the tile kernel beyond: batches on either side of every switch, ragged blocks and blocks
 with idle waves, rows that can and cannot leave as 16-byte pieces (odd N, unaligned outputs), canonical and tile-major layouts,
 odd / tiny tick counts, episodes that end by count_brick and by the time limit (several per chunk of 64 ticks), the `>` rule
@@ -53,11 +53,11 @@ def _end_state(env, orc):
 
 
 @pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
-@pytest.mark.parametrize("n", [1, 13, 2047, 2049, 4100, 8200, 16384])
+@pytest.mark.parametrize("n", [1, 13, 2049, 3583, 3585, 4100, 8200, 16384])
 def test_batch_shapes_and_tick_counts(dyn, n):
-    """n = 1 / 13 / 2047: blocks of 4 envs, the last one ragged, odd N (rows leave element by element); 2049: blocks of 16, the last
-    holds one env and fifteen idle waves; 4100 / 8200: a last block of 4 / 8 envs; 16 384: full blocks only.  Launches of 1, 2, 37
-    and 80 steps."""
+    """n = 1 / 13 / 2049 / 3583: blocks of 4 envs, the last one ragged, odd N (rows leave element by element); 3585: blocks of 16, the
+    last holds one env and fifteen idle waves; 4100 / 8200: a last block of 4 / 8 envs; 16 384: full blocks only.  Launches of 1, 2,
+    37 and 80 steps."""
     env, orc = _pair(dyn, n, seed=5, total_step=60)
     t0 = 0
     for T in (1, 2, 37, 80):
@@ -142,7 +142,7 @@ def test_time_parallel_kernel_segments_inside_a_chunk(dyn, total_step, time_gt):
         _end_state(env, orc)
 
 
-@pytest.mark.parametrize("n,f32", [(2050, False), (2051, False), (4100, True), (4102, True), (49152, False), (49168, False), (65536, True), (65552, True)])
+@pytest.mark.parametrize("n,f32", [(2050, False), (2051, False), (3586, False), (3587, False), (4100, True), (4102, True), (49152, False), (49168, False), (65536, True), (65552, True)])
 def test_staged_rows_alignments_layouts_and_the_switch_to_the_tile_kernel(n, f32):
     """Rows of a block leave as 16-byte pieces when every run of a tick starts and ends on 16 bytes (float64: even N; float32:
     N % 4 = 0) and element by element otherwise -- also when the output itself is not 16-byte aligned; tile-major outputs hold the
