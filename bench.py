@@ -601,9 +601,9 @@ def main():
                 traffic_source = "none: profiles/traffic.json belongs to kernel source %s, this library was built from %s" % (tj.get("source_sha16"), now)
         written = WRITTEN_BYTES[(args.kind, dkey)] * n * T / (kern_ms * 1e-3) / 1e9
         what = "%dD %s dense" % (args.kind, "dynamic" if dynamic else "static")
-        # the kernel this workload dispatches to (snac_hip.hip::launch): the staged 2D rollout, the block-cooperative 3D rollout (8-env tiles below 8192 envs), the
+        # the kernel this workload dispatches to (snac_hip.hip::launch): the staged 2D rollout, the block-cooperative 3D rollout (8-env tiles below 6144 envs; float32 rows: 4096), the
         # time-parallel 1D rollout up to 49 152 envs (float32 rows: 65 536), the tile kernel otherwise
-        kernel_name = ("k_rollout3db" if n >= 8192 and n % 4 == 0 else "k_rollout3d") if args.kind == 3 else ("k_rollout1dt" if args.kind == 1 and n <= (65536 if args.obs_f32 else 49152) else
+        kernel_name = ("k_rollout3db" if n >= (4096 if args.obs_f32 else 6144) and n % 4 == 0 else "k_rollout3d") if args.kind == 3 else ("k_rollout1dt" if args.kind == 1 and n <= (65536 if args.obs_f32 else 49152) else
                                                             ("k_rollout2d" if args.kind == 2 and n >= 65536 and n % 4 == 0 else "k_rollout"))
         out = {
             "metric": HEADLINE if headline else "env-steps/sec at N=%d envs (%s, %s obs); bit-exact vs CPU" % (n, what, dkey),

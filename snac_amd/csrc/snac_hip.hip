@@ -1288,8 +1288,8 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout3d(const KArgs a) {
 // 16 envs, a scratch-spilled flush, idle waves on the stepper's SIMD, wave priorities, the staging tile as float64 / misaligned
 // int16 / none) is in profiles/r03_3d_block_kernel.txt.
 // Semantics are K3D::step's, formulated as in k_step3d / Roll3D::tick.  Conditions: every row written (SNAC_OBS_ALL /
-// SNAC_OBS_TILED), canonical layout, <= TB_MAX plans, N % 4 = 0 and a 16-byte aligned output, N >= 8192 (below, k_rollout3d's
-// one-wave blocks are faster: 4096 envs 1.02 against 1.04 ms); the rest stays on k_rollout3d.
+// SNAC_OBS_TILED), canonical layout, <= TB_MAX plans, N % 4 = 0 and a 16-byte aligned output, N >= 6144 (float32 rows: 4096; below,
+// k_rollout3d's one-wave blocks are faster); the rest stays on k_rollout3d.
 
 // A barrier between waves that exchange data through LDS only (no wait for the writers' global stores).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -3029,10 +3029,13 @@ void launch_roll3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
 }
 
 // 3D rollouts by blocks of 64 envs; SNAC_3D_BLOCK=0 keeps them on k_rollout3d (A/B timing, tests of both paths)
-bool roll3db_ok(const KArgs& a) {
+bool roll3db_ok(const KArgs& a, bool f32) {
     static const bool off = [] { const char* e = std::getenv("SNAC_3D_BLOCK"); return e && e[0] == '0'; }();
-    static const int nmin = [] { const char* e = std::getenv("SNAC_3D_BLOCK_MIN"); return e ? std::atoi(e) : 8192; }();   // (tuning)
-    return !off && a.n >= nmin && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && (a.n & 3) == 0 &&
+    static const int nmin = [] { const char* e = std::getenv("SNAC_3D_BLOCK_MIN"); return e ? std::atoi(e) : -1; }();   // (tuning)
+    // where k_rollout3d's one-wave blocks stop being faster: float64 rows 4096 envs 1.02 against 1.04 ms, 6144 level, 8192 1.08 against
+    // 1.04; float32 rows 4096 envs 1.02 against 0.97 already
+    const int lim = nmin >= 0 ? nmin : (f32 ? 4096 : 6144);
+    return !off && a.n >= lim && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && (a.n & 3) == 0 &&
            (((uintptr_t)a.obs) & 15) == 0 && !pipeline_off();
 }
 template <bool DYN, typename OT>
@@ -3174,7 +3177,7 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             if (op == OP_ROLLOUT && roll2d_ok(a, (d->obs_dtype == SNAC_OBS_F32 && a.n >= 32768) ? 64 : E)) { launch_roll2d(d, a, s); break; }
             launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
-            if (op == OP_ROLLOUT && roll3db_ok(a)) { launch_roll3db(d, a, s); break; }
+            if (op == OP_ROLLOUT && roll3db_ok(a, d->obs_dtype == SNAC_OBS_F32)) { launch_roll3db(d, a, s); break; }
             if (op == OP_ROLLOUT && E == 8 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && !pipeline_off()) { launch_roll3d(d, a, s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off() && step_stage_ok(a)) { launch_step_tile<3>(d, a, s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans3d(d, a, s); break; }

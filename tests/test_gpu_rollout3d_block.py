@@ -1,6 +1,6 @@
 """GPU: the block-cooperative 3D rollout kernel (k_rollout3db, round 3: 64 envs per block, one stepper wave with an env per lane,
 eight writer waves that own the height maps, one barrier per tick, the stepper's reads patched for the tick they lag) against the
-CPU oracle.  The kernel takes 3D rollouts of N >= 8192 envs (N % 4 = 0, 16-byte aligned output) that write every observation: full
+CPU oracle.  The kernel takes 3D rollouts of N >= 6144 envs (float32 rows: 4096; N % 4 = 0, 16-byte aligned output) that write every observation: full
 blocks and a ragged last block (down to one writer wave with 4 envs), float64 and float32 rows, static and dataset plans,
 [T][N][D] and tile-major outputs, launches of 1 / 2 / 37 steps, explicit actions / step sizes, the `>` rule bits, time limits of
 1 .. 3 (an env starts over every tick: the stepper then reads no map at all for it, or a map that is a tick behind), the record
@@ -12,7 +12,7 @@ import helpers
 
 pytestmark = pytest.mark.gpu
 
-N0 = 8192
+N0 = 6144
 
 
 def _pair(dyn, n, seed, tag=None, total_step=None, obs_dtype=None, brick_gt=False, time_gt=False, base=0):
@@ -56,7 +56,7 @@ def _end_state(env, orc):
 @pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
 @pytest.mark.parametrize("n", [N0, N0 + 36, N0 + 64 + 4])
 def test_blocks_dtypes_and_launch_lengths(dyn, n, f32):
-    """n = 8192: full blocks only; + 36: a last block of 36 envs (four full writer waves, one with 4 envs, three idle); + 68: a last
+    """n = 6144: full blocks only; + 36: a last block of 36 envs (four full writer waves, one with 4 envs, three idle); + 68: a last
     block of 4 envs.  Launches of 1, 2 and 37 steps; random 3D agents box themselves in every ~22 steps, so every launch of 37 has
     envs that start over, some of them twice."""
     import torch
