@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define SNAC_ABI_VERSION 5
+#define SNAC_ABI_VERSION 6
 
 typedef enum snac_status {
     SNAC_OK = 0,
@@ -218,10 +218,16 @@ int snac_stream_sync(void* stream);
  *                     the last 4 GiB, and is released before the call returns.  With too little room, or without a usable
  *                     measurement, the block falls back to three runs created 32 GiB apart.  stream: the probe kernels, the
  *                     check and their waits run on this stream (NULL = the default stream); the call returns when they are done.
- *                     Every block is CHECKED before it is handed out: a pattern written by one kernel is read back by another
- *                     and, one word per chunk, by a copy; a measured block is also timed once more as a whole and rebuilt (once,
- *                     then the fixed layout) if it runs like a single slice.  A block that fails its check is SNAC_ERR_HIP, never
- *                     a silent retry.  Typically 0.5-1.5 s for the headline's 16 GB.  SNAC_ERR_HIP when memory runs out.
+ *                     How a measured block is built (round 4): the probe writes the headline rollout's own store shape (a wave's
+ *                     26 112-byte tile per step, 16 bytes per lane, 1 KiB per store instruction, 1024 waves); the block is a
+ *                     sequence of 1 GiB WINDOWS, each the 16 chunks of a group from the reference's slice and the 16 chunks of a
+ *                     group from another slice taking turns, and every window is timed as that pair BEFORE it is used (a pair
+ *                     that misses the fast level is taken apart); the mapped block is then timed again, EVERY window and once as
+ *                     a whole, and rebuilt from a larger pool (twice at most) if a window runs like a single slice.  What was
+ *                     measured stays with the block: snac_traj_describe.
+ *                     Every block is also CHECKED before it is handed out: a pattern written by one kernel is read back by
+ *                     another and, one word per chunk, by a copy.  A block that fails its check is SNAC_ERR_HIP, never a silent
+ *                     retry.  Typically 0.1-1 s for the headline's 16 GB.  SNAC_ERR_HIP when memory runs out.
  *                     SNAC_TRAJ_PROBE=0 skips the measurement, SNAC_TRAJ_DEBUG=1 prints it.
  *   snac_traj_alloc   the same with the default pool cap on the default stream.
  *   snac_traj_free    waits for the whole device to go idle (hipDeviceSynchronize: no kernel may still be writing the block),
@@ -229,18 +235,43 @@ int snac_stream_sync(void* stream);
  *                     recycled range has been seen to serve stale translations, tools/vmm_stale.hip; a stale pointer faults instead
  *                     of hitting someone else's data): every block of 1 GiB or more costs its own size plus its probe ranges in
  *                     ADDRESS SPACE for the life of the process -- no memory; 47 bits last for more than a thousand headline-sized
- *                     blocks.  NULL is a no-op; a pointer that did not come from snac_traj_alloc is SNAC_ERR_ARG.  (The Python
- *                     wrapper frees a block when the last tensor viewing it dies, so the device-wide wait can come from a
- *                     garbage collection.)
- * The caller owns the block; the library keeps only what it needs to unmap it again. */
+ *                     blocks; snac_traj_reserved_bytes() says how much is held that way.  NULL is a no-op; a pointer that did not
+ *                     come from snac_traj_alloc is SNAC_ERR_ARG.  (The Python wrapper frees a block when the last tensor viewing
+ *                     it dies, so the device-wide wait can come from a garbage collection.)
+ * The caller owns the block; the library keeps only what it needs to unmap and to describe it. */
 int snac_traj_alloc_ex(size_t bytes, int device, size_t pool_cap_bytes, void* stream, void** out);
 int snac_traj_alloc(size_t bytes, int device, void** out);
 int snac_traj_free(void* ptr);
 /* how a live block of snac_traj_alloc is backed (diagnostics): one of the values below, or SNAC_ERR_ARG for any other pointer */
 #define SNAC_TRAJ_ONE_RUN 1      /* below 1 GiB: handles in creation order */
 #define SNAC_TRAJ_THREE_RUNS 2   /* the fallback: three runs created 32 GiB apart, chunk j -> run j % 3 */
-#define SNAC_TRAJ_MEASURED 3     /* chunks of the reference group's slice and of another slice in turn, as probed */
+#define SNAC_TRAJ_MEASURED 3     /* windows of 1 GiB: chunks of the reference group's slice and of another slice in turn, every
+                                    window timed as the pair it is */
 int snac_traj_layout(const void* ptr);
+/* what the allocator measured while it built a live block (all times in microseconds per GiB written under the rollout's store
+ * shape; zeros for the layouts that are not measured).  A caller -- bench.py's `placement` -- can tell from this alone whether the
+ * block it was given runs at the two-slice level: windows_slow == 0 and block_us_per_gib close to fast_us_per_gib. */
+#define SNAC_TRAJ_INFO_WINDOWS 64
+typedef struct snac_traj_info {
+    int32_t layout;                  /* SNAC_TRAJ_* */
+    int32_t rebuilds;                /* measured blocks built and thrown away before this one (0 .. 2) */
+    int32_t pool_groups;             /* 512 MB groups the pool held when the block was assembled */
+    int32_t probe_launches;          /* launches of the probe kernel for this block (the last attempt) */
+    int32_t windows;                 /* 1 GiB windows timed in the finished block */
+    int32_t windows_slow;            /* of those: above 1.08 x fast_us_per_gib (0 unless the last rebuild still had one) */
+    float self_us_per_gib;           /* the reference group written as a pair with itself: the scale the classes are judged on */
+    float fast_us_per_gib;           /* median over the partners in another slice than the reference */
+    float slow_us_per_gib;           /* median over the partners in the reference's slice */
+    float window_max_us_per_gib;     /* the finished block: its slowest window ... */
+    float window_mean_us_per_gib;    /* ... the mean over its windows ... */
+    float block_us_per_gib;          /* ... and all of it in one launch */
+    float build_ms;                  /* wall time of the whole snac_traj_alloc call */
+    uint64_t bytes;                  /* mapped size */
+    float window_us[SNAC_TRAJ_INFO_WINDOWS];   /* the first 64 windows, in address order */
+} snac_traj_info;
+int snac_traj_describe(const void* ptr, snac_traj_info* out);
+/* address space (bytes) of ranges this process has unmapped and keeps reserved (see snac_traj_free) */
+uint64_t snac_traj_reserved_bytes(void);
 
 /* the driver loop of multiprocess.py:78-84 -- T vector steps with auto-reset, fused in one launch with the
  * env state held on chip.

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SNAC_OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 ENV_1D, ENV_2D, ENV_3D = 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 OBS_NONE, OBS_ALL, OBS_LAST, OBS_TILED = 0, 1, 2, 3
@@ -23,7 +23,7 @@ EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_obs_dim", 
            "snac_step_scalar", "snac_rollout",
            "snac_rollout_rec", "snac_replay_gather", "snac_make_plans", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
            "snac_import_state", "snac_obs_equal", "snac_stream_sync", "snac_rollout_tiled", "snac_replay_gather_tiled", "snac_traj_alloc",
-           "snac_traj_alloc_ex", "snac_traj_free", "snac_traj_layout")
+           "snac_traj_alloc_ex", "snac_traj_free", "snac_traj_layout", "snac_traj_describe", "snac_traj_reserved_bytes")
 
 
 class Sizes(C.Structure):
@@ -49,15 +49,26 @@ class State(C.Structure):
                 ("stat_iou_fx", C.c_void_p)]
 
 
+TRAJ_INFO_WINDOWS = 64
+
+
+class TrajInfo(C.Structure):
+    """snac_traj_info (include/snac_hip.h): what snac_traj_alloc measured while it built a block."""
+    _fields_ = ([(n, C.c_int32) for n in ("layout", "rebuilds", "pool_groups", "probe_launches", "windows", "windows_slow")]
+                + [(n, C.c_float) for n in ("self_us_per_gib", "fast_us_per_gib", "slow_us_per_gib", "window_max_us_per_gib",
+                                            "window_mean_us_per_gib", "block_us_per_gib", "build_ms")]
+                + [("bytes", C.c_uint64), ("window_us", C.c_float * TRAJ_INFO_WINDOWS)])
+
+
 class SnacError(RuntimeError):
     pass
 
 
 def build(force=False):
     """Compile libsnac_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    src = [os.path.join(CSRC, "snac_hip.hip"), os.path.join(INCLUDE, "snac_hip.h")]
+    src = [os.path.join(CSRC, f) for f in ("snac_hip.hip", "snac_traj.hip", "snac_common.h")] + [os.path.join(INCLUDE, "snac_hip.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
-        subprocess.check_call(["make", "-s", "-C", CSRC, "-B", "../libsnac_hip.so"])
+        subprocess.check_call(["make", "-s", "-C", CSRC] + (["-B"] if force else []) + ["../libsnac_hip.so"])
     return LIB_PATH
 
 
@@ -103,6 +114,8 @@ def lib():
         L.snac_traj_alloc_ex.argtypes = [C.c_size_t, C.c_int, C.c_size_t, vp, C.POINTER(vp)]
         L.snac_traj_free.argtypes = [vp]
         L.snac_traj_layout.argtypes = [vp]
+        L.snac_traj_describe.argtypes = [vp, C.POINTER(TrajInfo)]
+        L.snac_traj_reserved_bytes.restype = C.c_uint64
         for n in EXPORTS:
             getattr(L, n)
         if L.snac_version() != ABI_VERSION:

@@ -102,6 +102,29 @@ def layout_of(t):
     return LAYOUTS.get(rc)
 
 
+def describe(t):
+    """What snac_traj_alloc measured while it built the block under tensor `t` (snac_traj_describe), as a dict -- times in
+    microseconds per GiB written under the rollout's store shape: `fast` / `slow` = the two-slice and the single-slice level of this
+    box as the probe saw them, `block` = the finished block in one launch, `windows` = each of its 1 GiB windows -- or None if `t`
+    does not start at such a block."""
+    info = _lib.TrajInfo()
+    if _lib.lib().snac_traj_describe(C.c_void_p(t.untyped_storage().data_ptr()), C.byref(info)) != 0:
+        return None
+    r = lambda x: round(float(x), 1)
+    return {"layout": LAYOUTS.get(info.layout), "rebuilds": info.rebuilds, "pool_groups": info.pool_groups,
+            "probe_launches": info.probe_launches, "windows_slow": info.windows_slow, "build_ms": r(info.build_ms),
+            "us_per_gib": {"self": r(info.self_us_per_gib), "fast": r(info.fast_us_per_gib), "slow": r(info.slow_us_per_gib),
+                           "block": r(info.block_us_per_gib), "window_mean": r(info.window_mean_us_per_gib),
+                           "window_max": r(info.window_max_us_per_gib),
+                           "windows": [r(info.window_us[i]) for i in range(min(info.windows, _lib.TRAJ_INFO_WINDOWS))]},
+            "bytes": int(info.bytes)}
+
+
+def reserved_bytes():
+    """Address space (not memory) this process keeps reserved for ranges it has unmapped (snac_traj_free never recycles a range)."""
+    return int(_lib.lib().snac_traj_reserved_bytes())
+
+
 def traj_empty(shape, dtype, device, pool_cap=0):
     """torch.empty(shape, dtype=dtype, device=device) on snac_traj_alloc memory (contiguous; it holds the pattern of the library's
     own check, not zeros).  pool_cap: bytes of device memory the slice measurement may hold beyond the block while it runs
