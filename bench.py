@@ -131,6 +131,18 @@ def _oracle_rate(kind, dynamic, n, T, seed, cores, budget):
     return steps / (time.perf_counter() - t0), steps // n
 
 
+def oracle_first_ticks(kind, dynamic, n, seed, env_id_base, ticks, cores):
+    """What the CPU oracle says about the first `ticks` vector steps of this rank's shard (same seed, plan table, env ids as the
+    measured batch): the reset observation, then obs [ticks, n, D] float64, reward [ticks, n] float32, done [ticks, n] uint8.
+    The checker of the bench line's `parity_vs_oracle` (the oracle is test infrastructure: it checks, it is never the product)."""
+    from oracle import snac_oracle
+
+    orc = snac_oracle.OracleBatch(kind, dynamic, n, _table(kind, dynamic), seed=seed, env_id_base=env_id_base)
+    first = orc.reset()
+    o, r, d = orc.rollout(ticks, nthreads=cores)
+    return first, o, r, d
+
+
 def _python_loop_rate(kind, dynamic, seed, n=1024, budget=5.0):
     """(iii) the per-env Python loop shaped like VectorizedEnvWrapper.step (multiprocess.py:24-32): n independent env
     objects, a for-loop calling step() on each, np.asarray of the collected lists; the step size drawn per step with
@@ -263,7 +275,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from snac_amd import BatchedDMPEnv
+    from snac_amd import BatchedDMPEnv, _lib
 
     # RCCL ("nccl" on ROCm) in production; SNAC_BENCH_BACKEND=gloo lets the N > 1 path be exercised with several
     # ranks sharing one GPU (tests): the three int64 sums then take a CPU round trip.
@@ -437,11 +449,67 @@ def main():
     ranks_devices = ["cuda:%d pci %04x:%02x:%02x" % (i % max(ndev, 1) if backend != "nccl" else i, v >> 16, (v >> 8) & 0xff, v & 0xff) if v >= 0 else None
                      for i, v in enumerate(allreduce_(ids).tolist())]
 
+    kernel_name = _lib.lib().snac_last_kernel().decode()        # what the timed launches went to, as the library's dispatch says
+
     # integrity of what the timed passes wrote (after the clock stopped): the last step's rows in the trajectory tensor must be the
     # batch's current observation, read through a different kernel into ordinary memory
     traj_ok = bool(torch.equal(obs[T - 1], env.observe()))
     if not traj_ok:
         sys.stderr.write("bench.py: the trajectory tensor's last step differs from observe() -- the measurement is INVALID\n")
+    # ... "bit-exact vs CPU" as something THIS run proves: a fresh batch with the measured batch's seed, table and env ids makes one
+    # full pass (the same launch shape, the same kernel) into the measured trajectory block, and its reset observation and the first
+    # PARITY_TICKS ticks of observations, rewards and done flags are compared byte for byte with the CPU oracle's.  Every rank checks
+    # its own shard; false anywhere marks the line invalid (exit status 4).  (The -m gpu tests compare whole passes; this is the
+    # run's own certificate, a fraction of a second.)
+    PARITY_TICKS = 10
+    parity = None
+    if os.environ.get("SNAC_BENCH_PARITY", "1") != "0":
+        try:
+            first, oo, ro, do = oracle_first_ticks(args.kind, dynamic, n, 1, rank * n, PARITY_TICKS, min(16, os.cpu_count() or 1))
+            fresh = BatchedDMPEnv(args.kind, dynamic, n, device=dev, seed=1, env_id_base=rank * n,
+                                  obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+            g0 = fresh.reset()
+            go, gr, gd = fresh.rollout(T, obs="all", out=obs)
+            same_kernel = _lib.lib().snac_last_kernel().decode() == kernel_name
+            cast = (lambda x: x.astype("float32")) if args.obs_f32 else (lambda x: x)
+            parity = bool(same_kernel
+                          and g0.cpu().numpy().tobytes() == cast(first).tobytes()
+                          and go[:PARITY_TICKS].cpu().numpy().tobytes() == cast(oo).tobytes()
+                          and gr[:PARITY_TICKS].cpu().numpy().tobytes() == ro.tobytes()
+                          and gd[:PARITY_TICKS].cpu().numpy().view("uint8").tobytes() == do.tobytes())
+            del fresh, go, gr, gd, g0, first, oo, ro, do
+            if not parity:
+                traj_ok = False
+                sys.stderr.write("bench.py: rank %d: the first %d ticks differ from the CPU oracle -- the measurement is INVALID\n" % (rank, PARITY_TICKS))
+        except Exception as e:
+            sys.stderr.write("bench.py: oracle parity leg could not run (%r)\n" % (e,))
+            parity = "not run: %r" % (e,)
+    # every rank's own account, gathered into rank 0's line: kernel time, how its trajectory block is backed and how fast the
+    # allocator measured it, its integrity and parity checks -- a slow or wrong rank is explainable from the line
+    blk = None
+    try:
+        from snac_amd import trajmem as _tm
+
+        blk = _tm.describe(obs)
+    except Exception:
+        pass
+    lay_code = {"one run": 1, "three runs 32 GiB apart": 2, "measured: two slices in turn": 3}.get((blk or {}).get("layout"), 0)
+    mine = torch.zeros((world, 8), dtype=torch.float64, device=dev)
+    mine[rank] = torch.tensor([kern_ms, lay_code, (blk or {}).get("us_per_gib", {}).get("block", 0.0), (blk or {}).get("us_per_gib", {}).get("fast", 0.0),
+                               (blk or {}).get("windows_slow", 0), (blk or {}).get("rebuilds", 0), 1.0 if traj_ok else 0.0,
+                               1.0 if parity is True else (0.0 if parity is False else -1.0)], dtype=torch.float64)
+    mine = allreduce_(mine).tolist()
+    lay_names = {0: "hipMalloc", 1: "one run", 2: "three runs 32 GiB apart", 3: "measured: two slices in turn"}
+    per_rank_report = [{"rank": i, "kernel_ms": round(r[0], 4), "block_layout": lay_names[int(r[1])], "block_us_per_gib": r[2], "fast_us_per_gib": r[3],
+                        "windows_slow": int(r[4]), "rebuilds": int(r[5]), "trajectory_check": bool(r[6]), "parity_vs_oracle": (None if r[7] < 0 else bool(r[7]))}
+                       for i, r in enumerate(mine)]
+    all_ok = all(r["trajectory_check"] for r in per_rank_report)
+    parity_all = None if any(r["parity_vs_oracle"] is None for r in per_rank_report) else all(r["parity_vs_oracle"] for r in per_rank_report)
+    # N RCCL ranks must sit on N distinct GPUs
+    devices_ok = backend != "nccl" or world == 1 or len(set(ranks_devices)) == world
+    if not devices_ok:
+        sys.stderr.write("bench.py: %d RCCL ranks on %d distinct GPUs (%r) -- the measurement is INVALID\n" % (world, len(set(ranks_devices)), ranks_devices))
+
     # ... and every row of one more pass against a SECOND kernel: a twin of the batch rolls out through the tile kernel k_rollout
     # (an output that is not 16-byte aligned cannot take k_rollout2d's 16-byte stores, snac_hip.hip roll2d_ok) into ordinary memory;
     # all T x N rows, rewards and done flags of the two passes must be equal.  After the clock has stopped; one GPU, rank 0.
@@ -518,24 +586,110 @@ def main():
 
         res = {}
 
-        def rollout_cfg(name, kind, dyn, nn, f32, reps, note=None):
+        def last_kernel():
+            return _lib.lib().snac_last_kernel().decode()
+
+        def rollout_cfg(name, kind, dyn, nn, f32, reps, note=None, plans=0, layout=None, TT=0):
+            import numpy as np
+
             dt = torch.float32 if f32 else torch.float64
-            e = BatchedDMPEnv(kind, dyn, nn, device=dev, seed=1, obs_dtype=dt)
+            kw = {}
+            if plans:
+                kw["plans"] = np.zeros((plans, 26, 26))
+            if layout:
+                kw["layout"] = layout
+            e = BatchedDMPEnv(kind, dyn, nn, device=dev, seed=1, obs_dtype=dt, **kw)
+            if plans:
+                e.generate_plans(0, plans, seed=5)
             e.reset()
-            TT = e.total_step
+            TT = TT or e.total_step
             buf = view((TT, nn, e.obs_dim), dt)
             if buf is None:
                 return
             rw = torch.empty((TT, nn), dtype=torch.float32, device=dev)
             dn = torch.empty((TT, nn), dtype=torch.uint8, device=dev)
             ms = timed(lambda: e.rollout(TT, obs="all", out=buf, reward_out=rw, done_out=dn), reps)
-            key = (kind, "f32" if f32 else "f64")
-            algb = WRITTEN_BYTES[key] + 2.0 * STATE_BYTES[kind] / TT
+            esz = 4 if f32 else 8
+            written = e.obs_dim * esz + 5                           # the row + reward + done
+            algb = written + 2.0 * STATE_BYTES[kind] / TT
             gbs = algb * nn * TT / (ms * 1e-3) / 1e9
-            res[name] = {"kernel_ms": ms, "env_steps_per_s": nn * TT / (ms * 1e-3), "written_GBs": WRITTEN_BYTES[key] * nn * TT / (ms * 1e-3) / 1e9,
+            res[name] = {"kernel": last_kernel(), "kernel_ms": ms, "vector_steps": TT, "values_per_row": e.obs_dim, "plans": e.num_plans,
+                         "env_steps_per_s": nn * TT / (ms * 1e-3), "written_GBs": written * nn * TT / (ms * 1e-3) / 1e9,
                          "alg_bytes_per_env_step": algb, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": reps}
             if note:
                 res[name]["note"] = note
+
+        def edges_cfg(name, kind, parents, reps):
+            """snac_transition as one search wave (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175): `parents`
+            random rows of a 2^20-row node pool, one child each with a random action, written to fresh rows with the child's
+            observation.  Bytes per edge: the source record in, the destination record out, row + reward + done + indices."""
+            import ctypes as C
+
+            pool = 1 << 20
+            e = BatchedDMPEnv(kind, True, pool, device=dev, seed=1)
+            e.reset()
+            e.rollout(20, obs=None)
+            m = parents
+            src = torch.randint(0, pool - m, (m,), device=dev, dtype=torch.int32)
+            dst = (pool - m + torch.arange(m, device=dev, dtype=torch.int32)).contiguous()
+            acts = torch.randint(0, e.num_actions, (m,), device=dev).to(torch.int8)
+            ob = view((m, e.obs_dim), torch.float64)
+            rw = torch.empty(m, dtype=torch.float32, device=dev)
+            dn = torch.empty(m, dtype=torch.uint8, device=dev)
+            vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+            def call():
+                _lib.check(e._lib.snac_transition(C.byref(e._desc), C.byref(e._state), m, vp(src), vp(dst), 0, vp(acts), None, vp(ob),
+                                                  vp(rw), vp(dn), e._stream()))
+
+            ms = timed(call, reps)
+            rec = {2: 80, 3: 800}[kind] + 20                         # grid record + header + episode counter
+            algb = 2 * rec + e.obs_dim * 8 + 5 + 8 + 1
+            gbs = algb * m / (ms * 1e-3) / 1e9
+            res[name] = {"kernel": last_kernel(), "kernel_ms": ms, "edges_per_s": m / (ms * 1e-3), "alg_bytes_per_edge": algb, "achieved_GBs": gbs,
+                         "frac": gbs / HBM_PEAK_GBS, "launches": reps, "note": "random parents in a 2^20-row pool, one child per parent into fresh rows"}
+
+        def gather_cfg(name, nn, cap, batch, reps):
+            """snac_replay_gather (row f1; script/DQN/2d/DQN_2d_dynamic.py:145-166): float32 (s, s', plan) minibatch of `batch` random
+            transitions out of a float64 ring of `cap` ticks x `nn` envs."""
+            from snac_amd import ReplayRing
+
+            e = BatchedDMPEnv(2, True, nn, device=dev, seed=1)
+            e.reset()
+            ring = ReplayRing(e, cap)
+            ring.collect(cap)
+            slot = torch.randint(1, cap, (batch,), device=dev)
+            ei = torch.randint(0, nn, (batch,), device=dev)
+            ms = timed(lambda: ring.gather(slot, ei), reps)
+            algb = 2 * 408 + 2 * 204 + 1600 + 8 + 3                  # two f64 rows in, two f32 rows + 400 f32 plan cells out, indices, flags
+            gbs = algb * batch / (ms * 1e-3) / 1e9
+            res[name] = {"kernel": "k_gather", "kernel_ms": ms, "samples_per_s": batch / (ms * 1e-3), "alg_bytes_per_sample": algb, "achieved_GBs": gbs,
+                         "frac": gbs / HBM_PEAK_GBS, "launches": reps, "note": "device time incl. the wrapper's own torch ops"}
+
+        def facade_cfg(name, steps=3000):
+            """The single-env drop-in class as a DQN script drives it (Env/2D/DMP_Env_2D_dynamic_usedata_plan.py: one env.step(action) per
+            loop turn, np.random step sizes, reset on done), host-timed: one launch + one wait per step.  The reference's own class does
+            110 k steps/s on one core of the build container: the drop-in classes are the PARITY surface -- a
+            script runs unchanged, at about half the reference's single-env rate -- and BatchedDMPEnv is the THROUGHPUT surface."""
+            import numpy as np
+
+            from snac_amd.envs import deep_mobile_printing_2d1r_dynamic
+
+            e = deep_mobile_printing_2d1r_dynamic("data_2d_dynamic_dense_envplan_500_train.pkl")
+            np.random.seed(1)
+            e.reset()
+            acts = np.random.RandomState(0).randint(0, 5, steps)
+            for i in range(200):
+                if e.step(int(acts[i]))[2]:
+                    e.reset()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                if e.step(int(acts[i]))[2]:
+                    e.reset()
+            rate = steps / (time.perf_counter() - t0)
+            res[name] = {"facade_steps_per_s": rate, "us_per_step": 1e6 / rate, "reference_steps_per_s_one_core": 110300.0,
+                         "note": "deep_mobile_printing_2d1r(data_path).step(a) of snac_amd.envs, one env, host-timed; reference figure: BASELINE.md section 2 "
+                                 "(measured in the build container, other CPU); the drop-in classes are the parity surface, BatchedDMPEnv the throughput surface"}
 
         def step_cfg(name, kind, nn, reps):
             e = BatchedDMPEnv(kind, True, nn, device=dev, seed=1)
@@ -544,7 +698,7 @@ def main():
             ms = timed(lambda: e.step(auto_reset=True, out=out), reps)
             algb = CONTRACT_BYTES[(kind, "f64")]
             gbs = algb * nn / (ms * 1e-3) / 1e9
-            res[name] = {"us_per_tick": ms * 1e3, "env_steps_per_s": nn / (ms * 1e-3), "alg_bytes_per_env_step": algb, "achieved_GBs": gbs,
+            res[name] = {"kernel": last_kernel(), "us_per_tick": ms * 1e3, "env_steps_per_s": nn / (ms * 1e-3), "alg_bytes_per_env_step": algb, "achieved_GBs": gbs,
                          "frac": gbs / HBM_PEAK_GBS, "launches": reps,
                          "note": "device time per tick, launches enqueued back to back" + ("" if nn >= 262144 else "; at this batch size the host's enqueue rate is part of it")}
 
@@ -553,9 +707,17 @@ def main():
                     "0.29 -> 0.05 ms); the pass writes only 187 MB and is bound by instruction issue (7.3 per env-step by the counters), not by the HBM rate")
         rollout_cfg("c5_3d_dynamic_n16384_T1000", 3, True, 16384, False, 24)
         rollout_cfg("headline_f32_obs", 2, True, 65536, True, 24)
+        # the headline on a table of 2000 GENERATED plans (snac_make_plans: what generate_plans() is for) and in the observation layout
+        # of the script/PPO env copies (451 values per row: window, counters, the 400 plan cells)
+        rollout_cfg("headline_2000_generated_plans", 2, True, 65536, False, 24, plans=2000)
+        rollout_cfg("headline_ppo_layout_451_values", 2, True, 65536, False, 6, layout="ppo", TT=60)
         for kind in (2, 3):
             for nn in (65536, 524288):
                 step_cfg("step_%dd_dynamic_n%d" % (kind, nn), kind, nn, 200)
+        for kind in (2, 3):
+            edges_cfg("transition_%dd_524288_edges" % kind, kind, 524288, 20)
+        gather_cfg("replay_gather_65536", 65536, 64, 65536, 20)
+        facade_cfg("facade_2d_dynamic_one_env")
         return res
 
     extras = None
@@ -601,10 +763,6 @@ def main():
                 traffic_source = "none: profiles/traffic.json belongs to kernel source %s, this library was built from %s" % (tj.get("source_sha16"), now)
         written = WRITTEN_BYTES[(args.kind, dkey)] * n * T / (kern_ms * 1e-3) / 1e9
         what = "%dD %s dense" % (args.kind, "dynamic" if dynamic else "static")
-        # the kernel this workload dispatches to (snac_hip.hip::launch): the staged 2D rollout, the block-cooperative 3D rollout (8-env tiles below 6144 envs; float32 rows: 4096), the
-        # time-parallel 1D rollout up to 49 152 envs (float32 rows: 65 536), the tile kernel otherwise
-        kernel_name = ("k_rollout3db" if n >= (4096 if args.obs_f32 else 6144) and n % 4 == 0 else "k_rollout3d") if args.kind == 3 else ("k_rollout1dt" if args.kind == 1 and n <= (65536 if args.obs_f32 else 49152) else
-                                                            ("k_rollout2d" if args.kind == 2 and n >= 65536 and n % 4 == 0 else "k_rollout"))
         out = {
             "metric": HEADLINE if headline else "env-steps/sec at N=%d envs (%s, %s obs); bit-exact vs CPU" % (n, what, dkey),
             "value": total_steps / dt,
@@ -641,8 +799,11 @@ def main():
             "ranks_devices": ranks_devices,                       # every rank's cuda:<local> PCI bus id: N ranks on N distinct GPUs
             "kernel_ms_per_step": [round(x, 4) for x in per_step_ms],   # rank 0's launches, in order
             "preroll_passes": preroll_passes,                     # untimed, before the W warm-up passes (clock ramp)
-            "trajectory_check": traj_ok,                          # obs[T - 1] == observe() after the timed passes, and:
+            "trajectory_check": traj_ok and all_ok,               # obs[T - 1] == observe() after the timed passes (every rank), and:
             "trajectory_full_pass_check": full_check,             # one more pass == the same pass by the tile kernel, all T x N rows
+            "parity_vs_oracle": parity_all,                       # reset + the first 10 ticks of a fresh pass into the measured block == the CPU oracle, byte for byte (every rank)
+            "per_rank": per_rank_report,                          # every rank's kernel time, trajectory block and checks
+            "ranks_on_distinct_devices": devices_ok,
             "placement": placement_report,                        # rank 0's choice among SNAC_BENCH_PLACE candidate tensors
             "tiled_layout": tiled,                                # rank 0, informational: the build's own trajectory layout
             "extra": {"configs": extras},                         # rank 0, one GPU: the other configs / dtypes / step(), driver-timed
@@ -656,7 +817,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if not traj_ok:
+    if not (traj_ok and all_ok and devices_ok) or parity_all is False:
         sys.exit(4)
 
 

@@ -155,6 +155,10 @@ typedef struct snac_state {
 
 int snac_version(void);
 const char* snac_last_error(void);
+/* name of the kernel the calling thread's last launch through this library went to ("k_rollout2d", "k_step3d", "k_rollout" for
+ * the tile kernels, ...): diagnostics -- which of the specialised kernels a call took depends on batch size, alignment, layout and
+ * the tuning switches, and a measurement should name what it measured (bench.py's roofline.kernel) */
+const char* snac_last_kernel(void);
 
 /* constants of (kind, dynamic); replaces the attribute reads of the reference constructors */
 int snac_env_sizes(int kind, int dynamic, snac_sizes* out);

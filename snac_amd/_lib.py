@@ -23,7 +23,7 @@ EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_obs_dim", 
            "snac_step_scalar", "snac_rollout",
            "snac_rollout_rec", "snac_replay_gather", "snac_make_plans", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
            "snac_import_state", "snac_obs_equal", "snac_stream_sync", "snac_rollout_tiled", "snac_replay_gather_tiled", "snac_traj_alloc",
-           "snac_traj_alloc_ex", "snac_traj_free", "snac_traj_layout", "snac_traj_describe", "snac_traj_reserved_bytes")
+           "snac_traj_alloc_ex", "snac_traj_free", "snac_traj_layout", "snac_traj_describe", "snac_traj_reserved_bytes", "snac_last_kernel")
 
 
 class Sizes(C.Structure):
@@ -89,6 +89,7 @@ def lib():
         vp = C.c_void_p
         L.snac_version.restype = C.c_int
         L.snac_last_error.restype = C.c_char_p
+        L.snac_last_kernel.restype = C.c_char_p
         L.snac_stream_sync.argtypes = [vp]
         L.snac_env_sizes.argtypes = [C.c_int, C.c_int, C.POINTER(Sizes)]
         L.snac_obs_dim.argtypes = [C.POINTER(EnvDesc)]

@@ -753,47 +753,43 @@ __device__ __forceinline__ void emit_tile(char* stg, char* g, int lane, int nenv
 //             two halves of 32 envs), read back 16 bytes per lane (ds_read_b128) and stored with global_store_dwordx4: 1 KiB per
 //             store instruction, 13 (f32) / 26 (f64) stores per wave-tick instead of 64.
 // Further differences from k_rollout, all outside the semantics (K2D::step's, tests compare both kernels with the CPU restatement):
-//   * the plan table (<= P2D_MAX rows) lies ONCE per block in LDS, with popcount and total_brick per row: a reset needs no global
-//     load (vmcnt is in-order: k_rollout's per-env plan reload waits for every row stored before it), a step reads its plan bit from
-//     the table;
+//   * every wave keeps its 64 lanes' CURRENT plan rows in LDS (pl[row * 65 + lane], 5 KB; a step reads its plan bit there), and an
+//     env that starts over on a new row has the row's 20 words and its total_brick fetched through the SCALAR cache (s_load counts
+//     in lgkmcnt, not vmcnt: k_rollout's per-env plan reload is a vector load and waits for every row stored before it) and written
+//     into its column by its own lane.  (Round 3 kept the whole table, <= 512 rows, in the block's LDS: 42 KB per block, nothing
+//     gained -- 2.314 against 2.310 ms per pass -- and tables from generate_plans() fell back to the tile kernel.)  Tables of any
+//     size take this kernel: 2000 rows 2.33 ms, 32 767 rows 2.42 (the rows then miss the scalar cache), profiles/r04_2d_table_ab.txt;
 //   * the boolean IoU (script/DQN/2d/DQN_2d_dynamic.py:63-71) is kept incrementally per lane -- |P and G| and |G| change by at most
 //     one per drop, |P or G| = |P| + |G| - |P and G| -- instead of a 20-row popcount loop whenever some env of the wave finishes;
 //   * cb / tb and cs / T by the exact reciprocal form of Roll3D (one division per episode instead of two per tick);
 //   * EXPL: the caller's action / step-size bytes of tick t + 1 are requested a tick ahead (their latency is hidden; the wait for
 //     them is still a `vmcnt(0)` across the loop's back edge, i.e. one drain of the rows per tick, as in the tile kernel).
 // Tiles of 64 envs -- N >= 65 536 (pick_tile), float32 rows already from N = 32 768 (launch()) --, N % 4 == 0 and a 16-byte aligned obs
-// (the 16-byte stores), canonical layout, every observation written (SNAC_OBS_ALL / SNAC_OBS_TILED), at most P2D_MAX plans:
-// everything else stays on k_rollout.
-constexpr int P2D_MAX = 512;
+// (the 16-byte stores), canonical layout, every observation written (SNAC_OBS_ALL / SNAC_OBS_TILED): everything else stays on
+// k_rollout.
+
+typedef const uint32_t __attribute__((address_space(4))) cmem_u32;   // constant address space: uniform addresses become s_load
 
 template <bool DYN, typename OT, int WPB, bool EXPL>
 __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
     using K = K2D<DYN, 64>;
     constexpr int E = 64, D = K::D, RS = K::RS, GE = K::GE;
     constexpr int IMG_WORDS = 26 * RS * 2;                           // the bordered two-bit image: 26 rows x 65 x 8 B
-    constexpr int WAVE_WORDS = IMG_WORDS + TILE_STG_BYTES / 4;       // + the staging tile of emit_tile
+    constexpr int PL_WORDS = (GE * 65 + 3) & ~3;                     // the lanes' plan rows [20][65]
+    constexpr int WAVE_WORDS = IMG_WORDS + TILE_STG_BYTES / 4 + PL_WORDS;   // + the staging tile of emit_tile
     static_assert(IMG_WORDS % 4 == 0 && WAVE_WORDS % 4 == 0, "16-byte aligned staging tiles");
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[P2D_MAX * GE + P2D_MAX + WPB * WAVE_WORDS];
-    uint32_t* const tab = lds_all;                                   // plan rows [P][20]
-    uint32_t* const meta = lds_all + P2D_MAX * GE;                   // per plan: popcount | total_brick << 16
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * WAVE_WORDS];
     const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
-    for (int i = (int)threadIdx.x; i < a.num_plans * GE; i += WPB * 64) tab[i] = ((const uint32_t*)a.plans)[i];
-    __syncthreads();
-    for (int p = (int)threadIdx.x; p < a.num_plans; p += WPB * 64) {
-        int cnt = 0;
-        for (int q = 0; q < GE; ++q) cnt += __popc(tab[p * GE + q]);
-        meta[p] = (uint32_t)cnt | ((uint32_t)(uint16_t)a.plan_tb[p] << 16);
-    }
-    __syncthreads();
     const int tile = (int)blockIdx.x * WPB + wv;
     const int env0 = __builtin_amdgcn_readfirstlane(tile * E);
-    if (env0 >= a.n) return;                                         // behind the block's barriers
+    if (env0 >= a.n) return;
     const int nenv = min(E, a.n - env0);
     const bool active = lane < nenv;
     const int env = env0 + (active ? lane : 0);
-    uint32_t* const lds = lds_all + P2D_MAX * GE + P2D_MAX + wv * WAVE_WORDS;
+    uint32_t* const lds = lds_all + wv * WAVE_WORDS;
     uint64_t* const cells = K::cells(lds);
     char* const stg = (char*)(lds + IMG_WORDS);
+    uint32_t* const pl = lds + IMG_WORDS + TILE_STG_BYTES / 4;
     Lane s;
     s.clear();
     s.r = 3; s.c = 3;                                                // idle lanes keep an in-range position and plan row 0
@@ -803,10 +799,13 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
     const uint64_t gid = (uint64_t)(a.env_id_base + env);
     const EnvKeys sk = env_keys(a.key_step, gid), pk = env_keys(a.key_plan, gid);
     // |P|, |G|, |P and G| of the lane's env as the launch finds them
-    int pcnt = (int)(meta[s.pidx] & 0xffffu), gcnt = 0, inter = 0;
-    if (active) {
+    int pcnt = 0, gcnt = 0, inter = 0;
+    {
+        const uint32_t* const prow = (const uint32_t*)a.plans + (size_t)s.pidx * GE;   // (idle lanes: row 0)
         for (int q = 0; q < GE; ++q) {
-            const uint32_t g = K::decode_row(cells[(q + 3) * RS + lane]), p = tab[s.pidx * GE + q];
+            const uint32_t p = prow[q];
+            pl[q * 65 + lane] = p; pcnt += __popc(p);
+            const uint32_t g = active ? K::decode_row(cells[(q + 3) * RS + lane]) : 0u;
             gcnt += __popc(g); inter += __popc(g & p);
         }
     }
@@ -827,19 +826,35 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
         const size_t row = (size_t)t * (size_t)a.n + (size_t)env0;
         const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
         if (__builtin_expect(__any(nr), 0)) {                        // rare, out of line
+            bool fresh = false;                                      // a new plan row (K2D::reset: it brings its total_brick; the same row keeps the header's)
             if (nr) {
                 const int old_pidx = s.pidx;
                 episode += 1;
                 const int pidx = pick_plan<K>(a, pk, episode, old_pidx);
-                if (pidx != old_pidx) {                              // K2D::reset: a new row brings its total_brick, the same row keeps the header's
-                    const uint32_t m = meta[pidx];
-                    s.pidx = pidx; s.tb = (int)(int16_t)(m >> 16); pcnt = (int)(m & 0xffffu);
-                    dtb = (double)s.tb; rtb = 1.0 / dtb;
-                }
+                if (pidx != old_pidx) { fresh = true; s.pidx = pidx; }
                 s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
                 gcnt = 0; inter = 0;
             }
             for (unsigned long long m = __ballot(nr); m; m &= m - 1) K::clear(lds, __ffsll(m) - 1, lane);
+            for (unsigned long long m = __ballot(fresh); m; m &= m - 1) {
+                const int e = __ffsll(m) - 1;
+                const int pe = __builtin_amdgcn_readlane(s.pidx, e);   // wave-uniform: the row and its total_brick come through the scalar cache
+                cmem_u32* const src = (cmem_u32*)(uintptr_t)a.plans + (size_t)pe * GE;
+                cmem_u32* const tbw = (cmem_u32*)(uintptr_t)a.plan_tb + (pe >> 1);
+                uint32_t rw[GE];
+#pragma unroll
+                for (int q = 0; q < GE; ++q) rw[q] = src[q];
+                const int tbv = (int)(int16_t)((*tbw) >> ((pe & 1) * 16));
+                int pc = 0;
+#pragma unroll
+                for (int q = 0; q < GE; ++q) pc += __popc(rw[q]);
+                if (lane == e) {
+#pragma unroll
+                    for (int q = 0; q < GE; ++q) pl[q * 65 + lane] = rw[q];
+                    s.tb = tbv; pcnt = pc;
+                    dtb = (double)tbv; rtb = 1.0 / dtb;
+                }
+            }
         }
         // ---- phase 1: K2D::step (DMP_Env_2D_dynamic_usedata_plan.py:85-147), plan bit from the block's table
         const uint32_t w32 = rng_word(sk, a.t0 + (uint32_t)t);
@@ -856,7 +871,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
         const uint64_t w = *cw;
         const int off = 2 * s.c;
         const bool was = ((w >> off) & 1ull) != 0ull;
-        const bool planned = ((tab[s.pidx * GE + (s.r - 3)] >> (s.c - 3)) & 1u) != 0u;
+        const bool planned = ((pl[(s.r - 3) * 65 + lane] >> (s.c - 3)) & 1u) != 0u;
         const bool first = s.cs == 0;
         const bool drop = act == 4;
         s.cs = min(s.cs + 1, CNT_MAX);
@@ -3054,7 +3069,7 @@ bool stage2d_off() {
     return off;
 }
 bool roll2d_ok(const KArgs& a, int E) {
-    return E == 64 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= P2D_MAX &&
+    return E == 64 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) &&
            (a.n & 3) == 0 && ((uintptr_t)a.obs & 15) == 0 && !pipeline_off() && !stage2d_off();
 }
 template <bool DYN, typename OT>
@@ -3157,27 +3172,33 @@ void launch_tile(Op op, bool dyn, int E, int obs_dtype, const KArgs& a, hipStrea
     else dyn ? launch_dt<KT, true, 8, 1>(op, obs_dtype, a, s) : launch_dt<KT, false, 8, 1>(op, obs_dtype, a, s);
 }
 
+// which kernel the calling thread's last launch went to (snac_last_kernel(): bench.py and the tests name the kernel they measured
+// from here instead of restating the conditions below)
+thread_local const char* g_kernel = "";
+
 int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool dyn = d->dynamic != 0;
     const int E = pick_tile(d->kind, a.n);
+    const char* const tile_name = op == OP_ROLLOUT ? "k_rollout" : (op == OP_TRANSITION ? "k_transition" : "k_aux");
+    g_kernel = tile_name;
     switch (d->kind) {
         case SNAC_ENV_1D:
             // rollouts that write every row: the time-parallel kernel while its rate beats the tile kernel's (lane-per-env transition)
-            if (op == OP_ROLLOUT && roll1dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { launch_roll1dt(d, a, s); break; }
+            if (op == OP_ROLLOUT && roll1dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout1dt"; launch_roll1dt(d, a, s); break; }
             launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D:
-            if (op == OP_TRANSITION && !a.variant && !pipeline_off() && step_stage_ok(a)) { launch_step_tile<2>(d, a, s); break; }
-            if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans2d(d, a, s); break; }
+            if (op == OP_TRANSITION && !a.variant && !pipeline_off() && step_stage_ok(a)) { g_kernel = "k_step2d"; launch_step_tile<2>(d, a, s); break; }
+            if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { g_kernel = "k_transition2d"; launch_trans2d(d, a, s); break; }
             // float32 rows from N = 32 768: 512 staged waves (1.05 -> 0.74 ms per 600 ticks); float64 rows there are level (1.26-1.60 ms
             // by box for either kernel) and stay on 32-env tiles
-            if (op == OP_ROLLOUT && roll2d_ok(a, (d->obs_dtype == SNAC_OBS_F32 && a.n >= 32768) ? 64 : E)) { launch_roll2d(d, a, s); break; }
+            if (op == OP_ROLLOUT && roll2d_ok(a, (d->obs_dtype == SNAC_OBS_F32 && a.n >= 32768) ? 64 : E)) { g_kernel = "k_rollout2d"; launch_roll2d(d, a, s); break; }
             launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
-            if (op == OP_ROLLOUT && roll3db_ok(a, d->obs_dtype == SNAC_OBS_F32)) { launch_roll3db(d, a, s); break; }
-            if (op == OP_ROLLOUT && E == 8 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && !pipeline_off()) { launch_roll3d(d, a, s); break; }
-            if (op == OP_TRANSITION && !a.variant && !pipeline_off() && step_stage_ok(a)) { launch_step_tile<3>(d, a, s); break; }
-            if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { launch_trans3d(d, a, s); break; }
+            if (op == OP_ROLLOUT && roll3db_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout3db"; launch_roll3db(d, a, s); break; }
+            if (op == OP_ROLLOUT && E == 8 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && !pipeline_off()) { g_kernel = "k_rollout3d"; launch_roll3d(d, a, s); break; }
+            if (op == OP_TRANSITION && !a.variant && !pipeline_off() && step_stage_ok(a)) { g_kernel = "k_step3d"; launch_step_tile<3>(d, a, s); break; }
+            if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { g_kernel = "k_transition3d"; launch_trans3d(d, a, s); break; }
             if (E == 8 && a.n < 8192) dyn ? launch_dt<K3D, true, 8, 1>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 1>(op, d->obs_dtype, a, s);
             else if (E == 8) dyn ? launch_dt<K3D, true, 8, 4>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 4>(op, d->obs_dtype, a, s);
             else dyn ? launch_dt<K3D, true, 16, 2>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 16, 2>(op, d->obs_dtype, a, s);
@@ -3196,6 +3217,8 @@ extern "C" {
 int snac_version(void) { return SNAC_ABI_VERSION; }
 
 const char* snac_last_error(void) { return g_err; }
+
+const char* snac_last_kernel(void) { return g_kernel; }
 
 int snac_stream_sync(void* stream) {
     const hipError_t e = hipStreamSynchronize((hipStream_t)stream);

@@ -26,8 +26,9 @@ def fastest_tensor(shape, dtype, device, run, candidates=6, reps=3, min_bytes=1 
     for d in shape:
         numel *= int(d)
     if numel * torch.empty((), dtype=dtype).element_size() < min_bytes:
-        return alloc(shape, dtype, device), {"candidates_ms": [], "chosen": 0}
-    held, times = [], []
+        t = alloc(shape, dtype, device)
+        return t, {"candidates_ms": [], "chosen": 0, "blocks": [_describe(t)]}
+    held, times, notes = [], [], []
     for _ in range(max(1, int(candidates))):
         try:
             t = alloc(shape, dtype, device)
@@ -55,19 +56,32 @@ def fastest_tensor(shape, dtype, device, run, candidates=6, reps=3, min_bytes=1 
             ms = a.elapsed_time(b)
             best = ms if best is None else min(best, ms)
         times.append(best)
+        notes.append(_describe(t))
     if not held:
         raise RuntimeError("no candidate tensor of shape %s could be allocated" % (tuple(shape),))
     i = min(range(len(times)), key=times.__getitem__)
     chosen = held[i]
     del held, t
     torch.cuda.empty_cache()                                       # the other candidates go back to the driver
-    rep = {"candidates_ms": [round(x, 4) for x in times], "chosen": i}
-    try:                                                           # how the chosen tensor is backed, when it is a snac_traj_alloc block
+    # single_block_ms: what a caller who takes the FIRST allocation gets (candidates=1) -- the spread between this and the best is
+    # what placement buys; `blocks`: every candidate's own description (snac_traj_describe: layout, the allocator's microseconds per
+    # GiB for the whole block and its slowest window, rebuilds), so a slow candidate explains itself
+    rep = {"candidates_ms": [round(x, 4) for x in times], "chosen": i, "single_block_ms": round(times[0], 4), "blocks": notes}
+    if notes[i] and notes[i].get("layout"):
+        rep["layout"] = notes[i]["layout"]
+    return chosen, rep
+
+
+def _describe(t):
+    """The allocator's own account of the block under `t`, condensed (None for hipMalloc tensors)."""
+    try:
         from . import trajmem
 
-        lay = trajmem.layout_of(chosen)
-        if lay:
-            rep["layout"] = lay
+        d = trajmem.describe(t)
     except Exception:
-        pass
-    return chosen, rep
+        return None
+    if not d:
+        return None
+    u = d["us_per_gib"]
+    return {"layout": d["layout"], "rebuilds": d["rebuilds"], "pool_groups": d["pool_groups"], "probe_launches": d["probe_launches"],
+            "build_ms": d["build_ms"], "windows_slow": d["windows_slow"], "us_per_gib": {k: u[k] for k in ("fast", "slow", "block", "window_max")}}

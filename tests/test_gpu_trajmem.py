@@ -191,3 +191,40 @@ def test_pool_cap_bounds_what_the_measurement_holds():
     assert trajmem.layout_of(blk) == "three runs 32 GiB apart"
     blk.fill_(7)
     assert int(blk[-1].item()) == 7 and int(blk[::1 << 20].sum().item()) == 7 * ((blk.numel() + (1 << 20) - 1) >> 20)
+
+
+def test_measured_blocks_run_the_headline_rollout_at_the_fast_level_every_time():
+    """Four headline-sized blocks allocated, rolled into and freed in turn: every one must take the headline pass (65 536 envs x 600
+    ticks, float64 rows) at the two-slice level -- within 4 % of the fastest of the four and in at most 2.45 ms -- and say so in its
+    own description (snac_traj_describe: no slow window, the whole block within 5 % of the box's fast level).  Round 3 handed out
+    'measured' blocks that ran 18-24 % slow in half of the cases on some boxes: only their first GiB had been timed."""
+    import torch
+    from snac_amd import BatchedDMPEnv, trajmem
+
+    n, T = 65536, 600
+    env = BatchedDMPEnv(2, True, n, seed=1)
+    env.reset()
+    times, infos = [], []
+    for _ in range(4):
+        buf = trajmem.traj_empty((T, n, env.obs_dim), torch.float64, "cuda")
+        d = trajmem.describe(buf)
+        for _ in range(12):
+            env.rollout(T, obs="all", out=buf, want_reward=False, want_done=False)
+        ev = []
+        for _ in range(7):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            env.rollout(T, obs="all", out=buf, want_reward=False, want_done=False)
+            b.record()
+            ev.append((a, b))
+        torch.cuda.synchronize()
+        times.append(sorted(a.elapsed_time(b) for a, b in ev)[3])
+        infos.append(d)
+        del buf
+    for ms, d in zip(times, infos):
+        assert d["layout"] == "measured: two slices in turn", d
+        assert d["windows_slow"] == 0 and d["us_per_gib"]["block"] <= 1.05 * d["us_per_gib"]["fast"], d
+        assert len(d["us_per_gib"]["windows"]) == 15 and max(d["us_per_gib"]["windows"]) <= 1.08 * d["us_per_gib"]["fast"] + 0.5, d
+    assert max(times) <= 1.04 * min(times), (times, infos)
+    assert max(times) <= 2.45, (times, infos)
+    assert trajmem.reserved_bytes() > 0

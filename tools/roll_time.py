@@ -22,7 +22,17 @@ def main():
     dt = torch.float32 if (len(sys.argv) > 5 and sys.argv[5] == "f32") else torch.float64
     mem = sys.argv[6] if len(sys.argv) > 6 else "vmm"
     tiled = len(sys.argv) > 7 and sys.argv[7] == "tiled"
-    env = BatchedDMPEnv(kind, True, n, seed=1, obs_dtype=dt)
+    P = int(os.environ.get("SNAC_ROLL_PLANS", "0"))              # > 0: a table of P generated plans instead of the 400 stored ones
+    layout = os.environ.get("SNAC_ROLL_LAYOUT") or None          # ppo | lnet2d | lnet1d: the layout variants of the descriptor
+    kw = {}
+    if P:
+        import numpy as np
+        kw["plans"] = np.zeros((P, 30) if kind == 1 else (P, 26, 26)) + (20 if kind == 1 else 0)
+    if layout:
+        kw["layout"] = layout
+    env = BatchedDMPEnv(kind, True, n, seed=1, obs_dtype=dt, **kw)
+    if P:
+        env.generate_plans(0, P, seed=5)
     env.reset()
     T = T or env.total_step
     shape = ((n + 63) // 64, T, 64, env.obs_dim) if tiled else (T, n, env.obs_dim)
@@ -46,8 +56,9 @@ def main():
     esz = 4 if dt == torch.float32 else 8
     wb = (env.obs_dim * esz + 5) * n * T
     med = t[len(t) // 2]
-    print("%dD N=%d T=%d %s %s%s stage=%s: min %.3f  median %.3f ms   %.2f TB/s written   %.3e env-steps/s" % (
-        kind, n, T, "f32" if esz == 4 else "f64", mem, " tiled" if tiled else "", os.environ.get("SNAC_2D_STAGE", "1"), t[0], med,
+    print("%dD N=%d T=%d %s %s%s stage=%s table=%s plans=%d layout=%s (%d values): min %.3f  median %.3f ms   %.2f TB/s written   %.3e env-steps/s" % (
+        kind, n, T, "f32" if esz == 4 else "f64", mem, " tiled" if tiled else "", os.environ.get("SNAC_2D_STAGE", "1"),
+        os.environ.get("SNAC_2D_TABLE", "-"), env.num_plans, layout, env.obs_dim, t[0], med,
         wb / med / 1e9, n * T / med * 1e3), flush=True)
 
 
