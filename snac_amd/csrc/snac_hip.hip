@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -740,6 +741,141 @@ __device__ __forceinline__ void emit_tile(char* stg, char* g, int lane, int nenv
     }
 }
 
+// The same for the layout variants of snac_env_desc (rows of LD = 51 + tail values: 451 for the script/PPO dataset copies, 59 with the
+// record tail, ...).  A tile's rows of one step are still ONE contiguous run of 64 * LD values, 16-byte aligned as a whole (the callers
+// require N % 4 == 0), so it is staged and flushed in GROUPS of G envs -- the largest power of two whose rows fit the staging tile (a
+// multiple of 16 bytes for every LD: G >= 2 with float64, >= 4 with float32).  With 451-value rows a group is two or four envs, so
+// nothing may be done "by the lanes of the group's envs" (a first version did, and repeated the window decode 32 times per tick: 3.4 ms
+// per 60 ticks, 0.52 of the peak).  Instead every lane FILES what it holds once per tick in a compact record (cmp[lane][19]: the 7
+// window row codes, the two scalar slots, reward / done / position / counters / plan row), and a row is assembled by the whole wave,
+// lane = value: lanes 0..48 decode a window cell, 49 / 50 take the scalar slots, the next ones the position / record values, and for
+// the plan tail lane = plan cell (+ 64 i), read from the wave's plan rows in LDS.  The group then leaves 16 bytes per lane, 1 KiB per
+// store instruction.
+constexpr int VAR_CMP_WORDS = 19;                                    // per env: 7 + 4 + 8 dwords (odd: conflict-free)
+
+constexpr int VAR_STG_BYTES = 15 * 1024;                              // its staging tile: four 451-value float64 rows (14 432 B)
+
+// 0 / 1 as OT without a conversion instruction: the value's bit pattern is a mask of the constant 1.0
+template <typename OT>
+__device__ __forceinline__ OT bit_as(uint32_t word, int bit) {
+    const int m = ((int)(word << (31 - bit))) >> 31;                 // 0 or -1
+    if constexpr (sizeof(OT) == 8) return (OT)__hiloint2double(m & 0x3FF00000, 0);
+    else return (OT)__int_as_float(m & 0x3F800000);
+}
+
+template <typename OT, class PF>
+__device__ __forceinline__ void emit_rows_var(char* stg, uint32_t* cmp, char* g, int lane, int nenv, int LD, int tail, int frame_val,
+                                              const uint32_t (&wr)[7], double v0, double v1, const int (&recv)[8], PF plan) {
+    constexpr int D = 51, W = 49;
+    const int RB = LD * (int)sizeof(OT);
+    int G = 64;
+    while (G * RB > VAR_STG_BYTES) G >>= 1;
+    const int pos_n = (tail & SNAC_TAIL_POSITION) ? 2 : 0, plan_n = (tail & SNAC_TAIL_PLAN) ? 400 : 0, rec_n = (tail & SNAC_TAIL_RECORD) ? 8 : 0;
+    const int NE = D + pos_n + rec_n;                                // values of a row that come from the compact record (<= 61)
+    {
+        uint32_t* const mine = cmp + lane * VAR_CMP_WORDS;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) mine[i] = wr[i];
+        const uint64_t b0 = (uint64_t)__double_as_longlong(v0), b1 = (uint64_t)__double_as_longlong(v1);
+        mine[7] = (uint32_t)b0; mine[8] = (uint32_t)(b0 >> 32); mine[9] = (uint32_t)b1; mine[10] = (uint32_t)(b1 >> 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mine[11 + j] = (uint32_t)recv[j];
+    }
+    // what THIS lane contributes to every row: source dword in the compact record, kind (0 window cell, 1 scalar slot, 2 integer), place in the row
+    int src, kind, sh = 0, dst = lane;
+    if (lane < W) { src = lane / 7; sh = 30 - 2 * (lane - 7 * src); kind = 0; }
+    else if (lane < D) { src = 7 + 2 * (lane - W); kind = 1; }
+    else {
+        int k = lane - D;
+        kind = 2;
+        if (k < pos_n) { src = 11 + 2 + k; dst = D + k; }            // position: record values 2, 3
+        else { k -= pos_n; src = 11 + min(k, 7); dst = D + pos_n + plan_n + k; }
+    }
+    // the plan cells this lane fills in: cell lane + 64 i of every env -> plan row and bit (the same for every env and tick)
+    int prow[7], pbit[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const int pc = min(lane + 64 * i, 399); prow[i] = pc / 20; pbit[i] = pc - 20 * prow[i]; }
+    // U envs at a time, every LDS read of the batch issued before its first write: the compiler cannot tell the staging rows from the
+    // records and the plan rows, and one env per round trip made a tick latency-bound (64 round trips: 11 instead of 4.6 us per tick)
+    auto batch = [&](auto uc, int e, int e0) {
+        constexpr int U = decltype(uc)::value;
+        uint32_t lo[U], hi[U], pw[U][7];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t* const c = cmp + (e + u) * VAR_CMP_WORDS + src;
+            lo[u] = c[0]; hi[u] = c[1];                              // (src + 1 <= 18: inside the record)
+            if (plan_n) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) pw[u][i] = plan(e + u, prow[i]);
+            }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cv = ((int)(lo[u] << sh)) >> 30;               // signed 2-bit field: 0 / 1 / -1
+            const double val = kind == 0 ? (double)(cv < 0 ? frame_val : cv)
+                                         : (kind == 1 ? __longlong_as_double((long long)(((uint64_t)hi[u] << 32) | lo[u])) : (double)(int)lo[u]);
+            OT* const row = (OT*)stg + (e + u - e0) * LD;
+            if (lane < NE) row[dst] = (OT)val;
+            if (plan_n) {
+                OT* const q = row + D + pos_n;
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    if (i < 6 || lane < 16) q[lane + 64 * i] = bit_as<OT>(pw[u][i], pbit[i]);
+            }
+        }
+    };
+    for (int e0 = 0; e0 < nenv; e0 += G) {
+        const int ge = min(G, nenv - e0);                            // a multiple of 2 (float64) / 4 (float32): N % 4 == 0
+        if (G >= 16) {
+            // short rows (no plan tail: 51 .. 61 values): a group is 16 or more envs, and the transposition of emit_tile is the cheaper
+            // form -- the lanes of the group's envs write their own values (0.28 against 0.70 ms per 60 ticks for the 51-value L-Net rows)
+            if (lane >= e0 && lane < e0 + ge) {
+                OT* const S = (OT*)stg + (lane - e0) * LD;
+#pragma unroll
+                for (int el = 0; el < W; ++el) {
+                    const int i = el / 7, j = el - 7 * i;
+                    const int v = ((int)(wr[i] << (30 - 2 * j))) >> 30;
+                    S[el] = (OT)(v < 0 ? frame_val : v);
+                }
+                S[W] = (OT)v0; S[W + 1] = (OT)v1;
+                OT* q = S + D;
+                if (pos_n) { q[0] = (OT)recv[2]; q[1] = (OT)recv[3]; q += 2; }
+                if (rec_n) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) q[j] = (OT)recv[j];
+                }
+            }
+        } else {
+            int e = e0;
+            for (; e + 8 <= e0 + ge; e += 8) batch(std::integral_constant<int, 8>{}, e, e0);
+            for (; e + 2 <= e0 + ge; e += 2) batch(std::integral_constant<int, 2>{}, e, e0);
+        }
+        const int valid = ge * RB;                                   // a multiple of 16
+        char* const gh = g + (size_t)e0 * RB + lane * 16;
+        const char* const sh = stg + lane * 16;
+        const int full = valid >> 10, rest = valid & 1023;           // whole 1 KiB store instructions (wave-uniform), bytes of the last one
+        int i = 0;
+        for (; i + 4 <= full; i += 4) {                              // four at a time, their LDS reads issued first
+            uint4 fv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fv[k] = *(const uint4*)(sh + (i + k) * 1024);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(uint4*)(gh + (i + k) * 1024) = fv[k];
+        }
+        {
+            uint4 fv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fv[k] = *(const uint4*)(stg + min((i + k) * 1024 + lane * 16, VAR_STG_BYTES - 16));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i + k < full) *(uint4*)(gh + (i + k) * 1024) = fv[k];
+                else if (i + k == full && lane * 16 < rest) *(uint4*)(gh + (i + k) * 1024) = fv[k];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2D fused rollout for full-width tiles (round 3; the headline kernel).  k_rollout's phase 2 builds ONE observation row per
 // wave-instruction -- lanes 0..50 each fetch a cell of the same env -- so a wave-tick of 64 envs costs 64 x ~12 instructions and 64
@@ -770,13 +906,15 @@ __device__ __forceinline__ void emit_tile(char* stg, char* g, int lane, int nenv
 
 typedef const uint32_t __attribute__((address_space(4))) cmem_u32;   // constant address space: uniform addresses become s_load
 
-template <bool DYN, typename OT, int WPB, bool EXPL>
+template <bool DYN, typename OT, int WPB, bool EXPL, bool VAR>
 __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
     using K = K2D<DYN, 64>;
     constexpr int E = 64, D = K::D, RS = K::RS, GE = K::GE;
     constexpr int IMG_WORDS = 26 * RS * 2;                           // the bordered two-bit image: 26 rows x 65 x 8 B
     constexpr int PL_WORDS = (GE * 65 + 3) & ~3;                     // the lanes' plan rows [20][65]
-    constexpr int WAVE_WORDS = IMG_WORDS + TILE_STG_BYTES / 4 + PL_WORDS;   // + the staging tile of emit_tile
+    constexpr int CMP_WORDS = VAR ? E * VAR_CMP_WORDS : 0;           // layout variants: the compact records of emit_rows_var
+    constexpr int STG_WORDS = (VAR ? VAR_STG_BYTES : TILE_STG_BYTES) / 4;
+    constexpr int WAVE_WORDS = IMG_WORDS + STG_WORDS + PL_WORDS + CMP_WORDS;   // + the staging tile of emit_tile / emit_rows_var
     static_assert(IMG_WORDS % 4 == 0 && WAVE_WORDS % 4 == 0, "16-byte aligned staging tiles");
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * WAVE_WORDS];
     const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
@@ -789,7 +927,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
     uint32_t* const lds = lds_all + wv * WAVE_WORDS;
     uint64_t* const cells = K::cells(lds);
     char* const stg = (char*)(lds + IMG_WORDS);
-    uint32_t* const pl = lds + IMG_WORDS + TILE_STG_BYTES / 4;
+    uint32_t* const pl = lds + IMG_WORDS + STG_WORDS;
     Lane s;
     s.clear();
     s.r = 3; s.c = 3;                                                // idle lanes keep an in-range position and plan row 0
@@ -815,8 +953,9 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
     long long d_iou = 0;
     // this tile's first byte of step 0, and the distance to the same place one step later: [T][N][D], or tile-major
     const bool tl = a.obs_mode == SNAC_OBS_TILED;
-    char* const obs0 = (char*)a.obs + (tl ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)a.tiled_t0) * 64 * D : (size_t)env0 * D) * sizeof(OT);
-    const size_t tstride = (tl ? (size_t)64 * D : (size_t)a.n * D) * sizeof(OT);
+    const int LD = VAR ? a.ld : D;                                   // values per row: the layout variants append a tail
+    char* const obs0 = (char*)a.obs + (tl ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)a.tiled_t0) * 64 * LD : (size_t)env0 * LD) * sizeof(OT);
+    const size_t tstride = (tl ? (size_t)64 * LD : (size_t)a.n * LD) * sizeof(OT);
     int na = 0, nk = 1;                                              // EXPL: the bytes of the coming tick
     if constexpr (EXPL) {
         if (active && a.actions) na = (int)a.actions[(size_t)env0 + lane];
@@ -913,7 +1052,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
             for (int i = 0; i < 7; ++i) wr[i] = (uint32_t)(wp[i * RS] >> sh);
         }
         double v0 = (double)s.cb, v1 = (double)s.cs;
-        if (DYN) {                                                   // cb / tb, cs / T: correctly rounded (Roll3D, tests/native/recip_check.c)
+        if (VAR ? (a.sc_norm != 0) : DYN) {                          // cb / tb, cs / T: correctly rounded (Roll3D, tests/native/recip_check.c)
             const double c0 = v0, c1 = v1, q0 = c0 * rtb, q1 = c1 * rT;
             v0 = __builtin_fma(__builtin_fma(-q0, dtb, c0), rtb, q0);
             v1 = __builtin_fma(__builtin_fma(-q1, dT, c1), rT, q1);
@@ -922,9 +1061,15 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
                 v0 = c0 / dtb;
             }
         }
-        emit_tile<OT>(stg, obs0 + (size_t)t * tstride, lane, nenv,
-                      [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; },   // signed 2-bit field: 0 / 1 / -1
-                      v0, v1);
+        if constexpr (VAR) {
+            const int recv[8] = {reward, done ? 1 : 0, s.r, s.c, s.cb, s.cs, s.tb, s.pidx};   // SNAC_TAIL_RECORD's values (record_value)
+            emit_rows_var<OT>(stg, pl + PL_WORDS, obs0 + (size_t)t * tstride, lane, nenv, LD, a.tail, a.frame_val, wr, v0, v1, recv,
+                              [&](int e, int row) { return pl[row * 65 + e]; });
+        } else {
+            emit_tile<OT>(stg, obs0 + (size_t)t * tstride, lane, nenv,
+                          [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; },   // signed 2-bit field: 0 / 1 / -1
+                          v0, v1);
+        }
     }
     K::store_grid(lds, a, env0, nenv, lane);
     if (active) {
@@ -3069,15 +3214,22 @@ bool stage2d_off() {
     return off;
 }
 bool roll2d_ok(const KArgs& a, int E) {
-    return E == 64 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) &&
+    return E == 64 && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) &&
            (a.n & 3) == 0 && ((uintptr_t)a.obs & 15) == 0 && !pipeline_off() && !stage2d_off();
 }
 template <bool DYN, typename OT>
 void launch_roll2d_w(const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + 63) / 64;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout2d<DYN, OT, 4, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_rollout2d<DYN, OT, 4, false>), grid, block, 0, s, a);
+    // the layout variants (a.variant: frame value, scalar form, row tail) are their own instantiations
+    const bool expl = a.actions || a.step_size;
+    if (a.variant) {
+        if (expl) hipLaunchKernelGGL((k_rollout2d<DYN, OT, 4, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_rollout2d<DYN, OT, 4, false, true>), grid, block, 0, s, a);
+    } else {
+        if (expl) hipLaunchKernelGGL((k_rollout2d<DYN, OT, 4, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_rollout2d<DYN, OT, 4, false, false>), grid, block, 0, s, a);
+    }
 }
 void launch_roll2d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;

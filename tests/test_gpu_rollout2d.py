@@ -211,3 +211,71 @@ def test_a_full_episode_length_on_a_generated_table_of_2000_plans():
     _compare(env, orc, 100, 0)
     _compare(env, orc, 20, 100)
     _end_state(env, orc)
+
+
+def _last_kernel():
+    from snac_amd import _lib
+
+    return _lib.lib().snac_last_kernel().decode()
+
+
+VARIANTS = [
+    dict(layout="lnet2d"),                                           # 51 + position, frame value 2, normalised scalars on a static plan
+    dict(layout="ppo"),                                              # 451 values: window, raw counters, the 400 plan cells
+    dict(obs_tail=("record",)),                                      # 59
+    dict(obs_tail=("position", "plan", "record"), frame_value=2, obs_scalars="raw"),   # 461
+]
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("kw", VARIANTS, ids=["lnet2d", "ppo", "record", "all"])
+def test_layout_variants_on_the_staged_kernel(kw, f32):
+    """The observation layouts of the reference's env copies (frame value 2, raw / normalised counters, position / plan / record
+    tails: snac_env_desc.frame_value / obs_scalars / obs_tail) no longer fall back to the tile kernel at N >= 65 536: rows of any
+    length leave through the staging tile in groups of envs.  Against the oracle configured the same way -- a ragged last tile, time
+    limit 4 (every env starts over, on a new plan row, in every launch of 5), explicit inputs -- and, for a longer launch, against the
+    tile kernel's rows for a twin of the batch (an output that is not 16-byte aligned forces it), compared on the device."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    dyn = kw.get("layout") != "lnet2d"
+    n = N0 + 36
+    table = helpers.plan_table(2, dyn, "dense_train" if dyn else "p0")
+    dt = torch.float32 if f32 else torch.float64
+    env = BatchedDMPEnv(2, dyn, n, plans=table.reshape(len(table), 26, 26), seed=4, total_step=4, obs_dtype=dt, **kw)
+    orc = helpers.oracle().OracleBatch(2, dyn, n, table, seed=4)
+    norm = {None: dyn, "raw": False, "norm": True}[env.obs_scalars]
+    orc.configure(obs_norm=norm, frame=env.frame_value, tail=env.obs_tail)
+    orc.set_total_step(4)
+    cast = (lambda x: x.astype(np.float32)) if f32 else (lambda x: x)
+    assert env.reset().cpu().numpy().tobytes() == cast(orc.reset()).tobytes()
+    t0 = 0
+    for T in (1, 5, 2):
+        og, rg, dg = env.rollout(T)
+        assert _last_kernel() == "k_rollout2d"
+        oc, rc, dc = orc.rollout(T, t0=t0, nthreads=16)
+        assert og.cpu().numpy().tobytes() == cast(oc).tobytes(), "observations"
+        assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+        t0 += T
+    rng = np.random.default_rng(1)
+    acts, ks = rng.integers(0, 5, size=(3, n)).astype(np.int8), rng.integers(1, 4, size=(3, n)).astype(np.int8)
+    og, rg, dg = env.rollout(3, actions=torch.from_numpy(acts).to(env.device), step_size=torch.from_numpy(ks).to(env.device))
+    oc, rc, dc = orc.rollout(3, t0=t0, actions=acts, step_size=ks, nthreads=16)
+    assert og.cpu().numpy().tobytes() == cast(oc).tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes()
+    del og, oc
+    # a longer launch against the tile kernel, on the device
+    twin = env.fork(torch.arange(n, device=env.device))
+    T = 16
+    o1, r1, d1 = env.rollout(T)
+    assert _last_kernel() == "k_rollout2d"
+    raw = torch.empty(T * n * env.obs_dim + 1, dtype=dt, device=env.device)
+    o2, r2, d2 = twin.rollout(T, out=raw[1:].view(T, n, env.obs_dim))
+    assert _last_kernel() == "k_rollout" and o2.data_ptr() % 16 != 0
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    assert torch.equal(env._hdr, twin._hdr) and torch.equal(env._grid, twin._grid)
+    # tile-major output of the same layout
+    tw2 = env.fork(torch.arange(n, device=env.device))
+    ot, _, _ = env.rollout(3, obs="tiled")
+    assert _last_kernel() == "k_rollout2d"
+    on, _, _ = tw2.rollout(3)
+    assert torch.equal(env.untile(ot), on)
