@@ -1982,6 +1982,323 @@ __global__ __launch_bounds__(EB * 64, 16 / EB) void k_rollout1dt(const KArgs a) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2D fused rollout, TIME-parallel (round 4) -- the small-batch counterpart of k_rollout2d.  Below ~16 000 envs every 2D rollout kernel
+// is bound by the chain of its ticks (0.5-0.7 ms per 600 ticks whatever N: one wave walks 600 dependent steps), and that is the range
+// the reference is used in (multiprocess.py:96: --num_envs 3; every script/* drives one env).  In 2D, too, the CONTROL of an episode
+// depends on the actions alone (DMP_Env_2D_dynamic_usedata_plan.py:85-147: moves only clamp, a drop never moves, count_step counts
+// ticks, count_brick counts drops), so one wavefront takes ONE env and 64 consecutive ticks, lane j = tick t0 + j, as k_rollout1dt:
+//   counters   count_step / count_brick by lane index and drop-ballot prefix; done = the first lane whose counters say so; the lanes up
+//              to it are a segment, the rest of the chunk a second one behind the reset (wave-uniform state);
+//   position   row and column are two chains of x -> min(max(x + d, 3), 22): two inclusive DPP scans of the composed clamps;
+//   the board  at the chunk's start: 20 row words in LDS.  A tick's window = those rows OR the bricks dropped earlier in the chunk:
+//              the droppers are walked in a wave-uniform loop (their cells by v_readlane), every later lane marks the cell in a 49-bit
+//              mask if it falls into its window, a later dropper on the same cell learns that the cell was taken ("was"); afterwards
+//              each dropper ORs its bit into the board (ds_or_b32).  No per-cell lane masks, no prefix-OR over rows: ~14 vector
+//              instructions per dropper, ~13 droppers per chunk;
+//   the rows   every lane files its row COMPACT -- the 7 window row codes (2 bits per cell, k_rollout2d's encoding) and the two scalar
+//              slots, 32 bytes -- in a staging tile [tick][env of the block]; behind a barrier the block's threads expand it on the way
+//              out: a tick's rows of the block's EB envs are one run of EB x 408 bytes, stored 16 bytes per lane (the source of every
+//              lane's values in a run does not depend on the tick and is worked out once per launch).
+// ~8 + 4.5 wave-instructions per env-step (the lane-per-env kernel: 4.2), but nothing waits for the tick before: N = 1024 x 600 ticks
+// takes ~0.03 ms instead of 0.51.  Semantics are K2D::step's; counter-RNG or explicit inputs; SNAC_OBS_ALL / SNAC_OBS_TILED, canonical layout.
+template <bool DYN, typename OT, int EB, bool EXPL>
+__global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
+    using K = K2D<DYN, 64>;
+    constexpr int D = K::D, GE = K::GE;
+    constexpr int ROWB = D * (int)sizeof(OT);                        // 408 / 204 bytes per row
+    constexpr int RECW = 8;                                          // dwords per compact row: 7 codes in 4 dwords, two doubles
+    constexpr int TSTR = EB * RECW + 4;                              // staging dwords per tick (+4: the lanes' 16-byte writes spread over the banks)
+    // A block is 2 EB waves: EB STEPPERS (one env each: the control chain of a chunk of 64 ticks, compact rows into staging buffer c & 1)
+    // and EB WRITERS, which expand the chunk before (buffer (c - 1) & 1) while the steppers are at the next one -- one barrier per
+    // chunk.  With one wave per SIMD (N <= 1024) a chunk costs max(stepping, expanding) instead of their sum.
+    __shared__ uint32_t sG[EB][GE], sP[EB][GE];
+    __shared__ __align__(16) uint32_t stage2[2][64 * TSTR];
+    __shared__ float sR2[2][64][EB + 1];
+    __shared__ __align__(16) uint8_t sD2[2][64][EB];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wall = tid >> 6;
+    const bool stepper = wall < EB;
+    const int wv = wall & (EB - 1);                                  // the stepper's env of the block / the writer's share of the ticks
+    const int env0 = (int)blockIdx.x * EB;
+    const int nenv = min(EB, a.n - env0);                            // block-uniform; > 0 by the grid
+    const bool own = stepper && wv < nenv;                           // steppers past the batch only keep the barriers company
+    const int env = env0 + ((stepper && wv < nenv) ? wv : 0);
+    uint32_t* const G = sG[wv];                                      // the board as the current chunk found it: 20 interior row words
+    uint32_t* const P = sP[wv];                                      // the env's plan rows
+    Lane s;
+    s.unpack(a.hdr[env]);
+    int episode = a.episode[env];
+    asm volatile("" : "+v"(episode));
+    if (stepper && lane < GE) {                                      // (the writers share the index wv: they must not touch these)
+        G[lane] = ((const uint32_t*)a.grid)[(size_t)env * GE + lane];
+        P[lane] = ((const uint32_t*)a.plans)[(size_t)s.pidx * GE + lane];
+    }
+    const uint64_t gid = (uint64_t)(a.env_id_base + env);
+    const EnvKeys sk = env_keys(a.key_step, gid), pk = env_keys(a.key_plan, gid);
+    // wave-uniform env state (every lane holds the same values)
+    int r0 = s.r, c0 = s.c, cb0 = s.cb, cs0 = s.cs, ret0 = s.ep_ret, tb = s.tb, pidx = s.pidx;
+    asm volatile("" : "+v"(tb));                                     // the header has arrived HERE, not at a wait inside the loop
+    double dtb = (double)tb, rtb = 1.0 / dtb;                        // once per episode (Roll3D, tests/native/recip_check.c)
+    bool need_reset = a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+    bool flag_done = (s.flags & SNAC_FLAG_NEED_RESET) != 0;
+    int d_eps = 0, d_ret = 0;
+    long long d_iou = 0;
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);      // lanes <= this one
+    const bool tl = a.obs_mode == SNAC_OBS_TILED;
+    const double dT = (double)a.total_step, rT = 1.0 / dT;
+    // the block's rows of one tick are one run of nenv x ROWB bytes; 16-byte pieces when every run starts and ends on 16 bytes
+    const size_t ostr = (tl ? (size_t)64 : (size_t)a.n) * ROWB;      // bytes from one tick's run to the next
+    const bool vec = ((((uintptr_t)a.obs) | (uintptr_t)ostr | (uintptr_t)((size_t)nenv * ROWB)) & 15) == 0;
+    const bool dvec = EB == 16 && a.done && nenv == EB && ((((uintptr_t)a.done) | (uintptr_t)a.n) & 15) == 0;
+    // ---- what this lane expands when a run leaves: piece lane + 64 q of the run holds VP values; value v of it is element el of env e of
+    // the block -- a window cell (source: code i of the env's compact row, 2-bit field j) or a scalar slot.  The same for every tick.
+    constexpr int VP = 16 / (int)sizeof(OT);                         // values per 16-byte piece
+    constexpr int PTMAX = EB * ROWB / 16, NQ = (PTMAX + 63) / 64;
+    int fsrc[NQ][VP];                                                // dword offset in the tick's staging row | shift << 16 | scalar << 24
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int v = 0; v < VP; ++v) {
+                const int gel = min((lane + 64 * q) * VP + v, EB * D - 1);
+                const int e = gel / D, el = gel - e * D;
+                if (el < K::W) {
+                    const int i = el / 7, j = el - 7 * i;
+                    fsrc[q][v] = (e * RECW + (i >> 1)) | ((30 - 2 * j - (i & 1) * 16) << 16);
+                } else {
+                    fsrc[q][v] = (e * RECW + 4 + 2 * (el - K::W)) | (1 << 24);
+                }
+            }
+    }
+    const int nchunks = (a.T + 63) / 64;
+    for (int ch = 0; ch <= nchunks; ++ch) {
+        const int t0 = ch * 64;
+        const int nl = min(64, a.T - t0);
+        uint32_t* const stage = stage2[ch & 1];
+        float (*const sR)[EB + 1] = sR2[ch & 1];
+        uint8_t (*const sD)[EB] = sD2[ch & 1];
+        if (own && ch < nchunks) {
+        const bool valid = lane < nl;
+        const int t = t0 + lane;
+        const size_t row = (size_t)t * (size_t)a.n + (size_t)env;
+        const uint32_t w = rng_word(sk, a.t0 + (uint32_t)t);
+        int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+        if constexpr (EXPL) {
+            if (a.actions && valid) act = (int)a.actions[row];
+            if (a.step_size && valid) k = min(max((int)a.step_size[row], 1), 3);
+        }
+        int first_lane = 0;                                          // the segment's first lane
+        while (first_lane < nl) {
+            if (need_reset) {                                        // K2D::reset in the uniform state (rare: once per episode)
+                episode += 1;
+                const int np = pick_plan<K>(a, pk, episode, pidx);
+                if (np != pidx) {                                    // a new row brings its total_brick, the same row keeps the header's
+                    pidx = np; tb = (int)a.plan_tb[np];
+                    asm volatile("" : "+v"(tb));
+                    dtb = (double)tb; rtb = 1.0 / dtb;
+                    if (lane < GE) P[lane] = ((const uint32_t*)a.plans)[(size_t)np * GE + lane];
+                }
+                if (lane < GE) G[lane] = 0u;
+                r0 = 3; c0 = 3; cb0 = 0; cs0 = 0; ret0 = 0;
+                need_reset = false;
+            }
+            const bool seg = valid && lane >= first_lane;
+            const bool drop = seg && act == 4;
+            // ---- counters and the segment's end
+            const int cs = min(cs0 + (lane - first_lane + 1), CNT_MAX);
+            const unsigned long long dropm = __ballot(drop);
+            const int cb = min(cb0 + (int)__popcll(dropm & le), CNT_MAX);
+            const bool term = drop && cb >= tb + a.brick_gt;         // :117-126, before the time limit
+            const bool done = seg && (term || cs >= a.ts_done);
+            const unsigned long long donem = __ballot(done);
+            const int last = donem ? (__ffsll((long long)donem) - 1) : (nl - 1);     // the segment's last lane
+            const bool in = seg && lane <= last;
+            // ---- positions: two inclusive scans of x -> min(max(x + d, 3), 22) (clip_position :74-83; "up" is row + k, :100-103)
+            int ra = 0, rlo = -4096, rhi = 4096, ca = 0, clo = -4096, chi = 4096;
+            if (in) {
+                ra = act == 2 ? k : (act == 3 ? -k : 0); rlo = 3; rhi = 22;
+                ca = act == 1 ? k : (act == 0 ? -k : 0); clo = 3; chi = 22;
+            }
+            auto compose = [&](int pa, int plo, int phi, int& sa, int& slo, int& shi) {   // the earlier ticks first, then this lane's function
+                const int nlo = min(max(plo + sa, slo), shi), nhi = min(max(phi + sa, slo), shi);
+                sa += pa; slo = nlo; shi = nhi;
+            };
+#define SNAC_SCAN_STEP(CTRL, ROWS)                                                                                               \
+            {                                                                                                                    \
+                const int pa = dpp_from<CTRL, ROWS>(0, ra), plo = dpp_from<CTRL, ROWS>(-4096, rlo), phi = dpp_from<CTRL, ROWS>(4096, rhi); \
+                const int qa = dpp_from<CTRL, ROWS>(0, ca), qlo = dpp_from<CTRL, ROWS>(-4096, clo), qhi = dpp_from<CTRL, ROWS>(4096, chi); \
+                compose(pa, plo, phi, ra, rlo, rhi);                                                                             \
+                compose(qa, qlo, qhi, ca, clo, chi);                                                                             \
+            }
+            SNAC_SCAN_STEP(0x111, 0xf) SNAC_SCAN_STEP(0x112, 0xf) SNAC_SCAN_STEP(0x114, 0xf) SNAC_SCAN_STEP(0x118, 0xf)
+            SNAC_SCAN_STEP(0x142, 0xa) SNAC_SCAN_STEP(0x143, 0xc)
+#undef SNAC_SCAN_STEP
+            const int pr = min(max(r0 + ra, rlo), rhi), pc = min(max(c0 + ca, clo), chi);   // after the tick
+            const int prv_r = dpp_from<0x138>(r0, pr), prv_c = dpp_from<0x138>(c0, pc);
+            const int br = lane == first_lane ? r0 : prv_r, bc = lane == first_lane ? c0 : prv_c;   // before the tick: where a drop lands
+            // ---- the window round the new position from the board as the chunk found it (k_step2d's encoding) ...
+            uint32_t wr[7];
+            {
+                const int sh = pc - 3;                               // first window column, bordered: 0..19
+                constexpr uint32_t FRAME26 = 0x3800007u;             // frame columns 0-2 and 23-25 of an interior row
+                const uint32_t frm = spread16((FRAME26 >> sh) & 0x7Fu) * 3u;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const int q = pr - 6 + i;                        // board row of window row i
+                    const bool inb = (unsigned)q < (unsigned)GE;
+                    const uint32_t g = G[inb ? q : 0];
+                    wr[i] = inb ? (spread16(((g << 3) >> sh) & 0x7Fu) | frm) : 0x3FFFu;
+                }
+            }
+            // ... OR the bricks dropped earlier in this segment: every dropper in turn (wave-uniform), its cell against each later
+            // lane's window, and against each later dropper's own cell ("was": the cell was taken by then)
+            const int bcell = br * 32 + bc;                          // where this lane's drop lands
+            bool was = ((G[min(max(br - 3, 0), GE - 1)] >> (bc - 3)) & 1u) != 0u;
+            const bool planned = ((P[min(max(br - 3, 0), GE - 1)] >> (bc - 3)) & 1u) != 0u;
+            unsigned long long dmask = 0ull;
+            const unsigned long long inm = __ballot(in);
+            for (unsigned long long m = dropm & inm; m; m &= m - 1) {
+                const int L = __ffsll((long long)m) - 1;
+                const int cellL = __builtin_amdgcn_readlane(bcell, L);
+                const int di = (cellL >> 5) - (pr - 3), dj = (cellL & 31) - (pc - 3);
+                if (lane >= L && (unsigned)di < 7u && (unsigned)dj < 7u) dmask |= 1ull << (di * 7 + dj);
+                was = was || (lane > L && bcell == cellL);
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) wr[i] |= spread16((uint32_t)(dmask >> (7 * i)) & 0x7Fu);
+            const int reward = (drop && !term && !was && planned) ? 5 : 0;   // un-clamped cell vs plan (:129-133)
+            const unsigned long long r5 = __ballot(in && reward != 0);
+            const int ret = clamp16(ret0 + 5 * (int)__popcll(r5 & le));
+            // ---- outputs of the segment's lanes: compact rows into the block's staging tile
+            if (in) {
+                const double q0v = (double)cb, q1v = (double)cs;
+                double v0 = q0v, v1 = q1v;
+                if (DYN) {                                           // cb / tb, cs / T: correctly rounded (Roll3D, tests/native/recip_check.c)
+                    const double q0 = q0v * rtb, q1 = q1v * rT;
+                    v0 = tb > 0 ? __builtin_fma(__builtin_fma(-q0, dtb, q0v), rtb, q0) : q0v / dtb;
+                    v1 = __builtin_fma(__builtin_fma(-q1, dT, q1v), rT, q1);
+                }
+                uint32_t* const o = stage + lane * TSTR + wv * RECW;
+                const uint64_t b0 = (uint64_t)__double_as_longlong(v0), b1 = (uint64_t)__double_as_longlong(v1);
+                *(uint4*)o = make_uint4(wr[0] | (wr[1] << 16), wr[2] | (wr[3] << 16), wr[4] | (wr[5] << 16), wr[6]);
+                *(uint4*)(o + 4) = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
+                sR[lane][wv] = (float)reward;
+                sD[lane][wv] = (lane == last && donem) ? 1 : 0;
+                if (a.actions_out) a.actions_out[row] = (int8_t)act;
+                if (a.step_size_out) a.step_size_out[row] = (int8_t)k;
+                if (a.plan_idx_out) a.plan_idx_out[row] = (int16_t)pidx;
+                if (a.first_out) a.first_out[row] = cs == 1 ? 1 : 0;
+                if (drop) atomicOr(&G[br - 3], 1u << (bc - 3));      // += 1 then clamp to 1 (:115, :134-135): the board takes the brick
+            }
+            // ---- the segment's end: the uniform state moves on
+            r0 = __builtin_amdgcn_readlane(pr, last); c0 = __builtin_amdgcn_readlane(pc, last);     // `last` is uniform
+            cb0 = __builtin_amdgcn_readlane(cb, last); cs0 = __builtin_amdgcn_readlane(cs, last); ret0 = __builtin_amdgcn_readlane(ret, last);
+            flag_done = donem != 0ull;
+            if (donem) {                                             // boolean IoU of the finished episode (script/DQN/2d/DQN_2d_dynamic.py:63-71), episodic sums
+                asm volatile("" ::: "memory");                       // once per episode: stays a branch
+                const uint32_t g = lane < GE ? G[lane] : 0u, p = lane < GE ? P[lane] : 0u;
+                int inter = __popc(g & p), uni = __popc(g | p);
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) { inter += __shfl_xor(inter, off); uni += __shfl_xor(uni, off); }
+                inter = __builtin_amdgcn_readfirstlane(inter); uni = __builtin_amdgcn_readfirstlane(uni);
+                const double v = (double)inter / (double)uni;
+                d_eps += 1; d_ret += ret0; d_iou += __double2ll_rn(v * FX40);
+                need_reset = a.auto_reset != 0;
+            }
+            first_lane = last + 1;
+        }
+        }
+        // ---- the chunk before leaves: per tick one run of the block's rows, expanded from the compact rows by the writer waves
+        if (!stepper && ch > 0) {
+            const int t0 = (ch - 1) * 64;
+            const int nl = min(64, a.T - t0);
+            const uint32_t* const stage = stage2[(ch - 1) & 1];
+            const float (*const sR)[EB + 1] = sR2[(ch - 1) & 1];
+            const uint8_t (*const sD)[EB] = sD2[(ch - 1) & 1];
+            int t0v = t0, wq = wv, lq = lane;
+            asm volatile("" : "+s"(t0v), "+v"(wq), "+v"(lq));        // addresses from scratch every chunk (k_rollout1dt)
+            const size_t row0 = tl ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)(a.tiled_t0 + t0v)) * 64 + (size_t)(env0 & 63)
+                                   : (size_t)t0v * (size_t)a.n + (size_t)env0;
+            char* const ob = (char*)a.obs + row0 * ROWB;
+            constexpr int TPW = 64 / EB;                             // ticks per wave
+            auto value = [&](const uint32_t* rec, int el) -> OT {    // element el of the compact row rec
+                if (el < K::W) {
+                    const int i = el / 7, j = el - 7 * i;
+                    const uint32_t c = rec[i >> 1] >> ((i & 1) * 16);
+                    return (OT)(((int)(c << (30 - 2 * j))) >> 30);  // signed 2-bit field: 0 / 1 / -1
+                }
+                return (OT)__longlong_as_double((long long)(((uint64_t)rec[5 + 2 * (el - K::W)] << 32) | rec[4 + 2 * (el - K::W)]));
+            };
+            if (vec) {
+                const int pt = nenv * ROWB / 16;
+                for (int i = 0; i < TPW; ++i) {
+                    const int tk = wq * TPW + i;
+                    if (tk >= nl) break;
+                    const uint32_t* const trow = stage + tk * TSTR;
+                    char* const orun = ob + (size_t)tk * ostr + lq * 16;
+                    uint32_t lo[NQ][VP], hi[NQ][VP];                 // every LDS read of the tick first: one round trip per tick, not per piece
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int v = 0; v < VP; ++v) {
+                            const uint32_t* const sp = trow + (fsrc[q][v] & 0xffff);
+                            lo[q][v] = sp[0]; hi[q][v] = sp[1];
+                        }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        OT val[VP];
+#pragma unroll
+                        for (int v = 0; v < VP; ++v) {
+                            const int f = fsrc[q][v];
+                            const int cv = ((int)(lo[q][v] << ((f >> 16) & 0xff))) >> 30;
+                            val[v] = (f >> 24) ? (OT)__longlong_as_double((long long)(((uint64_t)hi[q][v] << 32) | lo[q][v])) : (OT)cv;
+                        }
+                        if (lq + 64 * q < pt) {
+                            if constexpr (VP == 2) { double2 o; o.x = val[0]; o.y = val[1]; *(double2*)(orun + q * 1024) = o; }
+                            else { float4 o; o.x = val[0]; o.y = val[1]; o.z = val[2]; o.w = val[3]; *(float4*)(orun + q * 1024) = o; }
+                        }
+                    }
+                }
+            } else {
+                const int pe = nenv * D;                             // ragged or unaligned: element by element, still in runs
+                for (int i = 0; i < TPW; ++i) {
+                    const int tk = wq * TPW + i;
+                    if (tk < nl)
+                        for (int gel = lq; gel < pe; gel += 64) {
+                            const int e = gel / D;
+                            ((OT*)(ob + (size_t)tk * ostr))[gel] = value(stage + tk * TSTR + e * RECW, gel - e * D);
+                        }
+                }
+            }
+            // reward / done: 64 / EB ticks x EB envs per wave, one instruction each
+            const size_t rw0 = (size_t)t0v * (size_t)a.n + (size_t)env0;
+            const int tk = wq * TPW + lq / EB, e = lq & (EB - 1);
+            const bool mine = tk < nl && e < nenv;
+            if (a.reward && mine) a.reward[rw0 + (size_t)tk * (size_t)a.n + e] = sR[tk][e];
+            if (dvec) {
+                const int wt = tid - EB * 64;                        // the writers' thread index
+                if (wt < nl) *(uint4*)(a.done + rw0 + (size_t)wt * (size_t)a.n) = *(const uint4*)sD[wt];
+            } else if (a.done && mine) a.done[rw0 + (size_t)tk * (size_t)a.n + e] = sD[tk][e];
+        }
+        __syncthreads();
+    }
+    // ---- the env's record
+    if (!own) return;
+    if (lane < GE) ((uint32_t*)a.grid)[(size_t)env * GE + lane] = G[lane];
+    if (lane == 0) {
+        s.r = r0; s.c = c0; s.cb = cb0; s.cs = cs0; s.ep_ret = ret0; s.tb = tb; s.pidx = pidx; s.cross = 0;
+        s.flags = flag_done ? SNAC_FLAG_NEED_RESET : 0;
+        a.hdr[env] = s.pack();
+        a.episode[env] = episode;
+        if (d_eps) {
+            a.stat_episodes[env] += d_eps;
+            a.stat_return[env] += d_ret;
+            a.stat_iou_fx[env] += d_iou;
+        }
+    }
+}
+
 // transition(state, action) of the MCTS variants (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175 and the eight sibling files;
 // caller: script/MCTS/utils/mcts_Qvalue_dynamic.py:88,118): ONE step of the same K::step on an explicit state, batched over
 // a.n tree edges.  The state arrays are a node pool; edge i reads row src_index[i] and writes row dst_index[i] (out of
@@ -3237,6 +3554,34 @@ void launch_roll2d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     else f32 ? launch_roll2d_w<false, float>(a, s) : launch_roll2d_w<false, double>(a, s);
 }
 
+// time-parallel 2D rollouts (one wave per env, lane = tick): small batches, where the lane-per-env kernels are bound by the chain of
+// their ticks (0.5-0.7 ms per 600 ticks at every N <= 16 384).  SNAC_2D_TP=0 keeps them on the tile kernel (A/B timing, tests of both
+// paths), SNAC_2D_TP_MAX=n moves the upper batch limit
+bool roll2dt_ok(const KArgs& a, bool f32) {
+    static const bool off = [] { const char* e = std::getenv("SNAC_2D_TP"); return e && e[0] == '0'; }();
+    static const int nmax = [] { const char* e = std::getenv("SNAC_2D_TP_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
+    const int lim = nmax ? nmax : 16383;
+    (void)f32;
+    return !off && a.n <= lim && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && !pipeline_off();
+}
+template <bool DYN, typename OT, int EB>
+void launch_roll2dt_e(const KArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)((a.n + EB - 1) / EB)), block(2 * EB * 64);   // EB stepper waves + EB writer waves
+    if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout2dt<DYN, OT, EB, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_rollout2dt<DYN, OT, EB, false>), grid, block, 0, s, a);
+}
+template <bool DYN, typename OT>
+void launch_roll2dt_w(const KArgs& a, hipStream_t s) {
+    static const int emin = [] { const char* e = std::getenv("SNAC_2D_TP_EB8"); return e ? std::atoi(e) : 2048; }();   // (tuning)
+    if (a.n >= emin) launch_roll2dt_e<DYN, OT, 8>(a, s);       // 8 envs per block: runs of 3264 / 1632 bytes per tick
+    else launch_roll2dt_e<DYN, OT, 4>(a, s);                        // small batches: more blocks than CUs first
+}
+void launch_roll2dt(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
+    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
+    if (dyn) f32 ? launch_roll2dt_w<true, float>(a, s) : launch_roll2dt_w<true, double>(a, s);
+    else f32 ? launch_roll2dt_w<false, float>(a, s) : launch_roll2dt_w<false, double>(a, s);
+}
+
 // time-parallel 1D rollouts (one wave per env, lane = tick).  Its rate levels off at 6-7e10 env-steps/s (instruction issue: ~9 per
 // env-step), the tile kernel's keeps growing with the batch: float64 rows 49 152 envs 0.54 against 0.68 ms per 750 ticks, 65 536
 // 0.72-0.87 against 0.72; float32 rows 65 536 envs 0.65 against 0.73, 131 072 1.35 against 0.94 (profiles/r03_1d_time_parallel.txt).
@@ -3344,6 +3689,7 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { g_kernel = "k_transition2d"; launch_trans2d(d, a, s); break; }
             // float32 rows from N = 32 768: 512 staged waves (1.05 -> 0.74 ms per 600 ticks); float64 rows there are level (1.26-1.60 ms
             // by box for either kernel) and stay on 32-env tiles
+            if (op == OP_ROLLOUT && roll2dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout2dt"; launch_roll2dt(d, a, s); break; }
             if (op == OP_ROLLOUT && roll2d_ok(a, (d->obs_dtype == SNAC_OBS_F32 && a.n >= 32768) ? 64 : E)) { g_kernel = "k_rollout2d"; launch_roll2d(d, a, s); break; }
             launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
