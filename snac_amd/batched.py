@@ -26,6 +26,11 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _current_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
+def _meta(*tensors):
+    """(shape, stride, dtype) of every tensor (None stays None): what step()'s fast path compares besides the data pointers."""
+    return tuple(None if t is None else (t.shape, t.stride(), t.dtype) for t in tensors)
+
+
 class BatchedDMPEnv:
     """N envs of one kind.
 
@@ -122,6 +127,7 @@ class BatchedDMPEnv:
         self.t = 0  # tick: number of vector steps taken (keys the counter RNG)
         self._was_reset = False
         self._fast = None                                            # step(): the argument set validated by the previous call
+        self._table_version, self._table_snapshot = 0, None          # state_dict(): one clone of the plan table per version of it
         self._dev_index = self.device.index
         self._desc_ref, self._state_ref = C.byref(self._desc), C.byref(self._state)
         self._snac_step = self._lib.snac_step
@@ -225,8 +231,11 @@ class BatchedDMPEnv:
         if f is not None and out is not None and f[0] is out and f[1] is actions and f[2] is step_size and f[3] == want_obs \
                 and _current_device() == self._dev_index:
             o, r, d = out
+            # the same objects may have been changed in place (resize_, set_, as_strided_, .data = ...): the pointers AND the
+            # shapes, strides and dtypes the kernel was validated for must still hold, or the full checks run again
             if (o.data_ptr() if want_obs else 0) == f[4] and r.data_ptr() == f[5] and d.data_ptr() == f[6] \
-                    and (actions is None or actions.data_ptr() == f[7]) and (step_size is None or step_size.data_ptr() == f[8]):
+                    and (actions is None or actions.data_ptr() == f[7]) and (step_size is None or step_size.data_ptr() == f[8]) \
+                    and _meta(o if want_obs else None, r, d, actions, step_size) == f[10]:
                 rc = self._snac_step(self._desc_ref, self._state_ref, self.t & 0xFFFFFFFF, f[7], f[8], 1 if auto_reset else 0,
                                      f[4] or None, f[5], f[6], _raw_stream(self._dev_index))
                 if rc:
@@ -259,7 +268,8 @@ class BatchedDMPEnv:
         # objects goes straight to the launch
         if out is not None and a is actions and k is step_size and _raw_stream is not None:
             self._fast = (out, actions, step_size, bool(want_obs), obs.data_ptr() if obs is not None else 0, reward.data_ptr(), done.data_ptr(),
-                          a.data_ptr() if a is not None else None, k.data_ptr() if k is not None else None, ret)
+                          a.data_ptr() if a is not None else None, k.data_ptr() if k is not None else None, ret,
+                          _meta(obs, reward, done, actions, step_size))
         else:
             self._fast = None
         return ret
@@ -402,6 +412,7 @@ class BatchedDMPEnv:
         packed, tb = _plans.pack_plans(self.kind, full[None])
         row = torch.from_numpy(packed.view(np.int32) if self.kind == 2 else packed)[0]
         self._plans[index].copy_(row.to(self.device))
+        self._table_version += 1
         self.plans_full[index] = full
         if update_tb:
             self._plan_tb[index] = int(tb[0])
@@ -427,6 +438,7 @@ class BatchedDMPEnv:
                                                  int(self.seed if seed is None else seed) & 0xFFFFFFFFFFFFFFFF, int(id_base),
                                                  _ptr(v), _ptr(area), self._stream()))
         self._plans_stale = True                               # the host copy (plans_full) no longer mirrors the device table
+        self._table_version += 1
         return area
 
     def generate_plans_numpy(self, first=0, count=None, sparse=False):
@@ -485,8 +497,13 @@ class BatchedDMPEnv:
         (position, grid, count_brick, count_step) per env (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175).  The device plan table and
         its total_brick column travel with the snapshot: generate_plans() / set_plan_row() change them, and a header's plan row
         means nothing without the table it indexes."""
+        # the table is cloned once per VERSION of it, not once per snapshot (tree search snapshots per node; a generated 3D table is
+        # 26 MB): every snapshot of an unchanged table shares one read-only clone
+        snap = self._table_snapshot
+        if snap is None or snap[0] != self._table_version:
+            snap = self._table_snapshot = (self._table_version, self._plans.clone(), self._plan_tb.clone())
         return dict(hdr=self._hdr.clone(), episode=self._episode.clone(), grid=self._grid.clone(), stats=self._stats.clone(),
-                    plans=self._plans.clone(), plan_tb=self._plan_tb.clone(),
+                    plans=snap[1], plan_tb=snap[2],
                     t=self.t, kind=self.kind, dynamic=self.dynamic, num_envs=self.num_envs)
 
     def load_state_dict(self, sd):
@@ -495,8 +512,11 @@ class BatchedDMPEnv:
         if "plans" in sd:
             if tuple(sd["plans"].shape) != tuple(self._plans.shape):
                 raise ValueError("snapshot holds a plan table of another size")
-            self._plans.copy_(sd["plans"]); self._plan_tb.copy_(sd["plan_tb"])
-            self._plans_stale = True                               # plans_full is re-decoded from the device table when it is needed
+            snap = self._table_snapshot
+            if not (snap is not None and snap[0] == self._table_version and sd["plans"] is snap[1] and sd["plan_tb"] is snap[2]):
+                self._plans.copy_(sd["plans"]); self._plan_tb.copy_(sd["plan_tb"])   # (a snapshot of the current table: nothing to copy)
+                self._table_version += 1
+                self._plans_stale = True                           # plans_full is re-decoded from the device table when it is needed
         self._hdr.copy_(sd["hdr"]); self._episode.copy_(sd["episode"]); self._grid.copy_(sd["grid"]); self._stats.copy_(sd["stats"])
         self.t = int(sd["t"])
         self._was_reset = True
@@ -512,6 +532,7 @@ class BatchedDMPEnv:
                               brick_gt=self.brick_gt, time_gt=self.time_gt, frame_value=self.frame_value,
                               obs_scalars=self.obs_scalars, obs_tail=self.obs_tail, static_plan=self.static_plan)
         child._plan_tb.copy_(self._plan_tb)                          # caller-supplied total_brick rows travel with the fork
+        child._table_version += 1
         child._hdr.copy_(self._hdr[index]); child._episode.copy_(self._episode[index]); child._grid.copy_(self._grid[index])
         child.t = self.t
         child._was_reset = self._was_reset

@@ -1190,9 +1190,8 @@ struct Roll3D {
         if (__any(nr)) {
             if (nr) {
                 episode += 1;
-                s.pidx = pick_plan<K>(a, pk, episode, s.pidx);
-                s.tb = tbtab[s.pidx];
-                new_tb();
+                const int np = pick_plan<K>(a, pk, episode, s.pidx);
+                if (np != s.pidx) { s.pidx = np; s.tb = tbtab[np]; new_tb(); }   // K::reset: a new row brings its total_brick, the same row keeps the header's
                 s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
             }
             for (unsigned long long m = __ballot(nr); m; m &= m - 1) K::clear(lds, __ffsll(m) - 1, lane);
@@ -1510,9 +1509,11 @@ __global__ __launch_bounds__(576) void k_rollout3db(const KArgs a) {
         };
         auto reset_scalars = [&]() {                                 // K3D::reset without the map
             episode += 1;
-            s.pidx = pick_plan<K>(a, pk, episode, s.pidx);
-            s.tb = tbtab[s.pidx];
-            dtb = (double)s.tb; rtb = rtab[s.pidx];
+            const int np = pick_plan<K>(a, pk, episode, s.pidx);
+            if (np != s.pidx) {                                      // K::reset: a new row brings its total_brick, the same row keeps the header's
+                s.pidx = np; s.tb = tbtab[np];
+                dtb = (double)s.tb; rtb = rtab[np];
+            }
             s.r = 3; s.c = 3; s.cb = 0; s.cs = 0; s.ep_ret = 0; s.cross = 0; s.flags = 0;
         };
         auto target_cell = [&](int aa) -> int {                      // the build target of action aa from the current position, plan coordinates

@@ -182,3 +182,31 @@ def test_snapshot_carries_the_plan_table_of_generated_plans():
     small = BatchedDMPEnv(2, True, 512, plans=a.plans_full[:7], seed=11)
     with pytest.raises(ValueError):
         small.load_state_dict(sd)
+
+
+def test_snapshots_share_one_clone_of_an_unchanged_plan_table():
+    """tree search snapshots per node; the plan table is cloned once per VERSION of it (generate_plans, set_plan_row
+    and a load of another table make a new version), and a snapshot of the current table is restored without copying it."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    a = BatchedDMPEnv(3, True, 64, seed=2)
+    a.reset()
+    s1 = a.state_dict()
+    a.rollout(5, obs=None)
+    s2 = a.state_dict()
+    assert s1["plans"] is s2["plans"] and s1["plan_tb"] is s2["plan_tb"] and s1["grid"] is not s2["grid"]
+    a.generate_plans(3, 4, seed=9)
+    s3 = a.state_dict()
+    assert s3["plans"] is not s1["plans"] and not torch.equal(s3["plans"], s1["plans"])
+    keep = s1["plans"].clone()
+    a.load_state_dict(s1)                                        # back to the first table: a new version again
+    assert torch.equal(a._plans, keep) and torch.equal(s1["plans"], keep)
+    s4 = a.state_dict()
+    assert s4["plans"] is not s3["plans"] and torch.equal(s4["plans"], keep)
+    a.load_state_dict(s4)                                        # the current table's own snapshot: no copy, same version
+    assert a.state_dict()["plans"] is s4["plans"]
+    a.set_plan_row(0, a.plans_full[1])
+    assert a.state_dict()["plans"] is not s4["plans"]
+    b = a.fork(torch.arange(8, device=a.device))
+    assert b.state_dict()["plans"] is not a.state_dict()["plans"]

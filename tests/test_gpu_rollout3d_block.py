@@ -193,3 +193,29 @@ def test_replay_rings_filled_by_the_block_kernel():
     ga.manual_seed(3); gb.manual_seed(3)
     sa, sb = a.sample(300, generator=ga), b.sample(300, generator=gb)
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
+
+
+def test_header_total_brick_survives_a_reset_onto_the_same_plan_in_every_3d_kernel():
+    """A static batch whose headers carry a total_brick other than the plan row's (set_plan_row(update_tb=True) after reset,
+    import_states with total_brick, an old snapshot): K::reset keeps it when an env starts over on the SAME plan row.  Round 3's
+    k_rollout3d / k_rollout3db reloaded it from the table, so results depended on which kernel a call was dispatched to: obs="all"
+    (the block kernel), an unaligned output (the eight-env kernel) and obs=None (the tile kernel) must agree."""
+    import torch
+    from snac_amd import _lib
+
+    n, T = 8192, 90
+    env, _ = _pair(False, n, seed=3, total_step=40)
+    twins = [env.fork(torch.arange(n, device=env.device)) for _ in range(2)]
+    for e in [env] + twins:
+        e._hdr.view(torch.int16)[:, 4] = 23                        # total_brick 23 instead of the plan's 360
+    o1, r1, d1 = env.rollout(T)
+    assert _lib.lib().snac_last_kernel() == b"k_rollout3db"
+    raw = torch.empty(T * n * 51 + 1, dtype=torch.float64, device=env.device)
+    o2, r2, d2 = twins[0].rollout(T, out=raw[1:].view(T, n, 51))
+    assert _lib.lib().snac_last_kernel() == b"k_rollout3d"
+    _, r3, d3 = twins[1].rollout(T, obs=None)
+    assert _lib.lib().snac_last_kernel() == b"k_rollout"
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(r1, r3) and torch.equal(d1, d3)
+    for tw in twins:
+        assert torch.equal(env._hdr, tw._hdr) and torch.equal(env._stats, tw._stats) and torch.equal(env._grid, tw._grid)
+    assert int(env.total_brick.min()) == 23 and int(env.episodic_stats()["episodes"]) > n

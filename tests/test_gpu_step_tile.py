@@ -121,3 +121,35 @@ def test_large_batch_equals_the_rollout(kind):
         assert torch.equal(og, ot[t]) and torch.equal(rg, rt[t]) and torch.equal(dg, dt[t]), t
     assert torch.equal(env._hdr, twin._hdr) and torch.equal(env._grid, twin._grid) and torch.equal(env._stats, twin._stats)
     assert torch.equal(env._episode, twin._episode)
+
+
+def test_fast_path_revalidates_tensors_that_were_changed_in_place():
+    """step() skips its argument checks when it is handed the same tensor objects as the call before -- but only while their shapes,
+    strides and dtypes are what was validated: a tensor resized or re-strided in place keeps its data_ptr(), and the kernel would
+    read or write past it."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    n = 256
+    env = BatchedDMPEnv(2, True, n, seed=3)
+    env.reset()
+    acts = torch.zeros(n, dtype=torch.int8, device=env.device)
+    ks = torch.ones(n, dtype=torch.int8, device=env.device)
+    out = (torch.empty((n, 51), dtype=torch.float64, device=env.device), torch.empty(n, dtype=torch.float32, device=env.device),
+           torch.empty(n, dtype=torch.uint8, device=env.device))
+    env.step(acts, ks, auto_reset=True, out=out)
+    assert env._fast is not None
+    env.step(acts, ks, auto_reset=True, out=out)                     # the fast path
+    t_before = env.t
+    acts.resize_(n // 2)                                             # same object, same data_ptr, half the elements
+    with pytest.raises(ValueError):
+        env.step(acts, ks, auto_reset=True, out=out)
+    assert env.t == t_before
+    acts.resize_(n)
+    env.step(acts, ks, auto_reset=True, out=out)
+    out[0].as_strided_((n, 51), (102, 1))                            # same pointer, rows twice as far apart
+    with pytest.raises(ValueError):
+        env.step(acts, ks, auto_reset=True, out=out)
+    out[0].as_strided_((n, 51), (51, 1))
+    env.step(acts, ks, auto_reset=True, out=out)
+    assert env.t == t_before + 2
