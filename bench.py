@@ -660,11 +660,25 @@ def main():
             ring.collect(cap)
             slot = torch.randint(1, cap, (batch,), device=dev)
             ei = torch.randint(0, nn, (batch,), device=dev)
-            ms = timed(lambda: ring.gather(slot, ei), reps)
+            import ctypes as C
+
+            slot32, ei32 = slot.to(torch.int32), ei.to(torch.int32)
+            so = torch.empty((batch, e.obs_dim), dtype=torch.float32, device=dev)
+            sn = torch.empty_like(so)
+            pl = torch.empty((batch, 400), dtype=torch.float32, device=dev)
+            vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+            def call():
+                _lib.check(e._lib.snac_replay_gather(C.byref(e._desc), C.byref(e._state), cap, vp(ring.obs), vp(ring.first), vp(ring.plan_idx),
+                                                     vp(slot32), vp(ei32), batch, vp(so), vp(sn), vp(pl), e._stream()))
+
+            ms = timed(call, reps)
+            ms_wrapped = timed(lambda: ring.gather(slot, ei), reps)
             algb = 2 * 408 + 2 * 204 + 1600 + 8 + 3                  # two f64 rows in, two f32 rows + 400 f32 plan cells out, indices, flags
             gbs = algb * batch / (ms * 1e-3) / 1e9
             res[name] = {"kernel": "k_gather", "kernel_ms": ms, "samples_per_s": batch / (ms * 1e-3), "alg_bytes_per_sample": algb, "achieved_GBs": gbs,
-                         "frac": gbs / HBM_PEAK_GBS, "launches": reps, "note": "device time incl. the wrapper's own torch ops"}
+                         "frac": gbs / HBM_PEAK_GBS, "launches": reps, "wrapper_ms": ms_wrapped,
+                         "note": "kernel_ms: snac_replay_gather alone (raw C ABI); wrapper_ms: ReplayRing.gather, which also gathers action / reward / done with torch"}
 
         def facade_cfg(name, steps=3000):
             """The single-env drop-in class as a DQN script drives it (Env/2D/DMP_Env_2D_dynamic_usedata_plan.py: one env.step(action) per

@@ -3830,8 +3830,11 @@ static int replay_gather(const snac_env_desc* d, const snac_state* st, int32_t c
     g.obs = obs_ring; g.first = first_ring; g.plan_idx = plan_idx_ring; g.tick = tick_idx; g.env = env_idx;
     g.plans = st->plans; g.s = s_out; g.s_next = s_next_out; g.plan_out = plan_out;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)((batch + 15) / 16)), block(256);   // 4 waves x 4 samples (S of k_gather; 8 were no faster)
     const bool f32 = d->obs_dtype == SNAC_OBS_F32;
+    // (round 4: a variant that takes whole groups of 16 samples with 16-byte stores -- lane = piece of the group's consecutive rows --
+    // was built and measured: 0.0382 against 0.0352 ms per 65 536 samples for this kernel, which already runs at 5.3 TB/s = 0.66 of the
+    // peak; what rounds 2 and 3 reported as "0.23-0.30" was the Python wrapper's own index kernels.  Not kept; tools/gather_time.py)
+    const dim3 grid((unsigned)((batch + 15) / 16)), block(256);   // 4 waves x 4 samples (S of k_gather; 8 were no faster)
     void (*kern)(const GArgs);
     if (d->kind == SNAC_ENV_1D) kern = f32 ? k_gather<1, float> : k_gather<1, double>;
     else if (d->kind == SNAC_ENV_2D) kern = f32 ? k_gather<2, float> : k_gather<2, double>;

@@ -155,8 +155,11 @@ class ReplayRing:
             fn = e._lib.snac_replay_gather_tiled if self.tiled else e._lib.snac_replay_gather
             _lib.check(fn(C.byref(e._desc), C.byref(e._state), self.cap, _ptr(self.obs), _ptr(self.first),
                           _ptr(self.plan_idx), _ptr(slot), _ptr(env_index), B, _ptr(s), _ptr(s_next), _ptr(plan), e._stream()))
-        sl, ei = slot.long(), env_index.long()
-        out = dict(s=s, s_next=s_next, action=self.action[sl, ei].long(), reward=self.reward[sl, ei], done=self.done[sl, ei].bool())
+        # action / reward / done of the samples: ONE flat index and three 1-D gathers (two-index advanced indexing was five index
+        # kernels that took as long as the gather kernel itself, tools/gather_time.py)
+        flat = slot.long() * e.num_envs + env_index.long()
+        out = dict(s=s, s_next=s_next, action=self.action.view(-1)[flat].long(), reward=self.reward.view(-1)[flat],
+                   done=self.done.view(-1)[flat].bool())
         if with_plan:
             out["plan"] = plan if e.kind == 1 else plan.view(B, 20, 20)
         return out

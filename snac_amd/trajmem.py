@@ -141,7 +141,19 @@ def traj_empty(shape, dtype, device, pool_cap=0):
         numel *= int(d)
     nbytes = max(1, numel * torch.empty((), dtype=dtype).element_size())
     with torch.cuda.device(index):
-        block = _Block(nbytes, index, pool_cap)
+        try:
+            block = _Block(nbytes, index, pool_cap)
+        except _lib.SnacError as e:
+            # Address space: a freed block's range is never handed out again (snac_traj_free), so a process that has allocated and
+            # freed thousands of large blocks can run out of ranges to reserve (reserved_bytes() says how much is held).  The memory is
+            # still there: fall back to an ordinary hipMalloc tensor -- one physical run, the single-slice write rate -- and say so.
+            if "hipMemAddressReserve" not in str(e):
+                raise
+            import warnings
+
+            warnings.warn("snac_traj_alloc could not reserve an address range (%.0f GiB of dead ranges held): falling back to torch.empty"
+                          % (reserved_bytes() / 2 ** 30))
+            return torch.empty(tuple(int(d) for d in shape), dtype=dtype, device=torch.device("cuda", index))
         try:
             flat = torch.as_tensor(block, device=torch.device("cuda", index))
             if flat.data_ptr() != block.ptr:                     # a copy instead of a view: not what was asked for

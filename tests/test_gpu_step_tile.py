@@ -135,7 +135,8 @@ def test_fast_path_revalidates_tensors_that_were_changed_in_place():
     env.reset()
     acts = torch.zeros(n, dtype=torch.int8, device=env.device)
     ks = torch.ones(n, dtype=torch.int8, device=env.device)
-    out = (torch.empty((n, 51), dtype=torch.float64, device=env.device), torch.empty(n, dtype=torch.float32, device=env.device),
+    base = torch.empty(2 * n * 51, dtype=torch.float64, device=env.device)
+    out = (base[: n * 51].view(n, 51), torch.empty(n, dtype=torch.float32, device=env.device),
            torch.empty(n, dtype=torch.uint8, device=env.device))
     env.step(acts, ks, auto_reset=True, out=out)
     assert env._fast is not None
