@@ -127,6 +127,10 @@ __device__ __forceinline__ size_t tile_row(const int* rows, int env0, int e) {
 // shows stop growing.
 constexpr int CNT_MAX = 32767;
 __device__ __forceinline__ int clamp16(int v) { return min(max(v, -32768), 32767); }
+// episodic sums by no-return atomics (nothing waits for them)
+__device__ __forceinline__ void stat_add(int64_t* p, long long v) {
+    (void)__hip_atomic_fetch_add((unsigned long long*)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // per-lane env scalars (one env per lane in phase 1)
 struct Lane {
@@ -2546,6 +2550,148 @@ __global__ __launch_bounds__(WPB * 64) void k_transition3d(const KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3D tree edges with gathered rows, round 4 (snac_transition: Env/3D/DMP_simulator_3d_dynamic_triangle_MCTS.py:195-277, one call per
+// edge in script/MCTS/utils/mcts_Qvalue_dynamic.py:88,118).  k_transition3d issues, per edge, one record load, one record store, one
+// 49-lane gather of 2-byte window cells and one 408-byte row store: half of its memory instructions are narrow (0.48 of the peak for
+// its 2.06 KB per edge).  Here the records of a wave's 32 edges pass through LDS once and every memory instruction is wide:
+//   in      the 32 source records (800 bytes each) arrive as 16-byte pieces, lane = piece of the group's 1600 (the owning edge's row by
+//           ds_bpermute), 25 loads in flight, and lie in LDS as REC[edge][400 cells];
+//   step    lane = edge: the six neighbour / path cells from its record in LDS, K3D::step by selects (k_transition3d's formulation),
+//           the built cell patched into the record, the 7x7 window round the NEW position read back cell by cell (ds_read_i16);
+//   out     the records leave again as 16-byte pieces (an edge onto its own row writes its one changed cell instead), and the 32
+//           observation rows through emit_tile -- the staging tile reuses the records' LDS -- as 16-byte stores, 1 KiB per instruction.
+// 25 + 25 + 13 wide memory instructions per 32 edges instead of 128.  Conditions: gathered / scattered rows (an index array given),
+// canonical layout, observations wanted, m % 4 == 0 and a 16-byte aligned obs; everything else stays on k_transition3d.
+template <bool DYN, typename OT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_edges3d(const KArgs a) {
+    using K = K3D<DYN, 8>;
+    constexpr int E = 32, GE = K::GE, RECB = GE * 2;                 // 800 bytes per record
+    constexpr int WAVE_BYTES = E * RECB > TILE_STG_BYTES ? E * RECB : TILE_STG_BYTES;
+    __shared__ __attribute__((aligned(16))) char lds_all[WPB * WAVE_BYTES];
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const int edge0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * WPB + wv) * E);
+    if (edge0 >= a.n) return;
+    const int nedge = min(E, a.n - edge0);
+    const bool active = lane < nedge;
+    const int edge = edge0 + (active ? lane : 0);
+    char* const rec = lds_all + wv * WAVE_BYTES;
+    const int srow = (int)row_of(a.src_index, a.pool, edge), drow = (int)row_of(a.dst_index, a.pool, edge);
+    Lane s;
+    s.unpack(a.hdr[srow]);
+    int episode = a.episode[srow];
+    const uint64_t gid = (uint64_t)(a.env_id_base + edge);
+    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+    // ---- the records of the group: piece q = lane + 64 p of 1600, edge q / 50, 16-byte lane q % 50 of its record
+    {
+        const uint4* const g4 = (const uint4*)a.grid;
+        uint4 pv[25];
+#pragma unroll
+        for (int p = 0; p < 25; ++p) {
+            const int q = p * 64 + lane, e = q / 50, l = q - 50 * e;
+            const int se = __shfl(srow, e);
+            const bool fresh = __shfl((int)nr, e) != 0;
+            pv[p] = (e < nedge && !fresh) ? g4[(size_t)se * 50 + l] : make_uint4(0u, 0u, 0u, 0u);   // a freshly reset env is empty
+        }
+#pragma unroll
+        for (int p = 0; p < 25; ++p) *(uint4*)(rec + (p * 64 + lane) * 16) = pv[p];
+    }
+    if (nr) {
+        const int old_pidx = s.pidx, old_tb = s.tb;
+        episode += 1;
+        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    }
+    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+    if (a.actions) act = (int)a.actions[edge];
+    if (a.step_size) k = (int)a.step_size[edge];
+    k = min(max(k, 1), 3);
+    int16_t* const mine = (int16_t*)(rec + (lane & (E - 1)) * RECB);   // (lanes 32..63 shadow 0..31: nothing of theirs is stored)
+    // a cell of the edge's map in bordered coordinates: the frame is -1
+    auto cell = [&](int R, int C) -> int {
+        const bool in = (unsigned)(R - 3) < 20u && (unsigned)(C - 3) < 20u;
+        const int v = (int)mine[in ? (R - 3) * 20 + (C - 3) : 0];
+        return in ? v : -1;
+    };
+    const int d = act & 3;
+    const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
+    const int tr = s.r + dr - 3, tc = s.c + dc - 3;
+    const bool inside = (unsigned)tr < 20u && (unsigned)tc < 20u;
+    const int tcell = inside ? tr * 20 + tc : 0;
+    const int pl = ((const int16_t*)a.plans)[(size_t)s.pidx * GE + tcell];
+    const int n0 = cell(s.r, s.c - 1), n1 = cell(s.r, s.c + 1), n2 = cell(s.r + 1, s.c), n3 = cell(s.r - 1, s.c);
+    const int c2 = cell(s.r + 2 * dr, s.c + 2 * dc), c3 = cell(s.r + 3 * dr, s.c + 3 * dc);
+    // K3D::step by selects (the formulation of k_transition3d / Roll3D::tick)
+    const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
+    const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
+    const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
+    s.cs = min(s.cs + 1, CNT_MAX);
+    const bool can_move = valid && act < 4 && nd == 0;
+    const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;
+    s.r += can_move ? dr * m : 0;
+    s.c += can_move ? dc * m : 0;
+    const bool built = active && is_build && nd != -1;
+    const int newh = min(nd + 1, CNT_MAX);
+    s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
+    s.cross += (built && newh <= pl) ? 1 : 0;
+    const bool limit = s.cb >= s.tb + a.brick_gt;
+    bool done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);
+    int reward = 0;
+    const int rcheck = newh > pl ? -1 : (newh == pl ? 10 : 1);
+    if (DYN) {
+        const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
+        const bool fin = is_build && (boxed_post || limit);
+        reward = is_build ? (boxed_post ? -100 : ((!limit && built) ? rcheck : 0)) : 0;
+        done = fin ? true : ((is_build && built) ? false : done);
+    } else {
+        const bool fin = is_build && (limit || boxed_pre);
+        reward = (is_build && !fin && built) ? rcheck : 0;
+        done = fin ? true : ((is_build && built) ? false : done);
+    }
+    done = done && active;
+    s.ep_ret = clamp16(s.ep_ret + reward);
+    s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    if (built) mine[tcell] = (int16_t)newh;                          // the record and the window show the built cell
+    if (active) {
+        if (a.reward) a.reward[edge] = (float)reward;
+        if (a.done) a.done[edge] = done ? 1 : 0;
+        a.hdr[drow] = s.pack();
+        a.episode[drow] = episode;
+        if (a.stats_on && done) {                                    // (snac_step on gathered rows: episodic sums)
+            const double v = K::iou(nullptr, s, 0);
+            stat_add(a.stat_episodes + drow, 1);
+            stat_add(a.stat_return + drow, s.ep_ret);
+            stat_add(a.stat_iou_fx + drow, __double2ll_rn(v * FX40));
+        }
+    }
+    // ---- the window round the new position, lane = edge
+    int cellv[K::W];
+#pragma unroll
+    for (int el = 0; el < K::W; ++el) { const int i = el / 7, j = el - 7 * i; cellv[el] = cell(s.r - 3 + i, s.c - 3 + j); }
+    // ---- the records leave: 16-byte pieces again; an edge onto its own row (not freshly reset) writes its one changed cell instead
+    const bool copy = nr || drow != srow;
+    if (active && !copy && built) ((int16_t*)a.grid)[(size_t)drow * GE + tcell] = (int16_t)newh;
+    {
+        uint4* const g4w = (uint4*)a.grid;
+        uint4 pv[25];
+#pragma unroll
+        for (int p = 0; p < 25; ++p) pv[p] = *(const uint4*)(rec + (p * 64 + lane) * 16);
+#pragma unroll
+        for (int p = 0; p < 25; ++p) {
+            const int q = p * 64 + lane, e = q / 50, l = q - 50 * e;
+            const int de = __shfl(drow, e);
+            const bool cp = __shfl((int)copy, e) != 0;
+            if (e < nedge && cp) g4w[(size_t)de * 50 + l] = pv[p];
+        }
+    }
+    const double c0 = (double)s.cb, c1 = (double)s.cs;
+    const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
+    emit_tile<OT>(rec, (char*)a.obs + (size_t)edge0 * K::D * sizeof(OT), lane, nedge, [&](int el) { return cellv[el]; }, v0, v1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 2D single step / tree edge without the LDS image.  k_transition expands every 80-byte bit-board into the bordered two-bit
 // LDS image and squeezes it back (20 rows per edge, for a window that shows 7 of them and a step that changes one bit).
 // Here a wave takes E edges and nothing is staged:
@@ -2710,9 +2856,6 @@ __global__ __launch_bounds__(WPB * 64) void k_transition2d(const KArgs a) {
 // Write-back: the header, the episode counter of an env that was reset, the ONE changed row word / cell (a reset env: its record).
 // Identity rows only (snac_step, snac_step_scalar), canonical layout, N % 4 == 0 and a 16-byte aligned obs; everything else --
 // tree edges with gathered rows, layout variants, N = 1 of the single-env classes -- stays on k_transition2d / 3d / k_transition.
-__device__ __forceinline__ void stat_add(int64_t* p, long long v) {
-    (void)__hip_atomic_fetch_add((unsigned long long*)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 template <bool DYN, typename OT, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
@@ -3438,6 +3581,10 @@ KArgs make_args(const snac_env_desc* d, const snac_state* st) {
 
 enum Op { OP_ROLLOUT, OP_AUX, OP_TRANSITION };
 
+// which kernel the calling thread's last launch went to (snac_last_kernel(): bench.py and the tests name the kernel they measured
+// from here instead of restating the dispatch conditions)
+thread_local const char* g_kernel = "";
+
 template <class K, typename OT, int WPB>
 void launch_k(Op op, const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + K::E - 1) / K::E;
@@ -3639,6 +3786,16 @@ void launch_trans3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
         else { if (f32) hipLaunchKernelGGL((k_transition3d<false, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<false, double, 4, true>), grid, block, 0, s, a); }
         return;
     }
+    // gathered / scattered rows (tree edges): the records through LDS, every memory instruction wide (k_edges3d); SNAC_EDGES3D=0 keeps
+    // them on k_transition3d (A/B timing, tests of both paths)
+    static const bool edges_off = [] { const char* e = std::getenv("SNAC_EDGES3D"); return e && e[0] == '0'; }();
+    if (!edges_off && a.obs && (a.n & 3) == 0 && ((uintptr_t)a.obs & 15) == 0) {
+        g_kernel = "k_edges3d";
+        const dim3 g2((unsigned)((tiles + 1) / 2)), b2(128);     // two waves per block: 51 KB of LDS, three blocks per CU
+        if (dyn) { if (f32) hipLaunchKernelGGL((k_edges3d<true, float, 2>), g2, b2, 0, s, a); else hipLaunchKernelGGL((k_edges3d<true, double, 2>), g2, b2, 0, s, a); }
+        else { if (f32) hipLaunchKernelGGL((k_edges3d<false, float, 2>), g2, b2, 0, s, a); else hipLaunchKernelGGL((k_edges3d<false, double, 2>), g2, b2, 0, s, a); }
+        return;
+    }
     if (dyn) { if (f32) hipLaunchKernelGGL((k_transition3d<true, float, 4, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<true, double, 4, false>), grid, block, 0, s, a); }
     else { if (f32) hipLaunchKernelGGL((k_transition3d<false, float, 4, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_transition3d<false, double, 4, false>), grid, block, 0, s, a); }
 }
@@ -3669,10 +3826,6 @@ void launch_tile(Op op, bool dyn, int E, int obs_dtype, const KArgs& a, hipStrea
     else if (E == 16) dyn ? launch_dt<KT, true, 16, WPB>(op, obs_dtype, a, s) : launch_dt<KT, false, 16, WPB>(op, obs_dtype, a, s);
     else dyn ? launch_dt<KT, true, 8, 1>(op, obs_dtype, a, s) : launch_dt<KT, false, 8, 1>(op, obs_dtype, a, s);
 }
-
-// which kernel the calling thread's last launch went to (snac_last_kernel(): bench.py and the tests name the kernel they measured
-// from here instead of restating the conditions below)
-thread_local const char* g_kernel = "";
 
 int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     hipStream_t s = (hipStream_t)stream;

@@ -404,3 +404,47 @@ def test_large_waves_of_2d_edges(dyn, f32):
     idx = np.arange(0, pool, 1031)
     cb = env.count_brick.cpu().numpy()
     assert [int(cb[i]) for i in idx] == [int(orc.b.contents.envs[int(i)].cb) for i in idx]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
+def test_large_waves_of_3d_edges_through_lds(dyn, f32):
+    """Round 4: 3D tree edges with gathered rows take k_edges3d (the wave's 32 source records through LDS, 16-byte pieces in and out,
+    the rows through emit_tile) when m % 4 == 0 and the observations are 16-byte aligned.  A wave of 32 768 + 36 edges on a pool of
+    2^17 rows -- shared random parents, distinct children, a tenth of the edges in place, a ragged last group of 4 -- against the oracle,
+    a second wave on the children; and m % 4 != 0 (k_transition3d) gives the same rows for the same edges."""
+    import torch
+    from snac_amd import BatchedDMPEnv, _lib
+
+    pool, m = 1 << 17, 32768 + 36
+    table = helpers.plan_table(3, dyn, "dense_train" if dyn else "p1")
+    env = BatchedDMPEnv(3, dyn, pool, plans=table.reshape(len(table), 26, 26), seed=22, obs_dtype=torch.float32 if f32 else torch.float64)
+    orc = helpers.oracle().OracleBatch(3, dyn, pool, table, seed=22)
+    env.reset(); orc.reset()
+    env.rollout(25, obs=None); orc.rollout(25, obs=None, nthreads=16)
+    rng = np.random.default_rng(6)
+    for wave in range(2):
+        dst = (pool // 2 + rng.choice(pool // 2, m, replace=False)).astype(np.int32)
+        src = rng.integers(0, pool // 2, m).astype(np.int32)
+        inplace = rng.random(m) < 0.1
+        src = np.where(inplace, dst, src).astype(np.int32)
+        acts = rng.integers(0, 8, m).astype(np.int8)
+        ks = rng.integers(1, 4, m).astype(np.int8) if wave == 0 else None
+        o, r, d = env.transition(acts, ks, src, dst, t=wave)
+        assert _lib.lib().snac_last_kernel() == b"k_edges3d"
+        oo, ro, do = orc.transition(acts, ks, src, dst, t=wave)
+        assert o.cpu().numpy().tobytes() == (oo.astype(np.float32) if f32 else oo).tobytes(), wave
+        assert r.cpu().numpy().tobytes() == ro.tobytes() and np.array_equal(d.cpu().numpy().astype(np.uint8), do), wave
+    assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+    st = orc.state()
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(pool, -1), st["grid"].astype(np.float64))
+    # the other kernel on the same edges: m - 2 of them (m % 4 != 0), rows compared on the device
+    twin = env.fork(torch.arange(pool, device=env.device))
+    dst = (pool // 2 + rng.choice(pool // 2, m, replace=False)).astype(np.int32)
+    src = rng.integers(0, pool // 2, m).astype(np.int32)
+    acts = rng.integers(0, 8, m).astype(np.int8)
+    o1, r1, d1 = env.transition(acts, None, src, dst, t=7)
+    o2, r2, d2 = twin.transition(acts[: m - 2], None, src[: m - 2], dst[: m - 2], t=7)
+    assert _lib.lib().snac_last_kernel() == b"k_transition3d"
+    assert torch.equal(o1[: m - 2], o2) and torch.equal(r1[: m - 2], r2) and torch.equal(d1[: m - 2], d2)
