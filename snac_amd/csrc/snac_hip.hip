@@ -1648,16 +1648,30 @@ __global__ __launch_bounds__(576) void k_rollout3db(const KArgs a) {
     // element g % 51 of env g / 51: a window cell (an int16 of the staging tile, converted on the way out) or one of the two scalar
     // slots (a float64 the stepper published).  Where each of a lane's values comes from does not change from tick to tick:
     constexpr int VP = 16 / (int)sizeof(OT), NP = 8 * ROWB / 16, NQ = (NP + 63) / 64, NV = NQ * VP;
-    int src[NV];                                                     // byte offset into stg16, or into the tick's ssc half
-    unsigned scal = 0;                                               // bit i: value i is a scalar slot
+    // Only 16 of a wave's 408 values are scalar slots, at most KS of them in one lane's pieces: those are read as a short list (round 3
+    // read a float64 for every value of every lane: 8 of a writer's ~28 LDS instructions per tick -- and what the nine waves of a
+    // block do in LDS is what stretches the stepper's tick from 1000 to 1940 cycles).
+    constexpr int KS = VP == 2 ? 3 : 4;
+    int src[NV];                                                     // byte offset into stg16 (window cells)
+    int ksel[NV];                                                    // -1: a window cell; else which entry of the lane's scalar list
+    int ssrc[KS];                                                    // byte offsets into the tick's ssc half (unused entries: slot 0)
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    for (int kq = 0; kq < KS; ++kq) ssrc[kq] = 0;
+    {
+        int nk = 0;
 #pragma unroll
-        for (int u = 0; u < VP; ++u) {
-            const int pc = min(lane + 64 * q, NP - 1), g = pc * VP + u, e = g / 51, x = g - 51 * e;
-            src[q * VP + u] = x < 49 ? ((e0 + e) * 56 + (x / 7) * 8 + x % 7) * 2 : ((e0 + e) * 2 + (x - 49)) * 8;
-            scal |= x < 49 ? 0u : 1u << (q * VP + u);
-        }
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int u = 0; u < VP; ++u) {
+                const int pc = min(lane + 64 * q, NP - 1), g = pc * VP + u, e = g / 51, x = g - 51 * e;
+                const bool sc_slot = x >= 49 && lane + 64 * q < NP;
+                src[q * VP + u] = x < 49 ? ((e0 + e) * 56 + (x / 7) * 8 + x % 7) * 2 : 0;
+                ksel[q * VP + u] = sc_slot ? min(nk, KS - 1) : -1;
+#pragma unroll
+                for (int kq = 0; kq < KS; ++kq) ssrc[kq] = (sc_slot && nk == kq) ? ((e0 + e) * 2 + (x - 49)) * 8 : ssrc[kq];
+                nk += sc_slot ? 1 : 0;
+            }
+    }
     const int npieces = rows * ROWB / 16;
     int d_eps = 0, d_ret = 0;
     long long d_iou = 0;
@@ -1679,14 +1693,17 @@ __global__ __launch_bounds__(576) void k_rollout3db(const KArgs a) {
         }
         if (qt == 0 && pub.y >= 0) hme[pub.y & 0xffff] = (int16_t)(pub.y >> 16);
         // ---- gather: every read before the first write (the compiler cannot tell the staging tile from the maps)
-        const int16_t* const corner = hq + (pub.x & 0xff) * 26 + ((pub.x >> 8) & 0xff);
-        int cv[7];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) cv[j] = (int)corner[j];              // part 7 reads a row it does not use
+        // the window row's 7 cells start at any cell of the map: the 8 cells from the even cell at or below it are four aligned dwords
+        // (two ds_read2_b32 instead of seven ds_read_u16), shifted down a cell when the row starts on an odd one.  Part 7 reads a row
+        // it does not use; the eighth cell lies inside the block's maps for every position.
+        const int coff = (int)(hq - K::hmap(hm)) + (pub.x & 0xff) * 26 + ((pub.x >> 8) & 0xff);   // the row's first cell, in cells
+        const uint32_t* const cw = hm + (coff >> 1);
+        const uint32_t d0 = cw[0], d1 = cw[1], d2 = cw[2], d3 = cw[3];
         if (qt < 7) {                                                    // one aligned 16-byte write (a misaligned 14-byte row, then read back
-            uint4 w;                                                     // cell by cell, cost 0.45 us per tick: 1.52 instead of 1.08 ms)
-            w.x = (uint32_t)(cv[0] & 0xffff) | ((uint32_t)cv[1] << 16); w.y = (uint32_t)(cv[2] & 0xffff) | ((uint32_t)cv[3] << 16);
-            w.z = (uint32_t)(cv[4] & 0xffff) | ((uint32_t)cv[5] << 16); w.w = (uint32_t)(cv[6] & 0xffff);
+            const uint32_t shb = (uint32_t)(coff & 1) * 16u;             // cell by cell, cost 0.45 us per tick: 1.52 instead of 1.08 ms)
+            uint4 w;
+            w.x = __builtin_amdgcn_alignbit(d1, d0, shb); w.y = __builtin_amdgcn_alignbit(d2, d1, shb);
+            w.z = __builtin_amdgcn_alignbit(d3, d2, shb); w.w = (d3 >> shb) & 0xffffu;
             *(uint4*)srow = w;
         }
         // the wave's rows leave: its own LDS writes are visible to its own reads in order
@@ -1696,13 +1713,18 @@ __global__ __launch_bounds__(576) void k_rollout3db(const KArgs a) {
             const char* const scs = (const char*)ssc[par];
             int ci[NV];
 #pragma unroll
-            for (int i = 0; i < NV; ++i) ci[i] = (int)*(const int16_t*)(cells + ((scal >> i) & 1u ? 0 : src[i]));
-            double sc[NV];                                               // all reads of the tile before anything waits: a lane without a
-#pragma unroll                                                           // scalar slot at position i reads slot 0 (a broadcast)
-            for (int i = 0; i < NV; ++i) sc[i] = *(const double*)(scs + ((scal >> i) & 1u ? src[i] : 0));
+            for (int i = 0; i < NV; ++i) ci[i] = (int)*(const int16_t*)(cells + src[i]);
+            double sc[KS];                                               // all reads of the tile before anything waits
+#pragma unroll
+            for (int kq = 0; kq < KS; ++kq) sc[kq] = *(const double*)(scs + ssrc[kq]);
             OT val[NV];
 #pragma unroll
-            for (int i = 0; i < NV; ++i) val[i] = (scal >> i) & 1u ? (OT)sc[i] : (OT)ci[i];
+            for (int i = 0; i < NV; ++i) {
+                double sv = sc[0];
+#pragma unroll
+                for (int kq = 1; kq < KS; ++kq) sv = ksel[i] == kq ? sc[kq] : sv;
+                val[i] = ksel[i] >= 0 ? (OT)sv : (OT)ci[i];
+            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int pc = lane + 64 * q;
