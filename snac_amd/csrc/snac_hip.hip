@@ -1,21 +1,18 @@
-// snac_hip.hip -- gfx950 (MI355X) kernels and the C ABI of include/snac_hip.h.
+// snac_hip.hip -- gfx950 (MI355X) kernels and the C ABI of include/snac_hip.h (trajectory memory: snac_traj.hip).
 //
-// Execution shape (DESIGN.md "Kernel"): one wavefront owns a TILE of E consecutive envs (E = 8/16/32/64 by batch size; 3D: 8).
-//   phase 1  lane l steps env (tile base + l): counter RNG, move / drop / build transition, reward, done,
-//            auto-reset, episodic sums -- plain per-lane VALU code, the env grids live in this wave's LDS
-//   phase 2  the whole wave writes the tile's observations: for each env, lanes 0..48 fetch one window cell
-//            each from LDS, lanes 49/50 the two scalar slots, and the 51 values leave as one contiguous
-//            store; a tile therefore writes E x 408 contiguous bytes per step (5.9 TB/s store shape,
-//            profiles/r01_wr_bench.txt), against 3.7-3.9 TB/s for one 408-byte row per wave.
-// The env records are read from HBM once per launch, kept on chip for all T steps, written back once.
-// Round-1's first kernel ran one env per wave with the env scalars in SGPRs: it was bound by the CU's
-// single scalar ALU (67 SALU instructions per env-step, profiles/r01_a_*) and by the store shape.
-// Integer / indexing work only -- no MFMA; the bound is HBM (observation writes).
-// Besides the tile kernels (k_rollout, k_transition, k_aux) four kernels are shaped round what bounds their case, each with the
-// tile kernel behind it for everything else: k_rollout3d (3D rollouts: one late vmcnt wait per step, reward / done in whole runs),
-// k_rollout1dt (1D rollouts up to ~50 000 envs: a wave takes one env and 64 TICKS, the control chain as scans and ballots),
-// k_transition2d / k_transition3d (single steps and tree edges without LDS images).  Rollout outputs are [T][N][D] or, with
-// SNAC_OBS_TILED, tile-major [N / 64][T][64][D] (a tile streams through its own region: 6.9 instead of 6.0 TB/s of writes).
+// Integer / indexing work only -- no MFMA; the bound is HBM (observation rows written) or, for small batches, the chain of ticks.
+// DESIGN.md section 3 has the table of kernels with their measured times, launch() at the end of this file the dispatch.  In short:
+//   k_rollout2d    the headline: 2D rollouts on tiles of 64 envs, lane = env in the transition AND in the observation rows, which are
+//                  transposed through an LDS staging tile and leave 16 bytes per lane (emit_tile; layout variants: emit_rows_var);
+//                  plan rows per wave in LDS, refilled through the scalar cache; no vector load in the loop (vmcnt retires in order);
+//   k_rollout2dt   2D rollouts of small batches, time-parallel: one wave per env, lane = tick, stepper and writer waves per block;
+//   k_rollout1dt   the same idea for 1D (counters by ballots, positions by DPP scans, heights by per-cell lane masks);
+//   k_rollout3db   3D rollouts: one stepper wave (lane = env) and eight writer waves per 64 envs, one barrier per tick;
+//   k_rollout3d    3D rollouts of small / odd batches: 8 envs per wave, software-pipelined round the store stream;
+//   k_step2d / 3d  snac_step on identity rows: wide loads, rows through emit_tile;  k_edges3d: 3D tree edges, records through LDS;
+//   k_transition2d / 3d, and the tile kernels k_rollout / k_transition / k_aux (rounds 1-2) behind all of them for everything else.
+// The env records are read from HBM once per launch, kept on chip for all T steps, written back once.  Rollout outputs are [T][N][D]
+// or, with SNAC_OBS_TILED, tile-major [N / 64][T][64][D].
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
