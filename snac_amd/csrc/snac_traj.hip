@@ -268,13 +268,21 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
         const float t2 = launch_probe(pool.gva[ga], pool.gva[gb], TRAJ_CHUNK_LOG2, (int)TRAJ_WINDOW, 1, true);
         return 1000.f * (t1 < t2 ? t1 : t2);
     };
+    // the same for sorting the pool against a reference: ONE launch where the class is clear (noise only ever adds time, and every pair
+    // the block is made of is timed again as a pair), a second one between the levels -- half of the probe launches of a block
+    auto probe_class = [&](size_t ga, size_t gb, float self_us) -> float {
+        const float t1 = 1000.f * launch_probe(pool.gva[ga], pool.gva[gb], TRAJ_CHUNK_LOG2, (int)TRAJ_WINDOW, 1, true);
+        if (t1 <= 1.05f * self_us || t1 >= 1.18f * self_us) return t1;
+        const float t2 = 1000.f * launch_probe(pool.gva[ga], pool.gva[gb], TRAJ_CHUNK_LOG2, (int)TRAJ_WINDOW, 1, true);
+        return t1 < t2 ? t1 : t2;
+    };
     std::vector<size_t> order_a, order_b;                        // groups of class A (the reference's slice) / class B, surest first
     float fast_level = 0.f, slow_level = 0.f, t_self = 0.f;
     bool found = false;
     const auto tp0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count(); };
     if (ok) {
-        launch_probe(pool.gva[0], pool.gva[1], TRAJ_CHUNK_LOG2, (int)TRAJ_WINDOW, 120, false);   // ~20 ms of the probe itself: the clocks are up before anything is timed
+        launch_probe(pool.gva[0], pool.gva[1], TRAJ_CHUNK_LOG2, (int)TRAJ_WINDOW, 80, false);   // ~12 ms of the probe itself: the clocks are up before anything is timed
         if (hipGetLastError() != hipSuccess) ok = false;
         std::vector<float> t;                                    // us of group g against the current reference (0: not measured)
         std::vector<char> aside;                                 // groups of earlier references' slices: class B material
@@ -306,7 +314,7 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
             std::vector<size_t> part;                            // the partners measured against this reference
             for (size_t g = 0; g < pool.groups() && ok; ++g) {
                 if (g == ref || aside[g]) continue;
-                if (t[g] == 0.f) t[g] = probe(ref, g);
+                if (t[g] == 0.f) t[g] = probe_class(ref, g, t_self);
                 part.push_back(g);
                 lo = t[g] < lo ? t[g] : lo; hi = t[g] > hi ? t[g] : hi;
             }
@@ -381,7 +389,7 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
             t.resize(pool.groups(), 0.f); aside.resize(pool.groups(), 0);
             size_t nc = near_clean, fc = far_clean;
             for (size_t g = before; g < pool.groups() && ok; ++g) {
-                t[g] = probe(ref, g);
+                t[g] = probe_class(ref, g, t_self);
                 nc += t[g] >= 1.16f * t_self ? 1 : 0;
                 fc += t[g] <= 1.07f * t_self ? 1 : 0;
             }

@@ -26,7 +26,7 @@ def main():
     env = BatchedDMPEnv(2, True, n, seed=1)
     env.reset()
     held, ballast = [], []
-    stats = {"measured": 0, "fallback": 0, "slow_windows": 0, "rebuilds": 0, "worst_block_us": 0.0, "worst_build_s": 0.0, "rollout_ms": []}
+    stats = {"measured": 0, "small_one_run": 0, "fallback": 0, "slow_windows": 0, "rebuilds": 0, "worst_block_us": 0.0, "worst_build_s": 0.0, "rollout_ms": []}
     for b in range(blocks):
         # churn: ballast tensors come and go
         while ballast and rnd.random() < 0.5:
@@ -60,7 +60,7 @@ def main():
             ms = sorted(a.elapsed_time(c) for a, c in ev)[3]
             stats["rollout_ms"].append(round(ms, 3))
         meas = d["layout"].startswith("measured")
-        stats["measured" if meas else "fallback"] += 1
+        stats["measured" if meas else ("small_one_run" if d["layout"] == "one run" else "fallback")] += 1   # below 1 GiB: one run by design
         stats["slow_windows"] += d["windows_slow"]
         stats["rebuilds"] += d["rebuilds"]
         stats["worst_block_us"] = max(stats["worst_block_us"], d["us_per_gib"]["block"])
