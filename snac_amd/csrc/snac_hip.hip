@@ -955,7 +955,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout2d(const KArgs a) {
     // this tile's first byte of step 0, and the distance to the same place one step later: [T][N][D], or tile-major
     const bool tl = a.obs_mode == SNAC_OBS_TILED;
     const int LD = VAR ? a.ld : D;                                   // values per row: the layout variants append a tail
-    char* const obs0 = (char*)a.obs + (tl ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)a.tiled_t0) * 64 * LD : (size_t)env0 * LD) * sizeof(OT);
+    char* const obs0 = (char*)a.obs + (tl ? (((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)a.tiled_t0) * 64 + (size_t)(env0 & 63)) * LD : (size_t)env0 * LD) * sizeof(OT);
     const size_t tstride = (tl ? (size_t)64 * LD : (size_t)a.n * LD) * sizeof(OT);
     int na = 0, nk = 1;                                              // EXPL: the bytes of the coming tick
     if constexpr (EXPL) {
@@ -3863,7 +3863,15 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             // float32 rows from N = 32 768: 512 staged waves (1.05 -> 0.74 ms per 600 ticks); float64 rows there are level (1.26-1.60 ms
             // by box for either kernel) and stay on 32-env tiles
             if (op == OP_ROLLOUT && roll2dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout2dt"; launch_roll2dt(d, a, s); break; }
-            if (op == OP_ROLLOUT && roll2d_ok(a, (d->obs_dtype == SNAC_OBS_F32 && a.n >= 32768) ? 64 : E)) { g_kernel = "k_rollout2d"; launch_roll2d(d, a, s); break; }
+            {
+                // float64 rows from 32 769 envs (40 960: 1.56 against 1.99 ms per 600 ticks for the tile kernel's 32-env tiles, 49 152: 1.75 / 2.08,
+                // 57 344: 2.05 / 2.26; at 32 768 and below the tile kernel's 1024 waves of 32 envs are ahead: 1.25 against 1.43), float32
+                // rows from 32 768 (0.81 against 1.06); half-filled tiles -- 32 envs per wave on twice the waves -- were tried for
+                // 24 576 .. 32 768 envs and lose on trajectory memory (profiles/r04_2d_midrange.txt).  SNAC_2D_STAGE_MIN=n moves the limit.
+                static const int stage_min = [] { const char* e = std::getenv("SNAC_2D_STAGE_MIN"); return e ? std::atoi(e) : 0; }();
+                const int from = stage_min ? stage_min : (d->obs_dtype == SNAC_OBS_F32 ? 32768 : 32769);
+                if (op == OP_ROLLOUT && roll2d_ok(a, a.n >= from ? 64 : E)) { g_kernel = "k_rollout2d"; launch_roll2d(d, a, s); break; }
+            }
             launch_tile<K2D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
             if (op == OP_ROLLOUT && roll3db_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout3db"; launch_roll3db(d, a, s); break; }

@@ -67,25 +67,33 @@ def test_tiles_dtypes_and_launch_lengths(dyn, n, f32):
     _compare(env, orc, 3, t0, f32)                                # the records written back by the launches above carry on
 
 
+@pytest.mark.parametrize("n", [32768 + 36, 49152 + 4])
 @pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
-def test_float32_rows_take_the_staged_kernel_from_32768_envs(dyn):
-    """With float32 rows the staged kernel pays from N = 32 768 (512 waves of 64 envs); float64 rows of the same batch stay on 32-env
-    tiles of the tile kernel -- both against the oracle, and against each other."""
+def test_the_staged_kernel_from_32769_envs(dyn, n):
+    """Above 32 768 envs both row types take the staged kernel (float32 rows from 32 768 on; round 3: float64 only from 65 536) --
+    float32 and float64 rows of the same batch against the oracle and against each other, a ragged last tile, the tile-major output."""
     import torch
+    from snac_amd import _lib
 
-    n = 32768 + 36
     env, orc = _pair(dyn, n, seed=6, total_step=30, obs_dtype=torch.float32)
     ref, _ = _pair(dyn, n, seed=6, total_step=30)
     t0 = 0
     for T in (1, 37):
         og, rg, dg = env.rollout(T)
+        assert _lib.lib().snac_last_kernel() == b"k_rollout2d"
         o2, r2, d2 = ref.rollout(T)
+        assert _lib.lib().snac_last_kernel() == b"k_rollout2d"
         oc, rc, dc = orc.rollout(T, t0=t0, nthreads=16)
         assert og.cpu().numpy().tobytes() == oc.astype(np.float32).tobytes() and o2.cpu().numpy().tobytes() == oc.tobytes()
         assert rg.cpu().numpy().tobytes() == rc.tobytes() and torch.equal(rg, r2) and torch.equal(dg, d2)
         t0 += T
     _end_state(env, orc)
     assert torch.equal(env._hdr, ref._hdr) and torch.equal(env._grid, ref._grid) and torch.equal(env._stats, ref._stats)
+    twin = ref.fork(torch.arange(n, device=ref.device))
+    ot, _, _ = ref.rollout(5, obs="tiled")
+    assert _lib.lib().snac_last_kernel() == b"k_rollout2d"
+    on, _, _ = twin.rollout(5)
+    assert torch.equal(ref.untile(ot), on)
 
 
 @pytest.mark.parametrize("rules", [(False, False), (True, False), (False, True), (True, True)], ids=str)
