@@ -2274,9 +2274,20 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
                         OT val[VP];
 #pragma unroll
                         for (int v = 0; v < VP; ++v) {
+                            // cell or scalar slot by a BIT select on a per-lane mask (v_bfi_b32): written as `kind ? a : b` the compiler
+                            // keeps the kinds as exec masks in spilled SGPRs and spends nine scalar instructions and a branch per value
                             const int f = fsrc[q][v];
+                            const uint32_t m = (uint32_t)-(f >> 24);             // all ones: a scalar slot
                             const int cv = ((int)(lo[q][v] << ((f >> 16) & 0xff))) >> 30;
-                            val[v] = (f >> 24) ? (OT)__longlong_as_double((long long)(((uint64_t)hi[q][v] << 32) | lo[q][v])) : (OT)cv;
+                            if constexpr (sizeof(OT) == 8) {
+                                const uint64_t cb = (uint64_t)__double_as_longlong((double)cv);
+                                const uint32_t rl = (m & lo[q][v]) | (~m & (uint32_t)cb), rh = (m & hi[q][v]) | (~m & (uint32_t)(cb >> 32));
+                                val[v] = (OT)__longlong_as_double((long long)(((uint64_t)rh << 32) | rl));
+                            } else {
+                                const float sf = (float)__longlong_as_double((long long)(((uint64_t)hi[q][v] << 32) | lo[q][v]));
+                                const uint32_t rb = (m & (uint32_t)__float_as_int(sf)) | (~m & (uint32_t)__float_as_int((float)cv));
+                                val[v] = (OT)__int_as_float((int)rb);
+                            }
                         }
                         if (lq + 64 * q < pt) {
                             if constexpr (VP == 2) { double2 o; o.x = val[0]; o.y = val[1]; *(double2*)(orun + q * 1024) = o; }
