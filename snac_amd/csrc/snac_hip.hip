@@ -798,6 +798,7 @@ __device__ __forceinline__ void emit_rows_var(char* stg, uint32_t* cmp, char* g,
     for (int i = 0; i < 7; ++i) { const int pc = min(lane + 64 * i, 399); prow[i] = pc / 20; pbit[i] = pc - 20 * prow[i]; }
     // U envs at a time, every LDS read of the batch issued before its first write: the compiler cannot tell the staging rows from the
     // records and the plan rows, and one env per round trip made a tick latency-bound (64 round trips: 11 instead of 4.6 us per tick)
+    const uint32_t m_sc = (uint32_t)-(int)(kind == 1), m_int = (uint32_t)-(int)(kind == 2);   // all ones: a scalar slot / an integer value
     auto batch = [&](auto uc, int e, int e0) {
         constexpr int U = decltype(uc)::value;
         uint32_t lo[U], hi[U], pw[U][7];
@@ -813,9 +814,13 @@ __device__ __forceinline__ void emit_rows_var(char* stg, uint32_t* cmp, char* g,
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            // which of the three forms a lane's value takes is a per-lane constant: bit selects on masks (written as `kind == ..` selects
+            // the compiler keeps the kinds as exec masks and pays for them in scalar instructions and branches, cf. k_rollout2dt)
             const int cv = ((int)(lo[u] << sh)) >> 30;               // signed 2-bit field: 0 / 1 / -1
-            const double val = kind == 0 ? (double)(cv < 0 ? frame_val : cv)
-                                         : (kind == 1 ? __longlong_as_double((long long)(((uint64_t)hi[u] << 32) | lo[u])) : (double)(int)lo[u]);
+            const uint32_t iv = (m_int & lo[u]) | (~m_int & (uint32_t)(cv < 0 ? frame_val : cv));
+            const uint64_t cb = (uint64_t)__double_as_longlong((double)(int)iv);
+            const uint32_t rl = (m_sc & lo[u]) | (~m_sc & (uint32_t)cb), rh = (m_sc & hi[u]) | (~m_sc & (uint32_t)(cb >> 32));
+            const double val = __longlong_as_double((long long)(((uint64_t)rh << 32) | rl));
             OT* const row = (OT*)stg + (e + u - e0) * LD;
             if (lane < NE) row[dst] = (OT)val;
             if (plan_n) {
