@@ -3737,15 +3737,22 @@ void launch_roll2d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     else f32 ? launch_roll2d_w<false, float>(a, s) : launch_roll2d_w<false, double>(a, s);
 }
 
-// time-parallel 2D rollouts (one wave per env, lane = tick): small batches, where the lane-per-env kernels are bound by the chain of
-// their ticks (0.5-0.7 ms per 600 ticks at every N <= 16 384).  SNAC_2D_TP=0 keeps them on the tile kernel (A/B timing, tests of both
-// paths), SNAC_2D_TP_MAX=n moves the upper batch limit
+// time-parallel 2D rollouts (one wave per env, lane = tick): small and middle batches, where the lane-per-env kernels are bound by the
+// chain of their ticks (0.5-0.7 ms per 600 ticks at every N <= 16 384) or leave CUs empty (one wave of 64 envs per CU at N = 16 384).
+// Where it stops paying was measured on trajectory memory (profiles/r04_2d_midrange.txt, part 3): float64 rows up to 19 456 envs --
+// except just below 16 384, where the tile kernel's 256 waves fill the chip exactly (5.8 against 5.55 TB/s) --, float32 rows up to
+// 30 719 (16 384 envs: 4.2 against 2.9 TB/s); batches whose per-tick runs are not 16-byte pieces (odd N) only up to 8192.
+// SNAC_2D_TP=0 keeps every 2D rollout off this kernel (A/B timing, tests of both paths), SNAC_2D_TP_MAX=n replaces the limits by n
 bool roll2dt_ok(const KArgs& a, bool f32) {
     static const bool off = [] { const char* e = std::getenv("SNAC_2D_TP"); return e && e[0] == '0'; }();
     static const int nmax = [] { const char* e = std::getenv("SNAC_2D_TP_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
-    const int lim = nmax ? nmax : 16383;
-    (void)f32;
-    return !off && a.n <= lim && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && !pipeline_off();
+    if (off || a.variant || !(a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) || pipeline_off()) return false;
+    if (nmax) return a.n <= nmax;
+    const size_t rowb = (size_t)K2D<true, 64>::D * (f32 ? 4 : 8);
+    const bool pieces = (((uintptr_t)a.obs) & 15) == 0 && (a.obs_mode == SNAC_OBS_TILED || (((size_t)a.n * rowb) & 15) == 0);
+    if (!pieces) return a.n <= 8192;
+    if (f32) return a.n < 30720;
+    return a.n <= 15872 || (a.n > 16384 && a.n <= 19456);
 }
 template <bool DYN, typename OT, int EB>
 void launch_roll2dt_e(const KArgs& a, hipStream_t s) {
