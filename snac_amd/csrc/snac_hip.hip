@@ -1796,6 +1796,13 @@ __global__ __launch_bounds__(576) void k_rollout3db(const KArgs a) {
 // Semantics are K1D::step's; counter-RNG or explicit inputs; SNAC_OBS_ALL / SNAC_OBS_TILED, the canonical layout.
 // data-parallel primitives: lanes without a source (or outside ROWS) receive `idv`.  0x110 + n: row_shr n; 0x142 / 0x143: lane 15 / 31
 // of the rows before to the whole next row(s); 0x138: the wave shifted up by one lane
+// (m & a) | (~m & b) as the one instruction it is (left to itself the compiler hoists ~m out of a loop and issues two)
+__device__ __forceinline__ uint32_t bfi32(uint32_t m, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+
 template <int CTRL, int ROWS = 0xf>
 __device__ __forceinline__ int dpp_from(int idv, int v) { return __builtin_amdgcn_update_dpp(idv, v, CTRL, ROWS, 0xf, false); }
 
@@ -2040,11 +2047,13 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
     constexpr int TSTR = EB * RECW + 4;                              // staging dwords per tick (+4: the lanes' 16-byte writes spread over the banks)
     // A block is 2 EB waves: EB STEPPERS (one env each: the control chain of a chunk of 64 ticks, compact rows into staging buffer c & 1)
     // and EB WRITERS, which expand the chunk before (buffer (c - 1) & 1) while the steppers are at the next one -- one barrier per
-    // chunk.  With one wave per SIMD (N <= 1024) a chunk costs max(stepping, expanding) instead of their sum.
+    // chunk.  With one wave per SIMD (N <= 1024) a chunk costs max(stepping, expanding) instead of their sum.  The ticks to expand are
+    // a queue both kinds of wave draw from (the steppers once their chunk is stepped): the two halves of a chunk level out at every N.
     __shared__ uint32_t sG[EB][GE], sP[EB][GE];
     __shared__ __align__(16) uint32_t stage2[2][64 * TSTR];
     __shared__ float sR2[2][64][EB + 1];
     __shared__ __align__(16) uint8_t sD2[2][64][EB];
+    __shared__ int tickq[2];                                         // next tick to expand, per staging buffer
     const int tid = (int)threadIdx.x, lane = tid & 63, wall = tid >> 6;
     const bool stepper = wall < EB;
     const int wv = wall & (EB - 1);                                  // the stepper's env of the block / the writer's share of the ticks
@@ -2106,6 +2115,7 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
         uint32_t* const stage = stage2[ch & 1];
         float (*const sR)[EB + 1] = sR2[ch & 1];
         uint8_t (*const sD)[EB] = sD2[ch & 1];
+        if (tid == 2 * EB * 64 - 1) tickq[ch & 1] = 0;               // the queue of THIS chunk's ticks, drawn from in the next round
         if (own && ch < nchunks) {
         const bool valid = lane < nl;
         const int t = t0 + lane;
@@ -2237,19 +2247,28 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
             first_lane = last + 1;
         }
         }
-        // ---- the chunk before leaves: per tick one run of the block's rows, expanded from the compact rows by the writer waves
-        if (!stepper && ch > 0) {
+        // ---- the chunk before leaves: per tick one run of the block's rows, expanded from the compact rows.  The ticks are a QUEUE
+        // (a counter in LDS): the writer waves draw from it from the start, the stepper waves once their chunk is stepped -- from
+        // 2048 envs on the expansion is the longer half of a chunk (writers alone 1.0e10 env-steps/s at N = 4096, steppers alone
+        // 2.2e10), below it the stepping: whoever is free takes the next tick
+        if (ch > 0) {
             const int t0 = (ch - 1) * 64;
             const int nl = min(64, a.T - t0);
             const uint32_t* const stage = stage2[(ch - 1) & 1];
             const float (*const sR)[EB + 1] = sR2[(ch - 1) & 1];
             const uint8_t (*const sD)[EB] = sD2[(ch - 1) & 1];
+            int* const queue = &tickq[(ch - 1) & 1];
             int t0v = t0, wq = wv, lq = lane;
             asm volatile("" : "+s"(t0v), "+v"(wq), "+v"(lq));        // addresses from scratch every chunk (k_rollout1dt)
             const size_t row0 = tl ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)(a.tiled_t0 + t0v)) * 64 + (size_t)(env0 & 63)
                                    : (size_t)t0v * (size_t)a.n + (size_t)env0;
             char* const ob = (char*)a.obs + row0 * ROWB;
-            constexpr int TPW = 64 / EB;                             // ticks per wave
+            constexpr int TPW = 64 / EB;                             // ticks per writer wave (reward / done)
+            auto draw = [&]() -> int {                               // the next tick of the queue, wave-uniform
+                int v = 0;
+                if (lq == 0) v = atomicAdd(queue, 1);
+                return __builtin_amdgcn_readfirstlane(v);
+            };
             auto value = [&](const uint32_t* rec, int el) -> OT {    // element el of the compact row rec
                 if (el < K::W) {
                     const int i = el / 7, j = el - 7 * i;
@@ -2260,9 +2279,10 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
             };
             if (vec) {
                 const int pt = nenv * ROWB / 16;
-                for (int i = 0; i < TPW; ++i) {
-                    const int tk = wq * TPW + i;
-                    if (tk >= nl) break;
+                int nxt = draw();
+                while (nxt < nl) {
+                    const int tk = nxt;
+                    nxt = draw();                                    // the draw after this one travels while the tick is expanded
                     const uint32_t* const trow = stage + tk * TSTR;
                     char* const orun = ob + (size_t)tk * ostr + lq * 16;
                     uint32_t lo[NQ][VP], hi[NQ][VP];                 // every LDS read of the tick first: one round trip per tick, not per piece
@@ -2284,14 +2304,13 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
                             const int f = fsrc[q][v];
                             const uint32_t m = (uint32_t)-(f >> 24);             // all ones: a scalar slot
                             const int cv = ((int)(lo[q][v] << ((f >> 16) & 0xff))) >> 30;
-                            if constexpr (sizeof(OT) == 8) {
-                                const uint64_t cb = (uint64_t)__double_as_longlong((double)cv);
-                                const uint32_t rl = (m & lo[q][v]) | (~m & (uint32_t)cb), rh = (m & hi[q][v]) | (~m & (uint32_t)(cb >> 32));
+                            if constexpr (sizeof(OT) == 8) {       // a cell's double has a zero low word: one AND, one v_bfi_b32
+                                const uint32_t ch = (uint32_t)((uint64_t)__double_as_longlong((double)cv) >> 32);
+                                const uint32_t rl = m & lo[q][v], rh = bfi32(m, hi[q][v], ch);
                                 val[v] = (OT)__longlong_as_double((long long)(((uint64_t)rh << 32) | rl));
                             } else {
                                 const float sf = (float)__longlong_as_double((long long)(((uint64_t)hi[q][v] << 32) | lo[q][v]));
-                                const uint32_t rb = (m & (uint32_t)__float_as_int(sf)) | (~m & (uint32_t)__float_as_int((float)cv));
-                                val[v] = (OT)__int_as_float((int)rb);
+                                val[v] = (OT)__int_as_float((int)bfi32(m, (uint32_t)__float_as_int(sf), (uint32_t)__float_as_int((float)cv)));
                             }
                         }
                         if (lq + 64 * q < pt) {
@@ -2302,24 +2321,23 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
                 }
             } else {
                 const int pe = nenv * D;                             // ragged or unaligned: element by element, still in runs
-                for (int i = 0; i < TPW; ++i) {
-                    const int tk = wq * TPW + i;
-                    if (tk < nl)
-                        for (int gel = lq; gel < pe; gel += 64) {
-                            const int e = gel / D;
-                            ((OT*)(ob + (size_t)tk * ostr))[gel] = value(stage + tk * TSTR + e * RECW, gel - e * D);
-                        }
-                }
+                for (int tk = draw(); tk < nl; tk = draw())
+                    for (int gel = lq; gel < pe; gel += 64) {
+                        const int e = gel / D;
+                        ((OT*)(ob + (size_t)tk * ostr))[gel] = value(stage + tk * TSTR + e * RECW, gel - e * D);
+                    }
             }
-            // reward / done: 64 / EB ticks x EB envs per wave, one instruction each
-            const size_t rw0 = (size_t)t0v * (size_t)a.n + (size_t)env0;
-            const int tk = wq * TPW + lq / EB, e = lq & (EB - 1);
-            const bool mine = tk < nl && e < nenv;
-            if (a.reward && mine) a.reward[rw0 + (size_t)tk * (size_t)a.n + e] = sR[tk][e];
-            if (dvec) {
-                const int wt = tid - EB * 64;                        // the writers' thread index
-                if (wt < nl) *(uint4*)(a.done + rw0 + (size_t)wt * (size_t)a.n) = *(const uint4*)sD[wt];
-            } else if (a.done && mine) a.done[rw0 + (size_t)tk * (size_t)a.n + e] = sD[tk][e];
+            if (!stepper) {
+                // reward / done: 64 / EB ticks x EB envs per writer wave, one instruction each
+                const size_t rw0 = (size_t)t0v * (size_t)a.n + (size_t)env0;
+                const int tk = wq * TPW + lq / EB, e = lq & (EB - 1);
+                const bool mine = tk < nl && e < nenv;
+                if (a.reward && mine) a.reward[rw0 + (size_t)tk * (size_t)a.n + e] = sR[tk][e];
+                if (dvec) {
+                    const int wt = tid - EB * 64;                    // the writers' thread index
+                    if (wt < nl) *(uint4*)(a.done + rw0 + (size_t)wt * (size_t)a.n) = *(const uint4*)sD[wt];
+                } else if (a.done && mine) a.done[rw0 + (size_t)tk * (size_t)a.n + e] = sD[tk][e];
+            }
         }
         __syncthreads();
     }
