@@ -2053,7 +2053,7 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
     __shared__ __align__(16) uint32_t stage2[2][64 * TSTR];
     __shared__ float sR2[2][64][EB + 1];
     __shared__ __align__(16) uint8_t sD2[2][64][EB];
-    __shared__ int tickq[2];                                         // next tick to expand, per staging buffer
+    __shared__ unsigned int tickq[2];                                // next tick to expand, per staging buffer
     const int tid = (int)threadIdx.x, lane = tid & 63, wall = tid >> 6;
     const bool stepper = wall < EB;
     const int wv = wall & (EB - 1);                                  // the stepper's env of the block / the writer's share of the ticks
@@ -2177,23 +2177,27 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
             const int br = lane == first_lane ? r0 : prv_r, bc = lane == first_lane ? c0 : prv_c;   // before the tick: where a drop lands
             // ---- the window round the new position from the board as the chunk found it (k_step2d's encoding) ...
             uint32_t wr[7];
+            uint32_t gdrop = G[min(max(br - 3, 0), GE - 1)], pdrop = P[min(max(br - 3, 0), GE - 1)];   // the drop's row: board and plan
             {
                 const int sh = pc - 3;                               // first window column, bordered: 0..19
                 constexpr uint32_t FRAME26 = 0x3800007u;             // frame columns 0-2 and 23-25 of an interior row
                 const uint32_t frm = spread16((FRAME26 >> sh) & 0x7Fu) * 3u;
+                uint32_t g[7];                                       // the seven rows in ONE round trip: left to the compiler each read
+#pragma unroll                                                       // sinks into its row's `inb` branch and is waited for there
+                for (int i = 0; i < 7; ++i) g[i] = G[min(max(pr - 6 + i, 0), GE - 1)];
+                asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(gdrop), "+v"(pdrop));
 #pragma unroll
                 for (int i = 0; i < 7; ++i) {
                     const int q = pr - 6 + i;                        // board row of window row i
                     const bool inb = (unsigned)q < (unsigned)GE;
-                    const uint32_t g = G[inb ? q : 0];
-                    wr[i] = inb ? (spread16(((g << 3) >> sh) & 0x7Fu) | frm) : 0x3FFFu;
+                    wr[i] = inb ? (spread16(((g[i] << 3) >> sh) & 0x7Fu) | frm) : 0x3FFFu;
                 }
             }
             // ... OR the bricks dropped earlier in this segment: every dropper in turn (wave-uniform), its cell against each later
             // lane's window, and against each later dropper's own cell ("was": the cell was taken by then)
             const int bcell = br * 32 + bc;                          // where this lane's drop lands
-            bool was = ((G[min(max(br - 3, 0), GE - 1)] >> (bc - 3)) & 1u) != 0u;
-            const bool planned = ((P[min(max(br - 3, 0), GE - 1)] >> (bc - 3)) & 1u) != 0u;
+            bool was = ((gdrop >> (bc - 3)) & 1u) != 0u;
+            const bool planned = ((pdrop >> (bc - 3)) & 1u) != 0u;
             unsigned long long dmask = 0ull;
             const unsigned long long inm = __ballot(in);
             for (unsigned long long m = dropm & inm; m; m &= m - 1) {
@@ -2257,18 +2261,21 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
             const uint32_t* const stage = stage2[(ch - 1) & 1];
             const float (*const sR)[EB + 1] = sR2[(ch - 1) & 1];
             const uint8_t (*const sD)[EB] = sD2[(ch - 1) & 1];
-            int* const queue = &tickq[(ch - 1) & 1];
+            unsigned int* const queue = &tickq[(ch - 1) & 1];
             int t0v = t0, wq = wv, lq = lane;
             asm volatile("" : "+s"(t0v), "+v"(wq), "+v"(lq));        // addresses from scratch every chunk (k_rollout1dt)
             const size_t row0 = tl ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)(a.tiled_t0 + t0v)) * 64 + (size_t)(env0 & 63)
                                    : (size_t)t0v * (size_t)a.n + (size_t)env0;
             char* const ob = (char*)a.obs + row0 * ROWB;
             constexpr int TPW = 64 / EB;                             // ticks per writer wave (reward / done)
-            auto draw = [&]() -> int {                               // the next tick of the queue, wave-uniform
+            // the next tick of the queue, wave-uniform -- in two halves, so that the counter's round trip can run beside the LDS reads
+            // of the tick in hand (LDS answers in order: behind those reads the draw has arrived too)
+            auto draw_issue = [&]() -> int {
                 int v = 0;
-                if (lq == 0) v = atomicAdd(queue, 1);
-                return __builtin_amdgcn_readfirstlane(v);
+                if (lq == 0) v = (int)atomicInc(queue, 0xffffffffu);   // (ds_inc_rtn_u32: the compiler's wave-aggregation
+                return v;                                                           // of atomicAdd waits for its answer on the spot)
             };
+            auto draw = [&]() -> int { return __builtin_amdgcn_readfirstlane(draw_issue()); };
             auto value = [&](const uint32_t* rec, int el) -> OT {    // element el of the compact row rec
                 if (el < K::W) {
                     const int i = el / 7, j = el - 7 * i;
@@ -2279,10 +2286,9 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
             };
             if (vec) {
                 const int pt = nenv * ROWB / 16;
-                int nxt = draw();
-                while (nxt < nl) {
-                    const int tk = nxt;
-                    nxt = draw();                                    // the draw after this one travels while the tick is expanded
+                int tk = draw();
+                while (tk < nl) {
+                    int pend = draw_issue();                         // the draw after this one travels with the tick's reads
                     const uint32_t* const trow = stage + tk * TSTR;
                     char* const orun = ob + (size_t)tk * ostr + lq * 16;
                     uint32_t lo[NQ][VP], hi[NQ][VP];                 // every LDS read of the tick first: one round trip per tick, not per piece
@@ -2293,7 +2299,7 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
                             const uint32_t* const sp = trow + (fsrc[q][v] & 0xffff);
                             lo[q][v] = sp[0]; hi[q][v] = sp[1];
                         }
-                    asm volatile("" ::: "memory");
+                    asm volatile("" : "+v"(pend) :: "memory");
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         OT val[VP];
@@ -2318,6 +2324,7 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
                             else { float4 o; o.x = val[0]; o.y = val[1]; o.z = val[2]; o.w = val[3]; *(float4*)(orun + q * 1024) = o; }
                         }
                     }
+                    tk = __builtin_amdgcn_readfirstlane(pend);
                 }
             } else {
                 const int pe = nenv * D;                             // ragged or unaligned: element by element, still in runs
@@ -3780,9 +3787,9 @@ void launch_roll2dt_e(const KArgs& a, hipStream_t s) {
 }
 template <bool DYN, typename OT>
 void launch_roll2dt_w(const KArgs& a, hipStream_t s) {
-    static const int emin = [] { const char* e = std::getenv("SNAC_2D_TP_EB8"); return e ? std::atoi(e) : 2048; }();   // (tuning)
+    static const int emin = [] { const char* e = std::getenv("SNAC_2D_TP_EB8"); return e ? std::atoi(e) : 1025; }();   // (tuning)
     if (a.n >= emin) launch_roll2dt_e<DYN, OT, 8>(a, s);       // 8 envs per block: runs of 3264 / 1632 bytes per tick
-    else launch_roll2dt_e<DYN, OT, 4>(a, s);                        // small batches: more blocks than CUs first
+    else launch_roll2dt_e<DYN, OT, 4>(a, s);                        // up to 1024 envs: a block per CU first (1536 envs: 0.097 against 0.086 ms)
 }
 void launch_roll2dt(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;

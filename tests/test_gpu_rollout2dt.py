@@ -1,5 +1,6 @@
-"""GPU: the time-parallel 2D rollout kernel (k_rollout2dt, round 4: one wavefront per env, lane = tick, blocks of 4 (below 2048
-envs) or 8 stepper waves and as many writer waves, compact rows through a double-buffered staging tile) against the CPU oracle, and
+"""GPU: the time-parallel 2D rollout kernel (k_rollout2dt, round 4: one wavefront per env, lane = tick, blocks of 4 (up to 1024
+envs) or 8 stepper waves and as many writer waves, compact rows through a double-buffered staging tile, the ticks to expand a queue
+both kinds of wave draw from) against the CPU oracle, and
 its borders in the dispatch: float64 rows up to 15 872 and from 16 385 to 19 456 envs, float32 rows below 30 720, batches whose
 per-tick runs are not 16-byte pieces (odd N, unaligned outputs) up to 8192 -- the tile kernel / k_rollout2d beyond.  Every test
 names the kernel it expects (snac_last_kernel).  Ragged blocks and blocks with idle waves, canonical and tile-major layouts,
@@ -56,11 +57,11 @@ def _end_state(env, orc):
 
 
 @pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
-@pytest.mark.parametrize("n", [1, 3, 13, 1001, 2046, 2048, 2052, 4100, 8191, 15872])
+@pytest.mark.parametrize("n", [1, 3, 13, 1001, 1024, 1026, 2046, 4100, 8191, 15872])
 def test_batch_shapes_and_tick_counts(dyn, n):
-    """n = 1 / 3 / 13 / 1001 / 2046: blocks of 4 envs, the last one ragged, odd N (rows leave element by element); 2048: the first batch
-    in blocks of 8; 2052 / 4100: a last block of 4 envs and four idle stepper waves; 8191: the largest odd batch of this kernel;
-    15 872: the last one below the tile kernel's full chip.  Launches of 1, 2, 37 and 80 steps; the time limit of 60 ends an episode
+    """n = 1 / 3 / 13 / 1001: blocks of 4 envs, the last one ragged, odd N (rows leave element by element); 1024: the last batch in
+    blocks of 4; 1026 / 2046: blocks of 8, a last block of 2 / 6 envs and idle stepper waves (which still draw ticks to expand); 4100: a
+    last block of 4; 8191: the largest odd batch of this kernel; 15 872: the last one below the tile kernel's full chip.  Launches of 1, 2, 37 and 80 steps; the time limit of 60 ends an episode
     in every launch of 80."""
     env, orc = _pair(dyn, n, seed=5, total_step=60)
     t0 = 0
