@@ -215,3 +215,58 @@ def test_config3_headline_pass_as_one_launch():
 def test_config5_3d_pass_as_one_launch():
     """BASELINE configs[4] as one launch of the 3D block kernel (k_rollout3db): rollout(1000) of 16 384 envs."""
     _one_launch(3, True, 16384, 1000, 125, "dense_train")
+
+
+BIG = [
+    # kind, N, T, float32 rows, kernel of the whole batch: every output below holds more than 2^31 values
+    (2, 131072, 330, True, "k_rollout2d"),                           # 2.2e9 values, 8.8 GB
+    (2, 8192, 5400, True, "k_rollout2dt"),                           # 2.26e9 values: 85 chunks of 64 ticks, rows [T][N] beyond 2^31 values
+    (2, 24576, 1800, True, "k_rollout2dt"),
+    (2, 24576, 1800, False, "k_rollout"),                            # the tile kernel, 18 GB
+    (3, 65536, 660, True, "k_rollout3db"),                           # 2.21e9 values
+    (3, 4088, 10900, True, "k_rollout3d"),                           # 2.27e9 values
+]
+
+
+@pytest.mark.parametrize("kind,n,T,f32,kernel", BIG, ids=lambda v: str(v))
+def test_outputs_of_more_than_2_31_values(kind, n, T, f32, kernel):
+    """Element and row indices beyond 2^31 (the headline's output is 2.0e9 values: just below).  The whole batch in one launch against
+    the same envs stepped as two half batches (env_id_base shifts the counter-RNG ids; each half's output is below 2^31 values, sizes
+    the other tests cover against the oracle), compared on the device in slabs of ticks; the last slab and the end state also
+    against the oracle for a window of envs at the far end of the batch."""
+    import torch
+    from snac_amd import BatchedDMPEnv, _lib
+
+    dt = torch.float32 if f32 else torch.float64
+    table = helpers.plan_table(kind, True, "dense_train")
+    full = table.reshape(len(table), 26, 26)
+    h = n // 2
+    big = BatchedDMPEnv(kind, True, n, plans=full, seed=13, obs_dtype=dt)
+    lo = BatchedDMPEnv(kind, True, h, plans=full, seed=13, obs_dtype=dt)
+    hi = BatchedDMPEnv(kind, True, h, plans=full, seed=13, obs_dtype=dt, env_id_base=h)
+    for e in (big, lo, hi):
+        e.reset()
+    ob, rb, db = big.rollout(T)
+    assert _lib.lib().snac_last_kernel().decode() == kernel
+    assert ob.numel() > 2 ** 31
+    ol, rl, dl = lo.rollout(T)
+    oh, rh, dh = hi.rollout(T)
+    step = max(1, (1 << 28) // (n * big.obs_dim))
+    for t0 in range(0, T, step):
+        t1 = min(T, t0 + step)
+        assert torch.equal(ob[t0:t1, :h], ol[t0:t1]) and torch.equal(ob[t0:t1, h:], oh[t0:t1]), (t0, t1)
+    assert torch.equal(rb[:, :h], rl) and torch.equal(rb[:, h:], rh) and torch.equal(db[:, :h], dl) and torch.equal(db[:, h:], dh)
+    assert torch.equal(big._hdr[:h], lo._hdr) and torch.equal(big._hdr[h:], hi._hdr)
+    assert torch.equal(big._grid[:h], lo._grid) and torch.equal(big._grid[h:], hi._grid)
+    # the far corner against the oracle: the last 64 envs over the last ticks (the oracle steps them from the start, keeps the tail)
+    w = 64
+    orc = helpers.oracle().OracleBatch(kind, True, w, table, seed=13, env_id_base=n - w)
+    orc.reset()
+    keep = min(T, 40)
+    if T > keep:
+        orc.rollout(T - keep, t0=0, obs=None, nthreads=16)
+    oc, rc, dc = orc.rollout(keep, t0=T - keep, nthreads=16)
+    want = oc.astype(np.float32) if f32 else oc
+    assert ob[T - keep:, n - w:].cpu().numpy().tobytes() == want.tobytes()
+    assert rb[T - keep:, n - w:].cpu().numpy().tobytes() == rc.tobytes()
+    assert np.array_equal(db[T - keep:, n - w:].cpu().numpy().view(np.uint8), dc)
