@@ -215,3 +215,32 @@ def test_tiled_ring_equals_the_tick_ring(n):
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
     qa, qb = a.sample_sequences(40, 6, generator=ga), b.sample_sequences(40, 6, generator=gb)
     assert all(torch.equal(qa[k], qb[k]) for k in qa)
+
+
+@pytest.mark.parametrize("layout", ["ticks", "tiled"])
+def test_a_ring_of_more_than_2_31_values(layout):
+    """A ring of 65 536 envs x 700 ticks holds 2.34e9 float32 values (the gather's row offsets pass 2^31): samples from its far end
+    equal those of a small ring that follows the batch's last 64 envs alone (env_id_base keys the counter RNG)."""
+    import torch
+    from snac_amd import BatchedDMPEnv, ReplayRing
+
+    n, cap, w = 65536, 700, 64
+    table = helpers.plan_table(2, True, "dense_train")
+    full = table.reshape(len(table), 26, 26)
+    big = BatchedDMPEnv(2, True, n, plans=full, seed=8, obs_dtype=torch.float32, total_step=150)
+    small = BatchedDMPEnv(2, True, w, plans=full, seed=8, obs_dtype=torch.float32, total_step=150, env_id_base=n - w)
+    big.reset()
+    small.reset()
+    rb, rs = ReplayRing(big, cap, layout=layout), ReplayRing(small, cap, layout=layout)
+    assert rb.obs.numel() > 2 ** 31
+    for T in (300, 400):
+        rb.collect(T)
+        rs.collect(T)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    slot = torch.randint(cap - 80, cap, (4096,), device="cuda", generator=g)
+    e = torch.randint(0, w, (4096,), device="cuda", generator=g)
+    a, b = rb.gather(slot, e + (n - w)), rs.gather(slot, e)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(rb.obs_at(cap - 1)[n - w:], rs.obs_at(cap - 1))
