@@ -2092,7 +2092,7 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
     // the block -- a window cell (source: code i of the env's compact row, 2-bit field j) or a scalar slot.  The same for every tick.
     constexpr int VP = 16 / (int)sizeof(OT);                         // values per 16-byte piece
     constexpr int PTMAX = EB * ROWB / 16, NQ = (PTMAX + 63) / 64;
-    int fsrc[NQ][VP];                                                // dword offset in the tick's staging row | shift << 16 | scalar << 24
+    int fsrc[NQ][VP];                                                // dword offset in the tick's staging row | first bit of the cell in its code word << 16 | scalar << 24
     if (vec) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
@@ -2102,7 +2102,7 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
                 const int e = gel / D, el = gel - e * D;
                 if (el < K::W) {
                     const int i = el / 7, j = el - 7 * i;
-                    fsrc[q][v] = (e * RECW + (i >> 1)) | ((30 - 2 * j - (i & 1) * 16) << 16);
+                    fsrc[q][v] = (e * RECW + (i >> 1)) | ((2 * j + (i & 1) * 16) << 16);   // the cell's two bits: their place in the code word
                 } else {
                     fsrc[q][v] = (e * RECW + 4 + 2 * (el - K::W)) | (1 << 24);
                 }
@@ -2309,7 +2309,7 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
                             // keeps the kinds as exec masks in spilled SGPRs and spends nine scalar instructions and a branch per value
                             const int f = fsrc[q][v];
                             const uint32_t m = (uint32_t)-(f >> 24);             // all ones: a scalar slot
-                            const int cv = ((int)(lo[q][v] << ((f >> 16) & 0xff))) >> 30;
+                            const int cv = __builtin_amdgcn_sbfe((int)lo[q][v], (uint32_t)(f >> 16) & 0xffu, 2u);   // v_bfe_i32: 0 / 1 / -1
                             if constexpr (sizeof(OT) == 8) {       // a cell's double has a zero low word: one AND, one v_bfi_b32
                                 const uint32_t ch = (uint32_t)((uint64_t)__double_as_longlong((double)cv) >> 32);
                                 const uint32_t rl = m & lo[q][v], rh = bfi32(m, hi[q][v], ch);
