@@ -764,16 +764,16 @@ __device__ __forceinline__ OT bit_as(uint32_t word, int bit) {
     else return (OT)__int_as_float(m & 0x3F800000);
 }
 
-template <typename OT, class PF>
+template <typename OT, int STG_BYTES = VAR_STG_BYTES, int UMAX = 8, class PF>
 __device__ __forceinline__ void emit_rows_var(char* stg, uint32_t* cmp, char* g, int lane, int nenv, int LD, int tail, int frame_val,
                                               const uint32_t (&wr)[7], double v0, double v1, const int (&recv)[8], PF plan) {
     constexpr int D = 51, W = 49;
     const int RB = LD * (int)sizeof(OT);
     int G = 64;
-    while (G * RB > VAR_STG_BYTES) G >>= 1;
+    while (G * RB > STG_BYTES) G >>= 1;
     const int pos_n = (tail & SNAC_TAIL_POSITION) ? 2 : 0, plan_n = (tail & SNAC_TAIL_PLAN) ? 400 : 0, rec_n = (tail & SNAC_TAIL_RECORD) ? 8 : 0;
     const int NE = D + pos_n + rec_n;                                // values of a row that come from the compact record (<= 61)
-    {
+    if (lane < nenv) {                                               // (cmp holds nenv records: k_rollout2dt's writers pass 4)
         uint32_t* const mine = cmp + lane * VAR_CMP_WORDS;
 #pragma unroll
         for (int i = 0; i < 7; ++i) mine[i] = wr[i];
@@ -854,7 +854,11 @@ __device__ __forceinline__ void emit_rows_var(char* stg, uint32_t* cmp, char* g,
             }
         } else {
             int e = e0;
-            for (; e + 8 <= e0 + ge; e += 8) batch(std::integral_constant<int, 8>{}, e, e0);
+            if constexpr (UMAX >= 8) {
+                for (; e + 8 <= e0 + ge; e += 8) batch(std::integral_constant<int, 8>{}, e, e0);
+            } else if constexpr (UMAX >= 4) {                        // (callers with four envs at a time: no eight-env batch to hold registers for)
+                for (; e + 4 <= e0 + ge; e += 4) batch(std::integral_constant<int, 4>{}, e, e0);
+            }
             for (; e + 2 <= e0 + ge; e += 2) batch(std::integral_constant<int, 2>{}, e, e0);
         }
         const int valid = ge * RB;                                   // a multiple of 16
@@ -872,7 +876,7 @@ __device__ __forceinline__ void emit_rows_var(char* stg, uint32_t* cmp, char* g,
         {
             uint4 fv[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) fv[k] = *(const uint4*)(stg + min((i + k) * 1024 + lane * 16, VAR_STG_BYTES - 16));
+            for (int k = 0; k < 4; ++k) fv[k] = *(const uint4*)(stg + min((i + k) * 1024 + lane * 16, STG_BYTES - 16));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (i + k < full) *(uint4*)(gh + (i + k) * 1024) = fv[k];
@@ -2038,13 +2042,94 @@ __global__ __launch_bounds__(EB * 64, 16 / EB) void k_rollout1dt(const KArgs a) 
 //              lane's values in a run does not depend on the tick and is worked out once per launch).
 // ~8 + 4.5 wave-instructions per env-step (the lane-per-env kernel: 4.2), but nothing waits for the tick before: N = 1024 x 600 ticks
 // takes ~0.03 ms instead of 0.51.  Semantics are K2D::step's; counter-RNG or explicit inputs; SNAC_OBS_ALL / SNAC_OBS_TILED, canonical layout.
-template <bool DYN, typename OT, int EB, bool EXPL>
-__global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
+// Row assembly for k_rollout2dt's layout variants: the rows of ONE tick's nenv (<= 4, even) envs from their compact records
+// rec[e * 16 ..] (codes 2 per dword, the two scalar doubles, the record's eight ints) and the envs' plan rows planw[e * 20 ..], through
+// the calling wave's staging tile (STG bytes) to g, 16 bytes per lane.  emit_rows_var's scheme -- lane = value: lanes 0 .. 60 the head
+// (window cells, scalar slots, position, record), lane + 64 i the plan cells -- cut down to few registers (one or two envs at a time,
+// nothing kept across them), so that sixteen waves of 128 registers fit a CU: with emit_rows_var inlined the writers needed 256.
+template <typename OT, int STG>
+__device__ __forceinline__ void emit_rows_lean(char* stg, const uint32_t* rec, const uint32_t* planw, char* g, int lane, int nenv, int LD,
+                                               int tail, int frame_val) {
+    constexpr int D = 51, W = 49;
+    const int RB = LD * (int)sizeof(OT);
+    const int G = 4 * RB <= STG ? 4 : 2;                             // envs per flush: G * RB is a multiple of 16 (float32 rows: always 4)
+    const int pos_n = (tail & SNAC_TAIL_POSITION) ? 2 : 0, plan_n = (tail & SNAC_TAIL_PLAN) ? 400 : 0, rec_n = (tail & SNAC_TAIL_RECORD) ? 8 : 0;
+    const int NE = D + pos_n + rec_n;
+    // this lane's head value: dword of the record, first bit of a cell's field, kind masks, place in the row
+    int src, off = 0, dst = lane;
+    uint32_t m_sc = 0u, m_int = 0u;
+    if (lane < W) { const int i = lane / 7, j = lane - 7 * i; src = i >> 1; off = 2 * j + 16 * (i & 1); }
+    else if (lane < D) { src = 4 + 2 * (lane - W); m_sc = ~0u; }
+    else {
+        int k = lane - D;
+        m_int = ~0u;
+        if (k < pos_n) { src = 10 + k; dst = D + k; }
+        else { k -= pos_n; src = 8 + min(k, 7); dst = D + pos_n + plan_n + k; }
+    }
+    for (int e0 = 0; e0 < nenv; e0 += G) {
+        const int ge = min(G, nenv - e0);
+#pragma unroll 1
+        for (int e = e0; e < e0 + ge; e += 2) {                      // two envs at a time: their LDS reads first
+            uint32_t lo[2], hi[2], pw[2][7];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t* const c = rec + (e + u) * 16 + src;
+                lo[u] = c[0]; hi[u] = c[1];
+                if (plan_n) {
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) pw[u][i] = planw[(e + u) * 20 + min(lane + 64 * i, 399) / 20];
+                }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cv = __builtin_amdgcn_sbfe((int)lo[u], (uint32_t)off, 2u);        // 0 / 1 / -1 (frame)
+                const uint32_t iv = bfi32(m_int, lo[u], (uint32_t)(cv < 0 ? frame_val : cv));
+                const uint64_t cb = (uint64_t)__double_as_longlong((double)(int)iv);
+                const uint32_t rl = bfi32(m_sc, lo[u], (uint32_t)cb), rh = bfi32(m_sc, hi[u], (uint32_t)(cb >> 32));
+                const double val = __longlong_as_double((long long)(((uint64_t)rh << 32) | rl));
+                OT* const row = (OT*)stg + (e + u - e0) * LD;
+                if (lane < NE) row[dst] = (OT)val;
+                if (plan_n) {
+                    OT* const q = row + D + pos_n;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        const int pc = min(lane + 64 * i, 399);
+                        if (i < 6 || lane < 16) q[lane + 64 * i] = bit_as<OT>(pw[u][i], pc - 20 * (pc / 20));
+                    }
+                }
+            }
+        }
+        // the group leaves: ge * RB bytes, a multiple of 16
+        const int valid = ge * RB;
+        char* const gh = g + (size_t)e0 * RB + lane * 16;
+        const char* const sh = stg + lane * 16;
+        for (int i = 0; i * 1024 < valid; i += 4) {                  // four 1 KiB store instructions at a time, their LDS reads first
+            uint4 fv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fv[k] = *(const uint4*)(sh + min((i + k) * 1024, STG - 1024));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((i + k) * 1024 + lane * 16 < valid) *(uint4*)(gh + (i + k) * 1024) = fv[k];
+        }
+    }
+}
+
+// VAR: the layout variants of snac_env_desc (frame value, raw / normalised counters, position / plan / record tails: rows of a.ld
+// values).  The steppers file eight more dwords per row (reward, done, position, counters, total_brick, plan row), and only the WR
+// writer waves expand: a writer assembles a tick's EB rows from their compact rows with emit_rows_lean (k_rollout2d's scheme:
+// lane = value, groups of envs through a staging tile of its own, 16 bytes per lane out).  The plan tail's cells come
+// from a per-writer copy of each env's plan row in LDS, refilled through the scalar cache when a tick's row differs from the copy
+// (any number of resets per chunk).  N % 4 = 0 and a 16-byte aligned output.
+template <bool DYN, typename OT, int EB, bool EXPL, bool VAR = false, int WR = EB>
+__global__ __launch_bounds__((EB + WR) * 64) void k_rollout2dt(const KArgs a) {
     using K = K2D<DYN, 64>;
     constexpr int D = K::D, GE = K::GE;
     constexpr int ROWB = D * (int)sizeof(OT);                        // 408 / 204 bytes per row
-    constexpr int RECW = 8;                                          // dwords per compact row: 7 codes in 4 dwords, two doubles
+    constexpr int RECW = VAR ? 16 : 8;                               // dwords per compact row: 7 codes in 4 dwords, two doubles (+ the record's 8 values)
     constexpr int TSTR = EB * RECW + 4;                              // staging dwords per tick (+4: the lanes' 16-byte writes spread over the banks)
+    constexpr int VSTG = 8192;                                       // VAR: a writer's staging tile (two 451-value float64 rows)
+    static_assert(VAR || WR == EB, "the canonical layout splits reward / done by writer wave");
     // A block is 2 EB waves: EB STEPPERS (one env each: the control chain of a chunk of 64 ticks, compact rows into staging buffer c & 1)
     // and EB WRITERS, which expand the chunk before (buffer (c - 1) & 1) while the steppers are at the next one -- one barrier per
     // chunk.  With one wave per SIMD (N <= 1024) a chunk costs max(stepping, expanding) instead of their sum.  The ticks to expand are
@@ -2054,15 +2139,17 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
     __shared__ float sR2[2][64][EB + 1];
     __shared__ __align__(16) uint8_t sD2[2][64][EB];
     __shared__ unsigned int tickq[2];                                // next tick to expand, per staging buffer
+    __shared__ __align__(16) char vstg[VAR ? WR : 1][VAR ? VSTG : 16];
+    __shared__ uint32_t vplan[VAR ? WR : 1][VAR ? EB * GE : 1];
     const int tid = (int)threadIdx.x, lane = tid & 63, wall = tid >> 6;
     const bool stepper = wall < EB;
-    const int wv = wall & (EB - 1);                                  // the stepper's env of the block / the writer's share of the ticks
+    const int wv = stepper ? wall : (VAR ? wall - EB : (wall & (EB - 1)));   // the stepper's env of the block / the writer's index
     const int env0 = (int)blockIdx.x * EB;
     const int nenv = min(EB, a.n - env0);                            // block-uniform; > 0 by the grid
     const bool own = stepper && wv < nenv;                           // steppers past the batch only keep the barriers company
     const int env = env0 + ((stepper && wv < nenv) ? wv : 0);
-    uint32_t* const G = sG[wv];                                      // the board as the current chunk found it: 20 interior row words
-    uint32_t* const P = sP[wv];                                      // the env's plan rows
+    uint32_t* const G = sG[stepper ? wv : 0];                        // the board as the current chunk found it: 20 interior row words
+    uint32_t* const P = sP[stepper ? wv : 0];                        // the env's plan rows
     Lane s;
     s.unpack(a.hdr[env]);
     int episode = a.episode[env];
@@ -2085,15 +2172,19 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
     const bool tl = a.obs_mode == SNAC_OBS_TILED;
     const double dT = (double)a.total_step, rT = 1.0 / dT;
     // the block's rows of one tick are one run of nenv x ROWB bytes; 16-byte pieces when every run starts and ends on 16 bytes
-    const size_t ostr = (tl ? (size_t)64 : (size_t)a.n) * ROWB;      // bytes from one tick's run to the next
-    const bool vec = ((((uintptr_t)a.obs) | (uintptr_t)ostr | (uintptr_t)((size_t)nenv * ROWB)) & 15) == 0;
+    const int RB = VAR ? a.ld * (int)sizeof(OT) : ROWB;              // bytes per row
+    const size_t ostr = (tl ? (size_t)64 : (size_t)a.n) * RB;        // bytes from one tick's run to the next
+    const bool vec = ((((uintptr_t)a.obs) | (uintptr_t)ostr | (uintptr_t)((size_t)nenv * RB)) & 15) == 0;
     const bool dvec = EB == 16 && a.done && nenv == EB && ((((uintptr_t)a.done) | (uintptr_t)a.n) & 15) == 0;
+    int ptag[EB];                                                    // VAR writers: the plan row each env's LDS copy holds
+#pragma unroll
+    for (int e = 0; e < EB; ++e) ptag[e] = -1;
     // ---- what this lane expands when a run leaves: piece lane + 64 q of the run holds VP values; value v of it is element el of env e of
     // the block -- a window cell (source: code i of the env's compact row, 2-bit field j) or a scalar slot.  The same for every tick.
     constexpr int VP = 16 / (int)sizeof(OT);                         // values per 16-byte piece
     constexpr int PTMAX = EB * ROWB / 16, NQ = (PTMAX + 63) / 64;
     int fsrc[NQ][VP];                                                // dword offset in the tick's staging row | first bit of the cell in its code word << 16 | scalar << 24
-    if (vec) {
+    if (!VAR && vec) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -2216,7 +2307,7 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
             if (in) {
                 const double q0v = (double)cb, q1v = (double)cs;
                 double v0 = q0v, v1 = q1v;
-                if (DYN) {                                           // cb / tb, cs / T: correctly rounded (Roll3D, tests/native/recip_check.c)
+                if (VAR ? (a.sc_norm != 0) : DYN) {                  // cb / tb, cs / T: correctly rounded (Roll3D, tests/native/recip_check.c)
                     const double q0 = q0v * rtb, q1 = q1v * rT;
                     v0 = tb > 0 ? __builtin_fma(__builtin_fma(-q0, dtb, q0v), rtb, q0) : q0v / dtb;
                     v1 = __builtin_fma(__builtin_fma(-q1, dT, q1v), rT, q1);
@@ -2225,6 +2316,10 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
                 const uint64_t b0 = (uint64_t)__double_as_longlong(v0), b1 = (uint64_t)__double_as_longlong(v1);
                 *(uint4*)o = make_uint4(wr[0] | (wr[1] << 16), wr[2] | (wr[3] << 16), wr[4] | (wr[5] << 16), wr[6]);
                 *(uint4*)(o + 4) = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
+                if constexpr (VAR) {                                 // SNAC_TAIL_RECORD's values (record_value), position, the plan row
+                    *(uint4*)(o + 8) = make_uint4((uint32_t)reward, (lane == last && donem) ? 1u : 0u, (uint32_t)pr, (uint32_t)pc);
+                    *(uint4*)(o + 12) = make_uint4((uint32_t)cb, (uint32_t)cs, (uint32_t)tb, (uint32_t)pidx);
+                }
                 sR[lane][wv] = (float)reward;
                 sD[lane][wv] = (lane == last && donem) ? 1 : 0;
                 if (a.actions_out) a.actions_out[row] = (int8_t)act;
@@ -2266,7 +2361,7 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
             asm volatile("" : "+s"(t0v), "+v"(wq), "+v"(lq));        // addresses from scratch every chunk (k_rollout1dt)
             const size_t row0 = tl ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)(a.tiled_t0 + t0v)) * 64 + (size_t)(env0 & 63)
                                    : (size_t)t0v * (size_t)a.n + (size_t)env0;
-            char* const ob = (char*)a.obs + row0 * ROWB;
+            char* const ob = (char*)a.obs + row0 * RB;
             constexpr int TPW = 64 / EB;                             // ticks per writer wave (reward / done)
             // the next tick of the queue, wave-uniform -- in two halves, so that the counter's round trip can run beside the LDS reads
             // of the tick in hand (LDS answers in order: behind those reads the draw has arrived too)
@@ -2284,7 +2379,39 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
                 }
                 return (OT)__longlong_as_double((long long)(((uint64_t)rec[5 + 2 * (el - K::W)] << 32) | rec[4 + 2 * (el - K::W)]));
             };
-            if (vec) {
+            if constexpr (VAR) {
+                if (!stepper) {
+                    char* const stg = vstg[wv];
+                    uint32_t* const wP = vplan[wv];
+                    const size_t rw0 = (size_t)t0v * (size_t)a.n + (size_t)env0;
+                    for (int tk = draw(); tk < nl; tk = draw()) {
+                        const uint32_t* const rec = stage + tk * TSTR;
+                        if (a.tail & SNAC_TAIL_PLAN) {
+                            const int pq = (int)rec[min(lq, EB - 1) * RECW + 15];                  // lane e: env e's plan row at this tick
+#pragma unroll
+                            for (int e = 0; e < EB; ++e) {
+                                const int pe = __builtin_amdgcn_readlane(pq, e);                   // wave-uniform: the row comes through the scalar cache
+                                if (e < nenv && pe != ptag[e]) {
+                                    cmem_u32* const src = (cmem_u32*)(uintptr_t)a.plans + (size_t)pe * GE;
+                                    uint32_t rw[GE];
+#pragma unroll
+                                    for (int q = 0; q < GE; ++q) rw[q] = src[q];
+                                    if (lq == 0) {
+#pragma unroll
+                                        for (int q = 0; q < GE; ++q) wP[e * GE + q] = rw[q];
+                                    }
+                                    ptag[e] = pe;
+                                }
+                            }
+                        }
+                        emit_rows_lean<OT, VSTG>(stg, rec, wP, ob + (size_t)tk * ostr, lq, nenv, a.ld, a.tail, a.frame_val);
+                        if (lq < nenv) {                             // four envs per tick: small stores beside rows of kilobytes
+                            if (a.reward) a.reward[rw0 + (size_t)tk * (size_t)a.n + lq] = sR[tk][lq];
+                            if (a.done) a.done[rw0 + (size_t)tk * (size_t)a.n + lq] = sD[tk][lq];
+                        }
+                    }
+                }
+            } else if (vec) {
                 const int pt = nenv * ROWB / 16;
                 int tk = draw();
                 while (tk < nl) {
@@ -2334,7 +2461,7 @@ __global__ __launch_bounds__(2 * EB * 64) void k_rollout2dt(const KArgs a) {
                         ((OT*)(ob + (size_t)tk * ostr))[gel] = value(stage + tk * TSTR + e * RECW, gel - e * D);
                     }
             }
-            if (!stepper) {
+            if (!VAR && !stepper) {
                 // reward / done: 64 / EB ticks x EB envs per writer wave, one instruction each
                 const size_t rw0 = (size_t)t0v * (size_t)a.n + (size_t)env0;
                 const int tk = wq * TPW + lq / EB, e = lq & (EB - 1);
@@ -3771,7 +3898,16 @@ void launch_roll2d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
 bool roll2dt_ok(const KArgs& a, bool f32) {
     static const bool off = [] { const char* e = std::getenv("SNAC_2D_TP"); return e && e[0] == '0'; }();
     static const int nmax = [] { const char* e = std::getenv("SNAC_2D_TP_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
-    if (off || a.variant || !(a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) || pipeline_off()) return false;
+    if (off || !(a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) || pipeline_off()) return false;
+    if (a.variant) {
+        // the layout variants (rows of a.ld values: k_rollout2dt<.., VAR>): whole groups of four envs and 16-byte pieces only.  Where
+        // the lane-per-env kernels take over again was measured with the 451-value rows of the PPO copies (profiles/r04_2d_layouts.txt)
+        // (profiles/r04_2d_layouts.txt, part 3): 6.0 TB/s from 1024 envs on against k_rollout2d's 5.45 at 49 152 envs and 7.2 at 65 536;
+        // short rows (no plan tail: 53 .. 61 values) level off at 5.4e9 env-steps/s and hand over near 8192 envs
+        static const int vmax = [] { const char* e = std::getenv("SNAC_2D_TP_VAR_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
+        const int lim = vmax ? vmax : ((a.tail & SNAC_TAIL_PLAN) ? 49152 : 8192);
+        return (a.n & 3) == 0 && (((uintptr_t)a.obs) & 15) == 0 && a.n <= lim;
+    }
     if (nmax) return a.n <= nmax;
     const size_t rowb = (size_t)K2D<true, 64>::D * (f32 ? 4 : 8);
     const bool pieces = (((uintptr_t)a.obs) & 15) == 0 && (a.obs_mode == SNAC_OBS_TILED || (((size_t)a.n * rowb) & 15) == 0);
@@ -3785,8 +3921,22 @@ void launch_roll2dt_e(const KArgs& a, hipStream_t s) {
     if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout2dt<DYN, OT, EB, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_rollout2dt<DYN, OT, EB, false>), grid, block, 0, s, a);
 }
+template <bool DYN, typename OT, int WR>
+void launch_roll2dt_var_w(const KArgs& a, hipStream_t s) {
+    constexpr int EB = 4;
+    const dim3 grid((unsigned)((a.n + EB - 1) / EB)), block((EB + WR) * 64);
+    if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout2dt<DYN, OT, EB, true, true, WR>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_rollout2dt<DYN, OT, EB, false, true, WR>), grid, block, 0, s, a);
+}
+template <bool DYN, typename OT>
+void launch_roll2dt_var(const KArgs& a, hipStream_t s) {
+    static const int wr = [] { const char* e = std::getenv("SNAC_2D_TP_VAR_WR"); return e ? std::atoi(e) : 12; }();   // (tuning)
+    if (wr == 4) launch_roll2dt_var_w<DYN, OT, 4>(a, s);
+    else launch_roll2dt_var_w<DYN, OT, 12>(a, s);
+}
 template <bool DYN, typename OT>
 void launch_roll2dt_w(const KArgs& a, hipStream_t s) {
+    if (a.variant) { launch_roll2dt_var<DYN, OT>(a, s); return; }
     static const int emin = [] { const char* e = std::getenv("SNAC_2D_TP_EB8"); return e ? std::atoi(e) : 1025; }();   // (tuning)
     if (a.n >= emin) launch_roll2dt_e<DYN, OT, 8>(a, s);       // 8 envs per block: runs of 3264 / 1632 bytes per tick
     else launch_roll2dt_e<DYN, OT, 4>(a, s);                        // up to 1024 envs: a block per CU first (1536 envs: 0.097 against 0.086 ms)

@@ -236,3 +236,94 @@ def test_replay_rings_filled_by_the_time_parallel_kernel():
     sa, sb = a.sample(300, generator=ga), b.sample(300, generator=gb)
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
     assert torch.equal(envs[0]._hdr, envs[1]._hdr) and torch.equal(envs[0]._grid, envs[1]._grid)
+
+
+VARIANTS = [
+    dict(layout="lnet2d"),                                           # 51 + position, frame value 2, normalised scalars on a static plan
+    dict(layout="ppo"),                                              # 451 values: window, raw counters, the 400 plan cells
+    dict(obs_tail=("record",)),                                      # 59
+    dict(obs_tail=("position", "plan", "record"), frame_value=2, obs_scalars="raw"),   # 461
+]
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("kw", VARIANTS, ids=["lnet2d", "ppo", "record", "all"])
+def test_layout_variants(kw, f32):
+    """The observation layouts of the reference's env copies (snac_env_desc.frame_value / obs_scalars / obs_tail) on the time-parallel
+    kernel: the steppers file the record's values with every compact row, the writer waves assemble rows of any length (the plan
+    tail from a per-writer copy of each env's plan row, refilled when a tick's row differs -- time limit 4: every env starts over, on
+    a new plan row, sixteen times per chunk).  Against the oracle configured the same way (launches of 1, 5, 70 and 130 ticks, explicit
+    inputs), against the tile kernel's rows for a twin of the batch (an output that is not 16-byte aligned forces it) over a whole
+    episode at the reference's own time limit, and the tile-major output."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    dyn = kw.get("layout") != "lnet2d"
+    n = 1000
+    table = helpers.plan_table(2, dyn, "dense_train" if dyn else "p0")
+    dt = torch.float32 if f32 else torch.float64
+    cast = (lambda x: x.astype(np.float32)) if f32 else (lambda x: x)
+    for total_step in (4, None):
+        env = BatchedDMPEnv(2, dyn, n, plans=table.reshape(len(table), 26, 26), seed=4, total_step=total_step, obs_dtype=dt, **kw)
+        orc = helpers.oracle().OracleBatch(2, dyn, n, table, seed=4)
+        norm = {None: dyn, "raw": False, "norm": True}[env.obs_scalars]
+        orc.configure(obs_norm=norm, frame=env.frame_value, tail=env.obs_tail)
+        if total_step:
+            orc.set_total_step(total_step)
+        assert env.reset().cpu().numpy().tobytes() == cast(orc.reset()).tobytes()
+        t0 = 0
+        for T in (1, 5, 70, 130):
+            og, rg, dg = env.rollout(T)
+            assert _kernel() == "k_rollout2dt"
+            oc, rc, dc = orc.rollout(T, t0=t0, nthreads=16)
+            assert og.cpu().numpy().tobytes() == cast(oc).tobytes(), ("observations", total_step, T)
+            assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+            t0 += T
+        rng = np.random.default_rng(1)
+        acts, ks = rng.integers(0, 5, size=(70, n)).astype(np.int8), rng.integers(1, 4, size=(70, n)).astype(np.int8)
+        og, rg, dg = env.rollout(70, actions=torch.from_numpy(acts).to(env.device), step_size=torch.from_numpy(ks).to(env.device))
+        assert _kernel() == "k_rollout2dt"
+        oc, rc, dc = orc.rollout(70, t0=t0, actions=acts, step_size=ks, nthreads=16)
+        assert og.cpu().numpy().tobytes() == cast(oc).tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes()
+        del og, oc
+        _end_state(env, orc)
+    # a whole episode against the tile kernel, on the device
+    twin = env.fork(torch.arange(n, device=env.device))
+    T = 600
+    o1, r1, d1 = env.rollout(T)
+    assert _kernel() == "k_rollout2dt"
+    raw = torch.empty(T * n * env.obs_dim + 1, dtype=dt, device=env.device)
+    o2, r2, d2 = twin.rollout(T, out=raw[1:].view(T, n, env.obs_dim))
+    assert _kernel() == "k_rollout" and o2.data_ptr() % 16 != 0
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    assert torch.equal(env._hdr, twin._hdr) and torch.equal(env._grid, twin._grid)     # (a fork starts its episodic sums at zero)
+    # tile-major output of the same layout
+    tw2 = env.fork(torch.arange(n, device=env.device))
+    ot, _, _ = env.rollout(70, obs="tiled")
+    assert _kernel() == "k_rollout2dt"
+    on, _, _ = tw2.rollout(70)
+    assert torch.equal(env.untile(ot), on)
+
+
+@pytest.mark.parametrize("n,kw,kern", [(8192, dict(obs_tail=("record",)), "k_rollout2dt"), (8196, dict(obs_tail=("record",)), "k_rollout"),
+                                       (49152, dict(layout="ppo"), "k_rollout2dt"), (49156, dict(layout="ppo"), "k_rollout2d"),
+                                       (1002, dict(layout="ppo"), "k_rollout")], ids=str)
+def test_layout_variants_at_the_borders(n, kw, kern):
+    """Short rows up to 8192 envs, rows with the plan tail up to 49 152, whole groups of four envs only: 20 ticks on either side
+    against the oracle."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(2, True, "dense_train")
+    env = BatchedDMPEnv(2, True, n, plans=table.reshape(len(table), 26, 26), seed=6, total_step=7, obs_dtype=torch.float32, **kw)
+    orc = helpers.oracle().OracleBatch(2, True, n, table, seed=6)
+    norm = {None: True, "raw": False, "norm": True}[env.obs_scalars]
+    orc.configure(obs_norm=norm, frame=env.frame_value, tail=env.obs_tail)
+    orc.set_total_step(7)
+    assert env.reset().cpu().numpy().tobytes() == orc.reset().astype(np.float32).tobytes()
+    og, rg, dg = env.rollout(20)
+    assert _kernel() == kern
+    oc, rc, dc = orc.rollout(20, t0=0, nthreads=16)
+    assert og.cpu().numpy().tobytes() == oc.astype(np.float32).tobytes()
+    assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+    _end_state(env, orc)
