@@ -725,6 +725,11 @@ def main():
         # of the script/PPO env copies (451 values per row: window, counters, the 400 plan cells)
         rollout_cfg("headline_2000_generated_plans", 2, True, 65536, False, 24, plans=2000)
         rollout_cfg("headline_ppo_layout_451_values", 2, True, 65536, False, 6, layout="ppo", TT=60)
+        # the batch sizes the on-policy scripts use: the same 451-value rows and the canonical ones on the time-parallel kernel
+        rollout_cfg("ppo_layout_n4096_T600", 2, True, 4096, False, 10, layout="ppo")
+        rollout_cfg("ppo_layout_n1024_T600", 2, True, 1024, False, 20, layout="ppo")
+        rollout_cfg("small_batch_n4096_T600", 2, True, 4096, False, 30)
+        rollout_cfg("small_batch_n1024_T600", 2, True, 1024, False, 30)
         for kind in (2, 3):
             for nn in (65536, 524288):
                 step_cfg("step_%dd_dynamic_n%d" % (kind, nn), kind, nn, 200)

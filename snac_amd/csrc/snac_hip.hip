@@ -2386,8 +2386,11 @@ __global__ __launch_bounds__((EB + WR) * 64) void k_rollout2dt(const KArgs a) {
                     const size_t rw0 = (size_t)t0v * (size_t)a.n + (size_t)env0;
                     for (int tk = draw(); tk < nl; tk = draw()) {
                         const uint32_t* const rec = stage + tk * TSTR;
+                        int ll = lq;
+                        asm volatile("" : "+v"(ll));                 // the lane's constants of the row assembly are worked out per tick: kept
+                                                                     // across the loop they are live in the steppers' code too (128 registers)
                         if (a.tail & SNAC_TAIL_PLAN) {
-                            const int pq = (int)rec[min(lq, EB - 1) * RECW + 15];                  // lane e: env e's plan row at this tick
+                            const int pq = (int)rec[min(ll, EB - 1) * RECW + 15];                  // lane e: env e's plan row at this tick
 #pragma unroll
                             for (int e = 0; e < EB; ++e) {
                                 const int pe = __builtin_amdgcn_readlane(pq, e);                   // wave-uniform: the row comes through the scalar cache
@@ -2404,7 +2407,7 @@ __global__ __launch_bounds__((EB + WR) * 64) void k_rollout2dt(const KArgs a) {
                                 }
                             }
                         }
-                        emit_rows_lean<OT, VSTG>(stg, rec, wP, ob + (size_t)tk * ostr, lq, nenv, a.ld, a.tail, a.frame_val);
+                        emit_rows_lean<OT, VSTG>(stg, rec, wP, ob + (size_t)tk * ostr, ll, nenv, a.ld, a.tail, a.frame_val);
                         if (lq < nenv) {                             // four envs per tick: small stores beside rows of kilobytes
                             if (a.reward) a.reward[rw0 + (size_t)tk * (size_t)a.n + lq] = sR[tk][lq];
                             if (a.done) a.done[rw0 + (size_t)tk * (size_t)a.n + lq] = sD[tk][lq];
@@ -3902,10 +3905,10 @@ bool roll2dt_ok(const KArgs& a, bool f32) {
     if (a.variant) {
         // the layout variants (rows of a.ld values: k_rollout2dt<.., VAR>): whole groups of four envs and 16-byte pieces only.  Where
         // the lane-per-env kernels take over again was measured with the 451-value rows of the PPO copies (profiles/r04_2d_layouts.txt)
-        // (profiles/r04_2d_layouts.txt, part 3): 6.0 TB/s from 1024 envs on against k_rollout2d's 5.45 at 49 152 envs and 7.2 at 65 536;
-        // short rows (no plan tail: 53 .. 61 values) level off at 5.4e9 env-steps/s and hand over near 8192 envs
+        // (profiles/r04_2d_layouts.txt, part 3): 6.0-6.4 TB/s from 1024 envs on against k_rollout2d's 5.45 at 49 152 envs and 7.2 at 65 536;
+        // short rows (no plan tail: 53 .. 61 values) level off at 5.8e9 env-steps/s and hand over near 6144 envs
         static const int vmax = [] { const char* e = std::getenv("SNAC_2D_TP_VAR_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
-        const int lim = vmax ? vmax : ((a.tail & SNAC_TAIL_PLAN) ? 49152 : 8192);
+        const int lim = vmax ? vmax : ((a.tail & SNAC_TAIL_PLAN) ? 49152 : 6144);
         return (a.n & 3) == 0 && (((uintptr_t)a.obs) & 15) == 0 && a.n <= lim;
     }
     if (nmax) return a.n <= nmax;
@@ -3921,18 +3924,14 @@ void launch_roll2dt_e(const KArgs& a, hipStream_t s) {
     if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout2dt<DYN, OT, EB, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_rollout2dt<DYN, OT, EB, false>), grid, block, 0, s, a);
 }
-template <bool DYN, typename OT, int WR>
-void launch_roll2dt_var_w(const KArgs& a, hipStream_t s) {
-    constexpr int EB = 4;
+template <bool DYN, typename OT>
+void launch_roll2dt_var(const KArgs& a, hipStream_t s) {
+    // 4 steppers and 12 writers per block: the rows are what takes the time (with 4 writers in blocks of 8 waves: 5.7 instead of 6.0 TB/s
+    // at 1024 envs and half the rate at 256)
+    constexpr int EB = 4, WR = 12;
     const dim3 grid((unsigned)((a.n + EB - 1) / EB)), block((EB + WR) * 64);
     if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout2dt<DYN, OT, EB, true, true, WR>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_rollout2dt<DYN, OT, EB, false, true, WR>), grid, block, 0, s, a);
-}
-template <bool DYN, typename OT>
-void launch_roll2dt_var(const KArgs& a, hipStream_t s) {
-    static const int wr = [] { const char* e = std::getenv("SNAC_2D_TP_VAR_WR"); return e ? std::atoi(e) : 12; }();   // (tuning)
-    if (wr == 4) launch_roll2dt_var_w<DYN, OT, 4>(a, s);
-    else launch_roll2dt_var_w<DYN, OT, 12>(a, s);
 }
 template <bool DYN, typename OT>
 void launch_roll2dt_w(const KArgs& a, hipStream_t s) {

@@ -305,11 +305,11 @@ def test_layout_variants(kw, f32):
     assert torch.equal(env.untile(ot), on)
 
 
-@pytest.mark.parametrize("n,kw,kern", [(8192, dict(obs_tail=("record",)), "k_rollout2dt"), (8196, dict(obs_tail=("record",)), "k_rollout"),
+@pytest.mark.parametrize("n,kw,kern", [(6144, dict(obs_tail=("record",)), "k_rollout2dt"), (6148, dict(obs_tail=("record",)), "k_rollout"),
                                        (49152, dict(layout="ppo"), "k_rollout2dt"), (49156, dict(layout="ppo"), "k_rollout2d"),
                                        (1002, dict(layout="ppo"), "k_rollout")], ids=str)
 def test_layout_variants_at_the_borders(n, kw, kern):
-    """Short rows up to 8192 envs, rows with the plan tail up to 49 152, whole groups of four envs only: 20 ticks on either side
+    """Short rows up to 6144 envs, rows with the plan tail up to 49 152, whole groups of four envs only: 20 ticks on either side
     against the oracle."""
     import torch
     from snac_amd import BatchedDMPEnv
