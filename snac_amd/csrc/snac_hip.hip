@@ -478,7 +478,10 @@ __device__ __forceinline__ int record_value(int j, int reward, int done, int r, 
     return j == 0 ? reward : j == 1 ? done : j == 2 ? r : j == 3 ? c : j == 4 ? cb : j == 5 ? cs : j == 6 ? tb : pidx;
 }
 
-template <class K, typename OT, bool FULL, bool VAR>
+// LP: every env's whole plan row is in the wave's LDS (k_rollout loads and keeps it; the single-step kernels place one cell): the plan
+// tail then comes from there.  From the table in memory it is a vector load in the middle of the row stores, and vmcnt retires in
+// order -- every batch of 64 plan cells waited for the stores before it (451-value rows: 9 us per tick and wave).
+template <class K, typename OT, bool FULL, bool VAR, bool LP = false>
 __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int k0, int k1, int lane, const KArgs& a,
                                           const Lane& s, const StepOut& so) {
     const int LD = VAR ? a.ld : K::D;
@@ -530,7 +533,12 @@ __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int
                         q += 2;
                     }
                     if (a.tail & SNAC_TAIL_PLAN) {
-                        for (int cell = lane; cell < K::PLAN_CELLS; cell += 64) q[cell] = (OT)(double)K::plan_value(a, pidx, cell);
+                        for (int cell = lane; cell < K::PLAN_CELLS; cell += 64) {
+                            int pv;
+                            if constexpr (LP && K::A != 8) { const int pr = cell / 20; pv = (int)((lds[K::P_OFF + pr * K::RS + e] >> (cell - 20 * pr)) & 1u); }
+                            else pv = K::plan_value(a, pidx, cell);
+                            q[cell] = (OT)(double)pv;
+                        }
                         q += K::PLAN_CELLS;
                     }
                     if (a.tail & SNAC_TAIL_RECORD) {
@@ -561,7 +569,13 @@ __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int
                     if (el >= K::D) {
                         int ti = el - K::D, out = 0;
                         if (a.tail & SNAC_TAIL_POSITION) { if (ti == 0) out = pos; ti -= 1; }
-                        if (a.tail & SNAC_TAIL_PLAN) { if (ti >= 0 && ti < K::PLAN_CELLS) out = K::plan_value(a, pidx, ti); ti -= K::PLAN_CELLS; }
+                        if (a.tail & SNAC_TAIL_PLAN) {
+                            if (ti >= 0 && ti < K::PLAN_CELLS) {
+                                if constexpr (LP) out = (int)K::plan(lds)[e * K::ES + ti];
+                                else out = K::plan_value(a, pidx, ti);
+                            }
+                            ti -= K::PLAN_CELLS;
+                        }
                         if ((a.tail & SNAC_TAIL_RECORD) && ti >= 0) out = record_value(ti, rw, dn, pos, 0, cb, cs, tb, pidx);
                         val = (double)out;
                     }
@@ -601,11 +615,11 @@ __device__ __forceinline__ uint32_t* wave_lds() {
     return lds + (threadIdx.x >> 6) * K::LDS_WORDS;
 }
 
-template <class K, typename OT, bool VAR>
+template <class K, typename OT, bool VAR, bool LP = false>
 __device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, const Lane& s, const KArgs& a, int lane, const StepOut& so) {
     write_scalars<K, OT, VAR>(lds, s, a.total_step, lane, a);
-    if (nenv == K::E) write_obs<K, OT, true, VAR>(lds, orow, nenv, K::key0(s), K::key1(s), lane, a, s, so);
-    else write_obs<K, OT, false, VAR>(lds, orow, nenv, K::key0(s), K::key1(s), lane, a, s, so);
+    if (nenv == K::E) write_obs<K, OT, true, VAR, LP>(lds, orow, nenv, K::key0(s), K::key1(s), lane, a, s, so);
+    else write_obs<K, OT, false, VAR, LP>(lds, orow, nenv, K::key0(s), K::key1(s), lane, a, s, so);
 }
 
 // T fused vector steps (T = 1: one step() call) for one tile of E envs per wave.
@@ -684,7 +698,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
             // SNAC_OBS_TILED: [ceil(N / 64)][T][64][LD] -- the tile's rows of step t follow its rows of step t - 1
             const size_t orow = a.obs_mode == SNAC_OBS_ALL ? row
                               : (a.obs_mode == SNAC_OBS_TILED ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)(a.tiled_t0 + t)) * 64 + (size_t)(env0 & 63) : (size_t)env0);
-            emit_obs<K, OT, VAR>(lds, obs + orow * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
+            emit_obs<K, OT, VAR, true>(lds, obs + orow * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
         }
     }
     K::store_grid(lds, a, env0, nenv, lane);
