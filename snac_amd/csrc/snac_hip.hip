@@ -483,7 +483,7 @@ __device__ __forceinline__ int record_value(int j, int reward, int done, int r, 
 // order -- every batch of 64 plan cells waited for the stores before it (451-value rows: 9 us per tick and wave).
 template <class K, typename OT, bool FULL, bool VAR, bool LP = false>
 __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int k0, int k1, int lane, const KArgs& a,
-                                          const Lane& s, const StepOut& so) {
+                                          const Lane& s, const StepOut& so, const int16_t* plan3 = nullptr) {
     const int LD = VAR ? a.ld : K::D;
     if constexpr (K::D == 51) {
         constexpr int U = 8;                                         // envs per batch (K::E is a multiple of U)
@@ -536,6 +536,7 @@ __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int
                         for (int cell = lane; cell < K::PLAN_CELLS; cell += 64) {
                             int pv;
                             if constexpr (LP && K::A != 8) { const int pr = cell / 20; pv = (int)((lds[K::P_OFF + pr * K::RS + e] >> (cell - 20 * pr)) & 1u); }
+                            else if constexpr (LP) pv = (int)plan3[e * K::PLAN_CELLS + cell];   // 3D: k_rollout's own copy of the rows (the kind keeps no plan in LDS)
                             else pv = K::plan_value(a, pidx, cell);
                             q[cell] = (OT)(double)pv;
                         }
@@ -616,10 +617,11 @@ __device__ __forceinline__ uint32_t* wave_lds() {
 }
 
 template <class K, typename OT, bool VAR, bool LP = false>
-__device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, const Lane& s, const KArgs& a, int lane, const StepOut& so) {
+__device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, const Lane& s, const KArgs& a, int lane, const StepOut& so,
+                                         const int16_t* plan3 = nullptr) {
     write_scalars<K, OT, VAR>(lds, s, a.total_step, lane, a);
-    if (nenv == K::E) write_obs<K, OT, true, VAR, LP>(lds, orow, nenv, K::key0(s), K::key1(s), lane, a, s, so);
-    else write_obs<K, OT, false, VAR, LP>(lds, orow, nenv, K::key0(s), K::key1(s), lane, a, s, so);
+    if (nenv == K::E) write_obs<K, OT, true, VAR, LP>(lds, orow, nenv, K::key0(s), K::key1(s), lane, a, s, so, plan3);
+    else write_obs<K, OT, false, VAR, LP>(lds, orow, nenv, K::key0(s), K::key1(s), lane, a, s, so, plan3);
 }
 
 // T fused vector steps (T = 1: one step() call) for one tile of E envs per wave.
@@ -638,6 +640,20 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
     const bool active = lane < nenv;
     const int env = env0 + (active ? lane : 0);
     uint32_t* lds = wave_lds<K, WPB>();
+    // 3D keeps no plan in LDS (a step needs one cell); the layout variants' plan tail needs all 400 every tick: its rows get a copy of
+    // their own here, refilled when an env starts over on another row
+    constexpr bool P3 = VAR && K::A == 8;
+    __shared__ int16_t plan3_all[P3 ? WPB * E * 400 : 1];
+    int16_t* const plan3 = plan3_all + (P3 ? (int)(threadIdx.x >> 6) * E * 400 : 0);
+    auto load_plan3 = [&](int e, int pidx) {
+        if constexpr (P3) {
+            if (a.tail & SNAC_TAIL_PLAN) {
+                const uint32_t* const src = (const uint32_t*)((const int16_t*)a.plans + (size_t)pidx * 400);
+                uint32_t* const dst = (uint32_t*)(plan3 + e * 400);
+                for (int i = lane; i < 200; i += 64) dst[i] = src[i];
+            }
+        }
+    };
     Lane s;
     s.clear();
     s.r = 3; s.c = 3;                                                // idle lanes keep an in-range position
@@ -645,7 +661,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
     if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
     asm volatile("" : "+v"(episode));                                // waited for HERE, not in the loop's reset branch behind the row stores
     K::load_grid(lds, a, env0, nenv, lane);
-    for (int e = 0; e < nenv; ++e) K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane);
+    for (int e = 0; e < nenv; ++e) { K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane); load_plan3(e, __builtin_amdgcn_readlane(s.pidx, e)); }
     const uint64_t gid = (uint64_t)(a.env_id_base + env);
     const EnvKeys sk = env_keys(a.key_step, gid), pk = env_keys(a.key_plan, gid);
     int d_eps = 0, d_ret = 0;
@@ -670,7 +686,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
                 K::clear(lds, e, lane);
                 // a vector load here waits for every observation store issued before it (vmcnt is in-order): skip it
                 // when the env keeps its plan
-                if (pe != __builtin_amdgcn_readlane(old_pidx, e)) K::load_plan(lds, a, e, pe, lane);
+                if (pe != __builtin_amdgcn_readlane(old_pidx, e)) { K::load_plan(lds, a, e, pe, lane); load_plan3(e, pe); }
             }
         }
         if (active) {
@@ -698,7 +714,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout(const KArgs a) {
             // SNAC_OBS_TILED: [ceil(N / 64)][T][64][LD] -- the tile's rows of step t follow its rows of step t - 1
             const size_t orow = a.obs_mode == SNAC_OBS_ALL ? row
                               : (a.obs_mode == SNAC_OBS_TILED ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)(a.tiled_t0 + t)) * 64 + (size_t)(env0 & 63) : (size_t)env0);
-            emit_obs<K, OT, VAR, true>(lds, obs + orow * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
+            emit_obs<K, OT, VAR, true>(lds, obs + orow * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0}, plan3);
         }
     }
     K::store_grid(lds, a, env0, nenv, lane);
