@@ -1840,12 +1840,18 @@ __device__ __forceinline__ uint32_t bfi32(uint32_t m, uint32_t a, uint32_t b) {
 template <int CTRL, int ROWS = 0xf>
 __device__ __forceinline__ int dpp_from(int idv, int v) { return __builtin_amdgcn_update_dpp(idv, v, CTRL, ROWS, 0xf, false); }
 
-template <bool DYN, typename OT, int EB, bool EXPL>
-__global__ __launch_bounds__(EB * 64, 16 / EB) void k_rollout1dt(const KArgs a) {                // 16 waves per CU either way: <= 128 VGPRs
+// VAR: the layout variants of snac_env_desc (frame value, raw / normalised counters, position / plan / record tails: rows of a.ld <= 46
+// values) -- a lane files its whole row, tails included (the plan tail from the segment's plan in LDS), the staging tile is sized
+// for the longest row (blocks of 4 envs only: 95 KB with float64 rows), the runs leave in as many 16-byte pieces as they have.
+// N % 4 = 0 and a 16-byte aligned output.
+template <bool DYN, typename OT, int EB, bool EXPL, bool VAR = false>
+__global__ __launch_bounds__(EB * 64, VAR ? 1 : 16 / EB) void k_rollout1dt(const KArgs a) {      // 16 waves per CU either way: <= 128 VGPRs (VAR: one block)
     using K = K1D<DYN, 8>;
     constexpr int D = K::D;
     constexpr int ROWB = D * (int)sizeof(OT);                        // 56 / 28 bytes per row
-    constexpr int TSTR = EB * ROWB + 16;                             // staging bytes per tick (+16: the lanes' row writes spread over the banks)
+    constexpr int LDMAX = VAR ? D + 1 + 30 + 8 : D;                  // the longest row of a layout variant: 46 values
+    constexpr int TSTR = EB * LDMAX * (int)sizeof(OT) + 16;          // staging bytes per tick (+16: the lanes' row writes spread over the banks)
+    static_assert(!VAR || EB == 4, "layout variants: blocks of four envs");
     __shared__ int sH[EB][32], sP[EB][32];
     __shared__ unsigned long long sM[EB][32];
     __shared__ __align__(16) char stage[64 * TSTR];                  // [tick][env of the block][D]: what 64 ticks of the block's envs write
@@ -1882,8 +1888,10 @@ __global__ __launch_bounds__(EB * 64, 16 / EB) void k_rollout1dt(const KArgs a) 
     const bool tl = a.obs_mode == SNAC_OBS_TILED;
     const double dT = (double)a.total_step, rT = 1.0 / dT;
     // the block's rows of one tick are one run of nenv x ROWB bytes; 16-byte pieces when every run starts and ends on 16 bytes
-    const size_t ostr = (tl ? (size_t)64 : (size_t)a.n) * ROWB;      // bytes from one tick's run to the next
-    const bool vec = ((((uintptr_t)a.obs) | (uintptr_t)ostr | (uintptr_t)((size_t)nenv * ROWB)) & 15) == 0;
+    const int RB = VAR ? a.ld * (int)sizeof(OT) : ROWB;              // bytes per row
+    const int tstr = VAR ? EB * RB + 16 : TSTR;                      // bytes per tick of the staging tile
+    const size_t ostr = (tl ? (size_t)64 : (size_t)a.n) * RB;        // bytes from one tick's run to the next
+    const bool vec = ((((uintptr_t)a.obs) | (uintptr_t)ostr | (uintptr_t)((size_t)nenv * RB)) & 15) == 0;
     const bool dvec = EB == 16 && a.done && nenv == EB && ((((uintptr_t)a.done) | (uintptr_t)a.n) & 15) == 0;
     for (int t0 = 0; t0 < a.T; t0 += 64) {
         const int nl = min(64, a.T - t0);
@@ -1964,15 +1972,29 @@ __global__ __launch_bounds__(EB * 64, 16 / EB) void k_rollout1dt(const KArgs a) 
             if (in) {
                 const double c0 = (double)cb, c1 = (double)cs;
                 double v0 = c0, v1 = c1;
-                if (DYN) {                                           // cb / tb, cs / T: correctly rounded (Roll3D, tests/native/recip_check.c)
+                if (VAR ? (a.sc_norm != 0) : DYN) {                  // cb / tb, cs / T: correctly rounded (Roll3D, tests/native/recip_check.c)
                     const double q0 = c0 * rtb, q1 = c1 * rT;
                     v0 = tb > 0 ? __builtin_fma(__builtin_fma(-q0, dtb, c0), rtb, q0) : c0 / dtb;
                     v1 = __builtin_fma(__builtin_fma(-q1, dT, c1), rT, q1);
                 }
-                OT* const o = (OT*)(stage + lane * TSTR + wv * ROWB);
+                OT* const o = (OT*)(stage + lane * tstr + wv * RB);
 #pragma unroll
-                for (int i = 0; i < K::W; ++i) o[i] = (OT)(double)win[i];
+                for (int i = 0; i < K::W; ++i) o[i] = (OT)(double)((VAR && win[i] < 0) ? a.frame_val : win[i]);
                 o[K::W] = (OT)v0; o[K::W + 1] = (OT)v1;
+                if constexpr (VAR) {                                 // the tails, in the descriptor's order
+                    OT* q = o + D;
+                    if (a.tail & SNAC_TAIL_POSITION) { q[0] = (OT)(double)pos; q += 1; }
+                    if (a.tail & SNAC_TAIL_PLAN) {
+#pragma unroll
+                        for (int c = 0; c < 30; ++c) q[c] = (OT)(double)P[c];
+                        q += 30;
+                    }
+                    if (a.tail & SNAC_TAIL_RECORD) {
+                        const int rv[8] = {reward, (lane == last && donem) ? 1 : 0, pos, 0, cb, cs, tb, pidx};   // record_value
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) q[j] = (OT)(double)rv[j];
+                    }
+                }
                 sR[lane][wv] = (float)reward;
                 sD[lane][wv] = (lane == last && donem) ? 1 : 0;
                 if (a.actions_out) a.actions_out[row] = (int8_t)act;
@@ -2006,9 +2028,16 @@ __global__ __launch_bounds__(EB * 64, 16 / EB) void k_rollout1dt(const KArgs a) 
                                                                      // and offsets kept across the loop cost more registers than there are
             const size_t row0 = tl ? ((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)(a.tiled_t0 + t0v)) * 64 + (size_t)(env0 & 63)
                                    : (size_t)t0v * (size_t)a.n + (size_t)env0;
-            char* const ob = (char*)a.obs + row0 * ROWB;
+            char* const ob = (char*)a.obs + row0 * RB;
             constexpr int TPW = 64 / EB;                             // ticks per wave
-            if (vec) {
+            if constexpr (VAR) {
+                const int pt = nenv * RB / 16;                       // 16-byte pieces of a tick's run (the dispatch sees to whole pieces)
+                for (int i = 0; i < TPW; ++i) {
+                    const int tk = wq * TPW + i;
+                    if (tk < nl)
+                        for (int pc = lq; pc < pt; pc += 64) *(uint4*)(ob + (size_t)tk * ostr + pc * 16) = *(const uint4*)(stage + tk * tstr + pc * 16);
+                }
+            } else if (vec) {
                 // 16-byte pieces: a tick's run has pt <= LPT of them, LPT lanes per tick, 64 / LPT ticks per store instruction
                 constexpr int PTMAX = EB * ROWB / 16, LPT = PTMAX > 32 ? 64 : (PTMAX > 16 ? 32 : (PTMAX > 8 ? 16 : 8)), TPI = 64 / LPT;
                 const int pt = nenv * ROWB / 16, pc = lq & (LPT - 1);
@@ -3984,7 +4013,16 @@ bool roll1dt_ok(const KArgs& a, bool f32) {
     static const bool off = [] { const char* e = std::getenv("SNAC_1D_TP"); return e && e[0] == '0'; }();
     static const int nmax = [] { const char* e = std::getenv("SNAC_1D_TP_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
     const int lim = nmax ? nmax : (f32 ? 65536 : 49152);
-    return !off && a.n <= lim && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && !pipeline_off();
+    if (off || !(a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) || pipeline_off()) return false;
+    if (a.variant) {
+        // the layout variants (k_rollout1dt<.., VAR>: blocks of four envs, one per CU): whole groups of four envs and 16-byte pieces;
+        // it levels off at 1.2e10 env-steps/s with the 37-value PPO rows (the tile kernel: 8.6e9 at 65 536 envs) and at 2.1e10 with the
+        // 8-value L-Net rows (the tile kernel passes that near 24 576 envs) (profiles/r04_1d_layouts.txt)
+        static const int vmax = [] { const char* e = std::getenv("SNAC_1D_TP_VAR_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
+        const int vlim = vmax ? vmax : ((a.tail & SNAC_TAIL_PLAN) ? 65536 : 24576);
+        return (a.n & 3) == 0 && (((uintptr_t)a.obs) & 15) == 0 && a.n <= vlim;
+    }
+    return a.n <= lim;
 }
 template <bool DYN, typename OT, int EB>
 void launch_roll1dt_e(const KArgs& a, hipStream_t s) {
@@ -3994,6 +4032,12 @@ void launch_roll1dt_e(const KArgs& a, hipStream_t s) {
 }
 template <bool DYN, typename OT>
 void launch_roll1dt_w(const KArgs& a, hipStream_t s) {
+    if (a.variant) {
+        const dim3 grid((unsigned)((a.n + 3) / 4)), block(256);
+        if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, false, true>), grid, block, 0, s, a);
+        return;
+    }
     static const int emin = [] { const char* e = std::getenv("SNAC_1D_TP_EB16"); return e ? std::atoi(e) : 3584; }();   // (tuning)
     if (a.n >= emin) launch_roll1dt_e<DYN, OT, 16>(a, s);      // 16 envs per block: runs of 896 / 448 bytes per tick (3072 envs: 0.048 against 0.041 ms; 3584: level)
     else launch_roll1dt_e<DYN, OT, 4>(a, s);                        // small batches: more blocks than CUs first

@@ -206,3 +206,78 @@ def test_replay_rings_filled_by_the_time_parallel_kernel():
     ga.manual_seed(3); gb.manual_seed(3)
     sa, sb = a.sample(300, generator=ga), b.sample(300, generator=gb)
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
+
+
+VARIANTS_1D = [
+    (False, dict(layout="lnet1d")),                                                     # 8 values: the position appended
+    (True, dict(layout="ppo")),                                                         # 37: window, counters, the 30 plan heights
+    (True, dict(obs_tail=("record",), obs_scalars="raw")),                              # 15
+    (False, dict(obs_tail=("position", "plan", "record"), frame_value=2, obs_scalars="norm")),   # 46
+]
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn,kw", VARIANTS_1D, ids=["lnet1d", "ppo", "record", "all"])
+def test_layout_variants_on_the_time_parallel_kernel(dyn, kw, f32):
+    """The observation layouts of the reference's 1D env copies (snac_env_desc.frame_value / obs_scalars / obs_tail) on k_rollout1dt:
+    a lane files its whole row, tails included.  Against the oracle configured the same way -- time limit 6 (every env starts over,
+    on a new plan row, ten times per chunk) and the kind's own; launches of 1, 5, 70 and 130 ticks, explicit inputs --, against the
+    tile kernel (an unaligned output; a batch that is not whole groups of four envs), and the tile-major output."""
+    import torch
+    from snac_amd import BatchedDMPEnv, _lib
+
+    def kernel():
+        return _lib.lib().snac_last_kernel().decode()
+
+    n = 1000
+    table, full = _tables(dyn)
+    dt = torch.float32 if f32 else torch.float64
+    cast = (lambda x: x.astype(np.float32)) if f32 else (lambda x: x)
+    for total_step in (6, None):
+        env = BatchedDMPEnv(1, dyn, n, plans=full, seed=4, total_step=total_step, obs_dtype=dt, **kw)
+        orc = helpers.oracle().OracleBatch(1, dyn, n, table, seed=4)
+        norm = {None: dyn, "raw": False, "norm": True}[env.obs_scalars]
+        orc.configure(obs_norm=norm, frame=env.frame_value, tail=env.obs_tail)
+        if total_step:
+            orc.set_total_step(total_step)
+        assert env.reset().cpu().numpy().tobytes() == cast(orc.reset()).tobytes()
+        t0 = 0
+        for T in (1, 5, 70, 130):
+            og, rg, dg = env.rollout(T)
+            assert kernel() == "k_rollout1dt"
+            oc, rc, dc = orc.rollout(T, t0=t0, nthreads=16)
+            assert og.cpu().numpy().tobytes() == cast(oc).tobytes(), ("observations", total_step, T)
+            assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+            t0 += T
+        rng = np.random.default_rng(1)
+        acts, ks = rng.integers(0, 3, size=(70, n)).astype(np.int8), rng.integers(1, 4, size=(70, n)).astype(np.int8)
+        og, rg, dg = env.rollout(70, actions=torch.from_numpy(acts).to(env.device), step_size=torch.from_numpy(ks).to(env.device))
+        assert kernel() == "k_rollout1dt"
+        oc, rc, dc = orc.rollout(70, t0=t0, actions=acts, step_size=ks, nthreads=16)
+        assert og.cpu().numpy().tobytes() == cast(oc).tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes()
+        del og, oc
+        _end_state(env, orc)
+    twin = env.fork(torch.arange(n, device=env.device))
+    T = 750
+    o1, r1, d1 = env.rollout(T)
+    assert kernel() == "k_rollout1dt"
+    raw = torch.empty(T * n * env.obs_dim + 4, dtype=dt, device=env.device)
+    o2, r2, d2 = twin.rollout(T, out=raw[1:1 + T * n * env.obs_dim].view(T, n, env.obs_dim))
+    assert kernel() == "k_rollout" and o2.data_ptr() % 16 != 0
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    assert torch.equal(env._hdr, twin._hdr) and torch.equal(env._grid, twin._grid)
+    tw2 = env.fork(torch.arange(n, device=env.device))
+    ot, _, _ = env.rollout(70, obs="tiled")
+    assert kernel() == "k_rollout1dt"
+    on, _, _ = tw2.rollout(70)
+    assert torch.equal(env.untile(ot), on)
+    # not whole groups of four envs: the tile kernel, the same oracle
+    big = BatchedDMPEnv(1, dyn, 4102, plans=full, seed=9, total_step=6, obs_dtype=dt, **kw)
+    orc = helpers.oracle().OracleBatch(1, dyn, 4102, table, seed=9)
+    orc.configure(obs_norm={None: dyn, "raw": False, "norm": True}[big.obs_scalars], frame=big.frame_value, tail=big.obs_tail)
+    orc.set_total_step(6)
+    assert big.reset().cpu().numpy().tobytes() == cast(orc.reset()).tobytes()
+    og, rg, dg = big.rollout(20)
+    assert kernel() == "k_rollout"
+    oc, rc, dc = orc.rollout(20, t0=0, nthreads=16)
+    assert og.cpu().numpy().tobytes() == cast(oc).tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes()
