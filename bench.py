@@ -729,6 +729,8 @@ def main():
         rollout_cfg("ppo_layout_n4096_T600", 2, True, 4096, False, 10, layout="ppo")
         rollout_cfg("ppo_layout_n1024_T600", 2, True, 1024, False, 20, layout="ppo")
         rollout_cfg("small_batch_n4096_T600", 2, True, 4096, False, 30)
+        rollout_cfg("ppo_layout_1d_n1024_T750", 1, True, 1024, False, 30, layout="ppo")
+        rollout_cfg("ppo_layout_3d_n16384_T200", 3, True, 16384, False, 6, layout="ppo", TT=200)
         rollout_cfg("small_batch_n1024_T600", 2, True, 1024, False, 30)
         for kind in (2, 3):
             for nn in (65536, 524288):
