@@ -1842,14 +1842,16 @@ __device__ __forceinline__ int dpp_from(int idv, int v) { return __builtin_amdgc
 
 // VAR: the layout variants of snac_env_desc (frame value, raw / normalised counters, position / plan / record tails: rows of a.ld <= 46
 // values) -- a lane files its whole row, tails included (the plan tail from the segment's plan in LDS), the staging tile is sized
-// for the longest row (blocks of 4 envs only: 95 KB with float64 rows), the runs leave in as many 16-byte pieces as they have.
+// for rows of up to VLD = 16 / 38 / 46 values (blocks of 4 envs: 34 / 79 / 95 KB with float64 rows), the runs leave in as many
+// 16-byte pieces as they have.
 // N % 4 = 0 and a 16-byte aligned output.
-template <bool DYN, typename OT, int EB, bool EXPL, bool VAR = false>
-__global__ __launch_bounds__(EB * 64, VAR ? 1 : 16 / EB) void k_rollout1dt(const KArgs a) {      // 16 waves per CU either way: <= 128 VGPRs (VAR: one block)
+template <bool DYN, typename OT, int EB, bool EXPL, int VLD = 0>
+__global__ __launch_bounds__(EB * 64, VLD ? 1 : 16 / EB) void k_rollout1dt(const KArgs a) {      // 16 waves per CU either way: <= 128 VGPRs (layout variants: what LDS allows)
     using K = K1D<DYN, 8>;
+    constexpr bool VAR = VLD != 0;                                   // VLD: the longest row the staging tile holds: 16 (L-Net, record), 38 (PPO), 46 values
     constexpr int D = K::D;
     constexpr int ROWB = D * (int)sizeof(OT);                        // 56 / 28 bytes per row
-    constexpr int LDMAX = VAR ? D + 1 + 30 + 8 : D;                  // the longest row of a layout variant: 46 values
+    constexpr int LDMAX = VAR ? VLD : D;
     constexpr int TSTR = EB * LDMAX * (int)sizeof(OT) + 16;          // staging bytes per tick (+16: the lanes' row writes spread over the banks)
     static_assert(!VAR || EB == 4, "layout variants: blocks of four envs");
     __shared__ int sH[EB][32], sP[EB][32];
@@ -4016,11 +4018,10 @@ bool roll1dt_ok(const KArgs& a, bool f32) {
     if (off || !(a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) || pipeline_off()) return false;
     if (a.variant) {
         // the layout variants (k_rollout1dt<.., VAR>: blocks of four envs, one per CU): whole groups of four envs and 16-byte pieces;
-        // it levels off at 1.2e10 env-steps/s with the 37-value PPO rows (the tile kernel: 8.6e9 at 65 536 envs) and at 2.1e10 with the
-        // 8-value L-Net rows (the tile kernel passes that near 24 576 envs) (profiles/r04_1d_layouts.txt)
-        static const int vmax = [] { const char* e = std::getenv("SNAC_1D_TP_VAR_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
-        const int vlim = vmax ? vmax : ((a.tail & SNAC_TAIL_PLAN) ? 65536 : 24576);
-        return (a.n & 3) == 0 && (((uintptr_t)a.obs) & 15) == 0 && a.n <= vlim;
+        // it levels off at 1.2e10 env-steps/s with the 37-value PPO rows (the tile kernel: 8.6e9 at 65 536 envs) and at 4.4-5.1e10 with the
+        // 8-value L-Net rows (the tile kernel: 3.1e10 at 65 536 envs) (profiles/r04_1d_layouts.txt)
+        static const int vmax = [] { const char* e = std::getenv("SNAC_1D_TP_VAR_MAX"); return e ? std::atoi(e) : 65536; }();   // (tuning)
+        return (a.n & 3) == 0 && (((uintptr_t)a.obs) & 15) == 0 && a.n <= vmax;
     }
     return a.n <= lim;
 }
@@ -4034,8 +4035,17 @@ template <bool DYN, typename OT>
 void launch_roll1dt_w(const KArgs& a, hipStream_t s) {
     if (a.variant) {
         const dim3 grid((unsigned)((a.n + 3) / 4)), block(256);
-        if (a.actions || a.step_size) hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, false, true>), grid, block, 0, s, a);
+        const bool expl = a.actions || a.step_size;
+        if (a.ld <= 16) {                                            // the smaller the staging tile, the more blocks share a CU
+            if (expl) hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, true, 16>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, false, 16>), grid, block, 0, s, a);
+        } else if (a.ld <= 38) {
+            if (expl) hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, true, 38>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, false, 38>), grid, block, 0, s, a);
+        } else {
+            if (expl) hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, true, 46>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_rollout1dt<DYN, OT, 4, false, 46>), grid, block, 0, s, a);
+        }
         return;
     }
     static const int emin = [] { const char* e = std::getenv("SNAC_1D_TP_EB16"); return e ? std::atoi(e) : 3584; }();   // (tuning)
