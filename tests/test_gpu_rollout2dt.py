@@ -327,3 +327,38 @@ def test_layout_variants_at_the_borders(n, kw, kern):
     assert og.cpu().numpy().tobytes() == oc.astype(np.float32).tobytes()
     assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
     _end_state(env, orc)
+
+
+@pytest.mark.parametrize("kind,kw", [(2, dict(layout="ppo")), (2, dict(obs_tail=("record",))), (1, dict(layout="ppo"))], ids=str)
+def test_replay_rings_of_layout_variants(kind, kw):
+    """Rings that collect rows of a layout variant through the time-parallel kernels (launches that write at an offset of a tile-major
+    ring and wrap): the tick ring and the tile-major ring hold the same rows and records; the last launch's rows equal the oracle's."""
+    import torch
+    from snac_amd import BatchedDMPEnv, ReplayRing
+
+    n = 1000
+    table = helpers.plan_table(kind, True, "sin_train" if kind == 1 else "dense_train")
+    full = table.reshape(len(table), 30) if kind == 1 else table.reshape(len(table), 26, 26)
+    envs = [BatchedDMPEnv(kind, True, n, plans=full, seed=12, total_step=40, **kw) for _ in range(2)]
+    orc = helpers.oracle().OracleBatch(kind, True, n, table, seed=12)
+    orc.configure(obs_norm={None: True, "raw": False, "norm": True}[envs[0].obs_scalars], frame=envs[0].frame_value, tail=envs[0].obs_tail)
+    orc.set_total_step(40)
+    orc.reset()
+    rings = []
+    for e, layout in zip(envs, ("ticks", "tiled")):
+        e.reset()
+        rings.append(ReplayRing(e, 100, layout=layout))
+    t0 = 0
+    for T in (70, 90, 100, 7):
+        for r in rings:
+            r.collect(T)
+            assert _kernel() == ("k_rollout1dt" if kind == 1 else "k_rollout2dt")
+        oc, rc, dc = orc.rollout(T, t0=t0, nthreads=16)
+        t0 += T
+    a, b = rings
+    for slot in range(100):
+        assert torch.equal(a.obs_at(slot), b.obs_at(slot)), slot
+    for name in ("reward", "done", "action", "step_size", "plan_idx", "first"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for i in range(7):
+        assert a.obs_at((a.head - 7 + i) % 100).cpu().numpy().tobytes() == oc[i].tobytes(), i
