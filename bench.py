@@ -705,6 +705,30 @@ def main():
                          "note": "deep_mobile_printing_2d1r(data_path).step(a) of snac_amd.envs, one env, host-timed; reference figure: BASELINE.md section 2 "
                                  "(measured in the build container, other CPU); the drop-in classes are the parity surface, BatchedDMPEnv the throughput surface"}
 
+        def vector_cfg(name, nn, steps=1500):
+            """VectorizedEnvWrapper.step(actions) (multiprocess.py:15-32 on the HIP path: numpy in, numpy out, one launch + one wait per
+            vector step), host-timed, with the reference's default --num_envs 3 and a batch a trainer would use.  The reference wrapper
+            steps its N envs one after the other at ~9 us each."""
+            import numpy as np
+
+            from snac_amd.vector import VectorizedEnvWrapper
+
+            table = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "snac_amd", "data", "plans.npz"))["2d_dense_train"]
+            w = VectorizedEnvWrapper((2, True, table), num_envs=nn)
+            np.random.seed(1)
+            w.reset()
+            acts = np.random.RandomState(0).randint(0, 5, (steps + 100, nn))
+            for i in range(100):
+                w.step(acts[i])
+            t0 = time.perf_counter()
+            for i in range(steps):
+                w.step(acts[100 + i])
+            dt_ = time.perf_counter() - t0
+            res[name] = {"vector_steps_per_s": steps / dt_, "env_steps_per_s": steps * nn / dt_, "us_per_vector_step": 1e6 * dt_ / steps, "num_envs": nn,
+                         "reference_env_steps_per_s_one_core": 110300.0,
+                         "note": "snac_amd.vector.VectorizedEnvWrapper.step(actions): host numpy in and out, no auto-reset (stepped past done like the "
+                                 "reference's loop); the reference's wrapper does its N env.step() calls in turn on one core"}
+
         def step_cfg(name, kind, nn, reps):
             e = BatchedDMPEnv(kind, True, nn, device=dev, seed=1)
             e.reset()
@@ -739,6 +763,8 @@ def main():
             edges_cfg("transition_%dd_524288_edges" % kind, kind, 524288, 20)
         gather_cfg("replay_gather_65536", 65536, 64, 65536, 20)
         facade_cfg("facade_2d_dynamic_one_env")
+        vector_cfg("vector_wrapper_3_envs", 3)
+        vector_cfg("vector_wrapper_256_envs", 256)
         return res
 
     extras = None

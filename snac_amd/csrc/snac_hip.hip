@@ -5,8 +5,11 @@
 //   k_rollout2d    the headline: 2D rollouts on tiles of 64 envs, lane = env in the transition AND in the observation rows, which are
 //                  transposed through an LDS staging tile and leave 16 bytes per lane (emit_tile; layout variants: emit_rows_var);
 //                  plan rows per wave in LDS, refilled through the scalar cache; no vector load in the loop (vmcnt retires in order);
-//   k_rollout2dt   2D rollouts of small batches, time-parallel: one wave per env, lane = tick, stepper and writer waves per block;
-//   k_rollout1dt   the same idea for 1D (counters by ballots, positions by DPP scans, heights by per-cell lane masks);
+//   k_rollout2dt   2D rollouts of small and middle batches, time-parallel: one wave per env, lane = tick; stepper and writer waves per
+//                  block, the ticks to expand a queue between them; <.., VAR>: the layout variants (PPO rows of 451 values ...), rows
+//                  assembled by twelve writer waves (emit_rows_lean);
+//   k_rollout1dt   the same idea for 1D (counters by ballots, positions by DPP scans, heights by per-cell lane masks); <.., VLD>: its
+//                  layout variants;
 //   k_rollout3db   3D rollouts: one stepper wave (lane = env) and eight writer waves per 64 envs, one barrier per tick;
 //   k_rollout3d    3D rollouts of small / odd batches: 8 envs per wave, software-pipelined round the store stream;
 //   k_step2d / 3d  snac_step on identity rows: wide loads, rows through emit_tile;  k_edges3d: 3D tree edges, records through LDS;

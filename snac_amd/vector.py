@@ -47,6 +47,8 @@ class VectorizedEnvWrapper:
         self._r, self._d = torch.empty(n, dtype=torch.float32, **pin), torch.empty(n, dtype=torch.uint8, **pin)
         self._o = self.batched.new_host_obs() if n <= self.HOST_OBS_MAX else self.batched._new_obs()
         self._a_np, self._k_np, self._r_np, self._d_np = self._a.numpy(), self._k.numpy(), self._r.numpy(), self._d.numpy()
+        self._out = (self._o, self._r, self._d)                  # ONE tuple object: step()'s fast path recognises the call before by identity
+        self._o_np = self._o.numpy() if self._o.device.type == "cpu" else None
         self.action_dim = self.batched.num_actions
         self.total_step = self.batched.total_step
 
@@ -81,10 +83,10 @@ class VectorizedEnvWrapper:
         self._k_np[:] = np.random.randint(1, 4, size=self.num_envs)
         self._a_np[:] = actions
         b = self.batched
-        b.step(self._a, self._k, out=(self._o, self._r, self._d))
+        b.step(self._a, self._k, out=self._out)
         if self._o.device.type == "cpu":                         # one launch, one wait
             b.sync()
-            obs = self._o.numpy().copy()
+            obs = self._o_np.copy()
         else:                                                    # the copy is ordered behind the kernel on the same stream
             obs = self._o.cpu().numpy()
             b.sync()
