@@ -131,6 +131,8 @@ class BatchedDMPEnv:
         self._dev_index = self.device.index
         self._desc_ref, self._state_ref = C.byref(self._desc), C.byref(self._state)
         self._snac_step = self._lib.snac_step
+        self._snac_step_scalar, self._snac_sync = self._lib.snac_step_scalar, self._lib.snac_stream_sync
+        self._ssf = None                                             # step_scalar_wait(): the host row validated by the call before
         self._host_ok = None                                         # the new_host_obs() row validated last
         self._mapped = {}                                            # page-locked host tensors seen by _is_mapped
 
@@ -289,6 +291,27 @@ class BatchedDMPEnv:
             with torch.cuda.device(self.device):
                 _lib.check(self._lib.snac_step_scalar(*args, self._stream()))
         self.t += 1
+        return obs
+
+    def step_scalar_wait(self, action, step_size, out):
+        """step_scalar(action, step_size, out=<a new_host_obs() row>) followed by sync(), as ONE call: what a single-env class does per
+        step.  A call with the same row object as the call before goes straight to the two library calls (no argument checks, no
+        descriptor / pointer objects built: 3 of the 18 us of such a step).  Returns `out`, readable."""
+        f = self._ssf
+        if f is not None and f[0] is out and out.data_ptr() == f[2] and _current_device() == self._dev_index:
+            st = _raw_stream(self._dev_index)
+            rc = self._snac_step_scalar(self._desc_ref, self._state_ref, self.t & 0xFFFFFFFF, action, step_size, 0, f[1], None, None, st)
+            if rc:
+                _lib.check(rc)
+            self.t += 1
+            rc = self._snac_sync(st)
+            if rc:
+                _lib.check(rc)
+            return out
+        obs = self.step_scalar(action, step_size, out=out)
+        self.sync()
+        if out is self._host_ok and _raw_stream is not None and isinstance(action, int) and isinstance(step_size, int):
+            self._ssf = (out, C.c_void_p(out.data_ptr()), out.data_ptr())
         return obs
 
     def reset_scalar(self, plan_idx, out=None):

@@ -67,9 +67,10 @@ class _Facade(_Base):
         self._nobs = self._env.obs_dim - 8                     # the observation proper (with the variant's own tail)
 
     # ---- shared plumbing ---------------------------------------------------------------------------
-    def _read(self):
-        """The one wait of a reset() / step(): -> (obs [1, n], reward, done, r, c, cb, cs, tb)."""
-        self._env.sync()
+    def _read(self, wait=True):
+        """The one wait of a reset() / step() (step_scalar_wait() has waited already): -> (obs [1, n], reward, done, r, c, cb, cs, tb)."""
+        if wait:
+            self._env.sync()
         row = self._row_np.copy()                              # the buffer is rewritten by the next launch
         rec = row[0, self._nobs:]
         return row[:, :self._nobs], float(rec[0]), bool(rec[1]), int(rec[2]), int(rec[3]), int(rec[4]), int(rec[5]), int(rec[6])
@@ -96,11 +97,11 @@ class _Facade(_Base):
             self.step_size = int(step_size)                    # hindsight variants: injected by the caller
         a = int(action)
         bad = not (0 <= a < self.action_dim) and self._dim != 3
-        self._env.step_scalar(a if -2 ** 31 <= a < 2 ** 31 else -1, self.step_size, out=self._row)
+        self._env.step_scalar_wait(a if -2 ** 31 <= a < 2 ** 31 else -1, self.step_size, self._row)   # launch + the step's one wait
         if bad:  # the reference leaves `position` unbound here, after count_step and the RNG have advanced
             self.count_step += 1
             raise UnboundLocalError("local variable 'position' referenced before assignment")
-        obs, reward, done, r, c, cb, cs, tb = self._read()
+        obs, reward, done, r, c, cb, cs, tb = self._read(False)
         self.count_step = cs
         self._set_cb(cb)
         return obs, reward, done, (r, c)
