@@ -729,14 +729,14 @@ def main():
                          "note": "snac_amd.vector.VectorizedEnvWrapper.step(actions): host numpy in and out, no auto-reset (stepped past done like the "
                                  "reference's loop); the reference's wrapper does its N env.step() calls in turn on one core"}
 
-        def step_cfg(name, kind, nn, reps):
-            e = BatchedDMPEnv(kind, True, nn, device=dev, seed=1)
+        def step_cfg(name, kind, nn, reps, layout=None):
+            e = BatchedDMPEnv(kind, True, nn, device=dev, seed=1, **({"layout": layout} if layout else {}))
             e.reset()
             out = (view((nn, e.obs_dim), torch.float64), torch.empty(nn, dtype=torch.float32, device=dev), torch.empty(nn, dtype=torch.uint8, device=dev))
             ms = timed(lambda: e.step(auto_reset=True, out=out), reps)
-            algb = CONTRACT_BYTES[(kind, "f64")]
+            algb = CONTRACT_BYTES[(kind, "f64")] + (e.obs_dim - (7 if kind == 1 else 51)) * 8    # a layout variant's tail is written too
             gbs = algb * nn / (ms * 1e-3) / 1e9
-            res[name] = {"kernel": last_kernel(), "us_per_tick": ms * 1e3, "env_steps_per_s": nn / (ms * 1e-3), "alg_bytes_per_env_step": algb, "achieved_GBs": gbs,
+            res[name] = {"kernel": last_kernel(), "us_per_tick": ms * 1e3, "values_per_row": e.obs_dim, "env_steps_per_s": nn / (ms * 1e-3), "alg_bytes_per_env_step": algb, "achieved_GBs": gbs,
                          "frac": gbs / HBM_PEAK_GBS, "launches": reps,
                          "note": "device time per tick, launches enqueued back to back" + ("" if nn >= 262144 else "; at this batch size the host's enqueue rate is part of it")}
 
@@ -759,6 +759,7 @@ def main():
         for kind in (2, 3):
             for nn in (65536, 524288):
                 step_cfg("step_%dd_dynamic_n%d" % (kind, nn), kind, nn, 200)
+        step_cfg("step_2d_ppo_layout_n65536", 2, 65536, 100, layout="ppo")   # what a trainer that steps 65 536 envs per tick reads: 451-value rows
         for kind in (2, 3):
             edges_cfg("transition_%dd_524288_edges" % kind, kind, 524288, 20)
         gather_cfg("replay_gather_65536", 65536, 64, 65536, 20)

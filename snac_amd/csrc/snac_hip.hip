@@ -3108,22 +3108,28 @@ __global__ __launch_bounds__(WPB * 64) void k_transition2d(const KArgs a) {
 //   both    the 51 values of an env leave through emit_tile (LDS transposition, 1 KiB stores); the staging tile reuses the
 //       record / scratch LDS, whose values are in registers by then.  Episodic sums by no-return atomics (nothing waits for them).
 // Write-back: the header, the episode counter of an env that was reset, the ONE changed row word / cell (a reset env: its record).
-// Identity rows only (snac_step, snac_step_scalar), canonical layout, N % 4 == 0 and a 16-byte aligned obs; everything else --
-// tree edges with gathered rows, layout variants, N = 1 of the single-env classes -- stays on k_transition2d / 3d / k_transition.
+// Identity rows only (snac_step, snac_step_scalar), N % 4 == 0 and a 16-byte aligned obs; the canonical layout, in 2D also the layout
+// variants of large batches (k_step2d<.., VAR>); everything else -- tree edges with gathered rows, the other layout variants, N = 1 of
+// the single-env classes -- stays on k_transition2d / 3d / k_transition.
 
-template <bool DYN, typename OT, int WPB>
+// VAR: the layout variants of snac_env_desc (rows of a.ld values: the 451-value rows of the PPO copies are what a trainer that steps
+// tens of thousands of envs per tick reads): the rows leave through emit_rows_var (k_rollout2d's row assembly), the plan tail from the
+// lanes' plan rows in LDS.  25 KB of LDS per wave, one block of four waves per CU -- 65 536 envs are exactly one round.
+template <bool DYN, typename OT, int WPB, bool VAR = false>
 __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
     using K = K2D<DYN, 64>;
     constexpr int E = 64, GE = K::GE;
     static_assert(E * GE * 4 <= TILE_STG_BYTES, "the records fit the staging tile");
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * TILE_STG_BYTES / 4];
+    constexpr int PLW = VAR ? GE * 65 : 0, CMPW = VAR ? E * VAR_CMP_WORDS : 0;            // the envs' plan rows [row][65], emit_rows_var's records
+    constexpr int WAVE_WORDS = (VAR ? VAR_STG_BYTES : TILE_STG_BYTES) / 4 + PLW + CMPW;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * WAVE_WORDS];
     const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
     const int env0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * WPB + wv) * E);
     if (env0 >= a.n) return;
     const int nenv = min(E, a.n - env0);
     const bool active = lane < nenv;
     const int env = env0 + (active ? lane : 0);
-    uint32_t* const rec = lds_all + wv * (TILE_STG_BYTES / 4);       // [64][20] row words, then the staging tile
+    uint32_t* const rec = lds_all + wv * WAVE_WORDS;                 // [64][20] row words, then the staging tile
     // ---- every load that does not depend on another: the tile's records (16 bytes per lane), header, episode counter
     uint4 rv[5];
     {
@@ -3224,9 +3230,22 @@ __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
         }
     }
     const double c0 = (double)s.cb, c1 = (double)s.cs;
-    const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
-    emit_tile<OT>((char*)rec, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv,
-                  [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; }, v0, v1);
+    const bool norm = VAR ? (a.sc_norm != 0) : DYN;
+    const double v0 = norm ? c0 / (double)s.tb : c0, v1 = norm ? c1 / (double)a.total_step : c1;
+    if constexpr (VAR) {
+        uint32_t* const pl = rec + VAR_STG_BYTES / 4;                // [20][65]: lane l's column holds its env's plan rows
+        uint32_t* const cmp = pl + PLW;
+        if (a.tail & SNAC_TAIL_PLAN) {
+#pragma unroll
+            for (int q = 0; q < GE; ++q) pl[q * 65 + lane] = prow[q];
+        }
+        const int recv[8] = {reward, done ? 1 : 0, s.r, s.c, s.cb, s.cs, s.tb, s.pidx};   // SNAC_TAIL_RECORD's values (record_value)
+        emit_rows_var<OT>((char*)rec, cmp, (char*)a.obs + (size_t)env0 * (size_t)a.ld * sizeof(OT), lane, nenv, a.ld, a.tail, a.frame_val, wr, v0, v1,
+                          recv, [&](int e, int row) { return pl[row * 65 + e]; });
+    } else {
+        emit_tile<OT>((char*)rec, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv,
+                      [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; }, v0, v1);
+    }
 }
 
 typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));   // a 16-byte global access at a 2-byte aligned address
@@ -4066,12 +4085,23 @@ bool step_stage_ok(const KArgs& a) {
     static const bool off = [] { const char* e = std::getenv("SNAC_STEP_STAGE"); return e && e[0] == '0'; }();
     return !off && !a.src_index && !a.dst_index && (a.n & 3) == 0 && ((uintptr_t)a.obs & 15) == 0;
 }
+// the layout variants on k_step2d<.., VAR>: 64 envs per wave are 64 rows of kilobytes per wave -- batches large enough to fill the
+// CUs that way; below, the 8-env tiles of k_transition spread the rows over more waves.  PPO rows (451 values), us per tick at
+// 24 576 / 32 768 / 65 536 envs: 36.4 / 36.5 / 37.7 against 29.0 / 46.1 / 88.1; L-Net rows 16 384 / 65 536: 7.8 / 9.9 against 7.3 / 20.2
+// (profiles/r04_step_layouts.txt).  SNAC_STEP_VAR_MIN=n replaces both limits.
+bool step_var_ok(const KArgs& a) {
+    static const int nmin = [] { const char* e = std::getenv("SNAC_STEP_VAR_MIN"); return e ? std::atoi(e) : 0; }();   // (tuning)
+    return a.n >= (nmin ? nmin : ((a.tail & SNAC_TAIL_PLAN) ? 32768 : 24576));
+}
 template <int KIND>
 void launch_step_tile(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
     const int tiles = (a.n + 63) / 64;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    if (KIND == 2) {
+    if (KIND == 2 && a.variant) {
+        if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, true>), grid, block, 0, s, a); }
+        else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, true>), grid, block, 0, s, a); }
+    } else if (KIND == 2) {
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4>), grid, block, 0, s, a); }
     } else {
@@ -4142,7 +4172,7 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             if (op == OP_ROLLOUT && roll1dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout1dt"; launch_roll1dt(d, a, s); break; }
             launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D:
-            if (op == OP_TRANSITION && !a.variant && !pipeline_off() && step_stage_ok(a)) { g_kernel = "k_step2d"; launch_step_tile<2>(d, a, s); break; }
+            if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var_ok(a))) { g_kernel = "k_step2d"; launch_step_tile<2>(d, a, s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { g_kernel = "k_transition2d"; launch_trans2d(d, a, s); break; }
             // float32 rows from N = 32 768: 512 staged waves (1.05 -> 0.74 ms per 600 ticks); float64 rows there are level (1.26-1.60 ms
             // by box for either kernel) and stay on 32-env tiles

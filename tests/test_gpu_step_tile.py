@@ -154,3 +154,46 @@ def test_fast_path_revalidates_tensors_that_were_changed_in_place():
     out[0].as_strided_((n, 51), (51, 1))
     env.step(acts, ks, auto_reset=True, out=out)
     assert env.t == t_before + 2
+
+
+STEP_VARIANTS = [
+    (False, dict(layout="lnet2d")),                                  # 53 values, frame value 2, normalised scalars on a static plan
+    (True, dict(layout="ppo")),                                      # 451 values: window, raw counters, the 400 plan cells
+    (True, dict(obs_tail=("position", "plan", "record"), frame_value=2, obs_scalars="raw")),   # 461
+]
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn,kw", STEP_VARIANTS, ids=["lnet2d", "ppo", "all"])
+def test_layout_variants_of_large_batches_step_on_the_tile_form(dyn, kw, f32):
+    """snac_step with a layout variant (rows of 53 .. 461 values) takes k_step2d<.., VAR> from 32 768 envs (rows with the plan tail) /
+    24 576 (short rows): 40 ticks with auto-reset at a time limit of 9 against the oracle configured the same way -- counter-RNG ticks,
+    then explicit inputs --, a ragged last tile (32 768 + 36 envs); one tick of a batch below the limit on k_transition, the same oracle."""
+    import torch
+    from snac_amd import BatchedDMPEnv, _lib
+
+    n = 32768 + 36
+    table = helpers.plan_table(2, dyn, "dense_train" if dyn else "p0")
+    dt = torch.float32 if f32 else torch.float64
+    cast = (lambda x: x.astype(np.float32)) if f32 else (lambda x: x)
+    for nn, kern in ((n, "k_step2d"), (4100, "k_transition")):
+        env = BatchedDMPEnv(2, dyn, nn, plans=table.reshape(len(table), 26, 26), seed=3, total_step=9, obs_dtype=dt, **kw)
+        orc = helpers.oracle().OracleBatch(2, dyn, nn, table, seed=3)
+        orc.configure(obs_norm={None: dyn, "raw": False, "norm": True}[env.obs_scalars], frame=env.frame_value, tail=env.obs_tail)
+        orc.set_total_step(9)
+        assert env.reset().cpu().numpy().tobytes() == cast(orc.reset()).tobytes()
+        rng = np.random.default_rng(2)
+        for t in range(40 if nn == n else 12):
+            if t % 3 == 2:
+                acts, ks = rng.integers(0, 5, nn).astype(np.int8), rng.integers(1, 4, nn).astype(np.int8)
+                og, rg, dg = env.step(torch.from_numpy(acts).to(env.device), torch.from_numpy(ks).to(env.device), auto_reset=True)
+                oc, rc, dc = orc.step(t, acts, ks, auto_reset=True, nthreads=16)
+            else:
+                og, rg, dg = env.step(auto_reset=True)
+                oc, rc, dc = orc.step(t, auto_reset=True, nthreads=16)
+            assert _lib.lib().snac_last_kernel().decode() == kern
+            assert og.cpu().numpy().tobytes() == cast(oc).tobytes(), (t, "obs")
+            assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
+        s, e = orc.stats(), env.episodic_stats()
+        assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
+        assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
