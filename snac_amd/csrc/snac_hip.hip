@@ -2626,7 +2626,20 @@ __global__ __launch_bounds__(WPB * 64) void k_transition(const KArgs a) {
             a.stat_iou_fx[drow] += __double2ll_rn(v * FX40);
         }
     }
-    if (a.obs) emit_obs<K, OT, VAR>(lds, (OT*)a.obs + (size_t)env0 * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
+    if constexpr (VAR && K::A != 8) {
+        // 1D / 2D: a row with the plan tail needs its env's whole plan: staged in LDS first (every load before the first row store: from
+        // the table in memory each batch of 64 plan cells is a vector load behind the stores before it; 2D PPO rows at 16 384 envs:
+        // 26.6 -> 19.3 us per tick).  3D keeps reading the table: its 800-byte plans cost more to stage than they save (130 -> 160 us
+        // at 65 536 envs, six instead of nine waves per CU).
+        if (a.obs && (a.tail & SNAC_TAIL_PLAN)) {
+            for (int e = 0; e < nenv; ++e) K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane);
+            emit_obs<K, OT, VAR, true>(lds, (OT*)a.obs + (size_t)env0 * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
+        } else if (a.obs) {
+            emit_obs<K, OT, VAR>(lds, (OT*)a.obs + (size_t)env0 * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
+        }
+    } else {
+        if (a.obs) emit_obs<K, OT, VAR>(lds, (OT*)a.obs + (size_t)env0 * LD, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
+    }
     if (a.dst_index && active) rows[lane] = (int)drow;           // the scalar slots have been written out by now
     K::store_grid(lds, a, env0, nenv, lane, a.dst_index ? rows : nullptr);
     if (active) { a.hdr[drow] = s.pack(); a.episode[drow] = episode; }
@@ -3109,7 +3122,7 @@ __global__ __launch_bounds__(WPB * 64) void k_transition2d(const KArgs a) {
 //       record / scratch LDS, whose values are in registers by then.  Episodic sums by no-return atomics (nothing waits for them).
 // Write-back: the header, the episode counter of an env that was reset, the ONE changed row word / cell (a reset env: its record).
 // Identity rows only (snac_step, snac_step_scalar), N % 4 == 0 and a 16-byte aligned obs; the canonical layout, in 2D also the layout
-// variants of large batches (k_step2d<.., VAR>); everything else -- tree edges with gathered rows, the other layout variants, N = 1 of
+// variants of large batches (k_step2d<.., VAR>: from 45 056 / 32 768 / 24 576 envs); everything else -- tree edges with gathered rows, the other layout variants, N = 1 of
 // the single-env classes -- stays on k_transition2d / 3d / k_transition.
 
 // VAR: the layout variants of snac_env_desc (rows of a.ld values: the 451-value rows of the PPO copies are what a trainer that steps
@@ -4087,11 +4100,12 @@ bool step_stage_ok(const KArgs& a) {
 }
 // the layout variants on k_step2d<.., VAR>: 64 envs per wave are 64 rows of kilobytes per wave -- batches large enough to fill the
 // CUs that way; below, the 8-env tiles of k_transition spread the rows over more waves.  PPO rows (451 values), us per tick at
-// 24 576 / 32 768 / 65 536 envs: 36.4 / 36.5 / 37.7 against 29.0 / 46.1 / 88.1; L-Net rows 16 384 / 65 536: 7.8 / 9.9 against 7.3 / 20.2
-// (profiles/r04_step_layouts.txt).  SNAC_STEP_VAR_MIN=n replaces both limits.
-bool step_var_ok(const KArgs& a) {
+// 40 960 / 49 152 / 65 536 envs: 36.7 / 36.8 / 37.7 against 35.4 / 40.8 / 88 (float32 rows at 32 768: 26.7 against 32.0); L-Net rows
+// 24 576 / 32 768 / 65 536: 8.3 / 8.8 / 9.9 against 8.5 / 10.5 / 20.2 (profiles/r04_step_layouts.txt).  SNAC_STEP_VAR_MIN=n replaces
+// the limits.
+bool step_var_ok(const KArgs& a, bool f32) {
     static const int nmin = [] { const char* e = std::getenv("SNAC_STEP_VAR_MIN"); return e ? std::atoi(e) : 0; }();   // (tuning)
-    return a.n >= (nmin ? nmin : ((a.tail & SNAC_TAIL_PLAN) ? 32768 : 24576));
+    return a.n >= (nmin ? nmin : ((a.tail & SNAC_TAIL_PLAN) ? (f32 ? 32768 : 45056) : 24576));
 }
 template <int KIND>
 void launch_step_tile(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
@@ -4172,7 +4186,7 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             if (op == OP_ROLLOUT && roll1dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout1dt"; launch_roll1dt(d, a, s); break; }
             launch_tile<K1D, 4>(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D:
-            if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var_ok(a))) { g_kernel = "k_step2d"; launch_step_tile<2>(d, a, s); break; }
+            if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var_ok(a, d->obs_dtype == SNAC_OBS_F32))) { g_kernel = "k_step2d"; launch_step_tile<2>(d, a, s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { g_kernel = "k_transition2d"; launch_trans2d(d, a, s); break; }
             // float32 rows from N = 32 768: 512 staged waves (1.05 -> 0.74 ms per 600 ticks); float64 rows there are level (1.26-1.60 ms
             // by box for either kernel) and stay on 32-env tiles

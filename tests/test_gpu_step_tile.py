@@ -166,13 +166,14 @@ STEP_VARIANTS = [
 @pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
 @pytest.mark.parametrize("dyn,kw", STEP_VARIANTS, ids=["lnet2d", "ppo", "all"])
 def test_layout_variants_of_large_batches_step_on_the_tile_form(dyn, kw, f32):
-    """snac_step with a layout variant (rows of 53 .. 461 values) takes k_step2d<.., VAR> from 32 768 envs (rows with the plan tail) /
-    24 576 (short rows): 40 ticks with auto-reset at a time limit of 9 against the oracle configured the same way -- counter-RNG ticks,
-    then explicit inputs --, a ragged last tile (32 768 + 36 envs); one tick of a batch below the limit on k_transition, the same oracle."""
+    """snac_step with a layout variant (rows of 53 .. 461 values) takes k_step2d<.., VAR> from 45 056 envs (rows with the plan tail;
+    float32 rows: 32 768) / 24 576 (short rows): 40 ticks with auto-reset at a time limit of 9 against the oracle configured the same
+    way -- counter-RNG ticks, then explicit inputs --, a ragged last tile (45 056 + 36 envs); a batch below the limits on k_transition
+    (whole plans staged in LDS for the plan tail), the same oracle."""
     import torch
     from snac_amd import BatchedDMPEnv, _lib
 
-    n = 32768 + 36
+    n = 45056 + 36
     table = helpers.plan_table(2, dyn, "dense_train" if dyn else "p0")
     dt = torch.float32 if f32 else torch.float64
     cast = (lambda x: x.astype(np.float32)) if f32 else (lambda x: x)
