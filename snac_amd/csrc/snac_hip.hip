@@ -536,13 +536,18 @@ __device__ __forceinline__ void write_obs(uint32_t* lds, OT* orow, int nenv, int
                         q += 2;
                     }
                     if (a.tail & SNAC_TAIL_PLAN) {
-                        for (int cell = lane; cell < K::PLAN_CELLS; cell += 64) {
-                            int pv;
-                            if constexpr (LP && K::A != 8) { const int pr = cell / 20; pv = (int)((lds[K::P_OFF + pr * K::RS + e] >> (cell - 20 * pr)) & 1u); }
-                            else if constexpr (LP) pv = (int)plan3[e * K::PLAN_CELLS + cell];   // 3D: k_rollout's own copy of the rows (the kind keeps no plan in LDS)
-                            else pv = K::plan_value(a, pidx, cell);
-                            q[cell] = (OT)(double)pv;
+                        constexpr int NP = (K::PLAN_CELLS + 63) / 64;                     // seven batches of 64 cells
+                        int pv[NP];                                                       // every read of the env first: from the table in memory
+#pragma unroll                                                                            // (LP = false) seven loads in flight, one wait
+                        for (int i = 0; i < NP; ++i) {
+                            const int cell = min(lane + 64 * i, K::PLAN_CELLS - 1);
+                            if constexpr (LP && K::A != 8) { const int pr = cell / 20; pv[i] = (int)((lds[K::P_OFF + pr * K::RS + e] >> (cell - 20 * pr)) & 1u); }
+                            else if constexpr (LP) pv[i] = (int)plan3[e * K::PLAN_CELLS + cell];   // 3D: k_rollout's own copy of the rows (the kind keeps no plan in LDS)
+                            else pv[i] = K::plan_value(a, pidx, cell);
                         }
+#pragma unroll
+                        for (int i = 0; i < NP; ++i)
+                            if (lane + 64 * i < K::PLAN_CELLS) q[lane + 64 * i] = (OT)(double)pv[i];
                         q += K::PLAN_CELLS;
                     }
                     if (a.tail & SNAC_TAIL_RECORD) {
