@@ -760,6 +760,7 @@ def main():
             for nn in (65536, 524288):
                 step_cfg("step_%dd_dynamic_n%d" % (kind, nn), kind, nn, 200)
         step_cfg("step_2d_ppo_layout_n65536", 2, 65536, 100, layout="ppo")   # what a trainer that steps 65 536 envs per tick reads: 451-value rows
+        step_cfg("step_3d_ppo_layout_n65536", 3, 65536, 100, layout="ppo")
         for kind in (2, 3):
             edges_cfg("transition_%dd_524288_edges" % kind, kind, 524288, 20)
         gather_cfg("replay_gather_65536", 65536, 64, 65536, 20)

@@ -3127,7 +3127,7 @@ __global__ __launch_bounds__(WPB * 64) void k_transition2d(const KArgs a) {
 //       record / scratch LDS, whose values are in registers by then.  Episodic sums by no-return atomics (nothing waits for them).
 // Write-back: the header, the episode counter of an env that was reset, the ONE changed row word / cell (a reset env: its record).
 // Identity rows only (snac_step, snac_step_scalar), N % 4 == 0 and a 16-byte aligned obs; the canonical layout, in 2D also the layout
-// variants of large batches (k_step2d<.., VAR>: from 45 056 / 32 768 / 24 576 envs); everything else -- tree edges with gathered rows, the other layout variants, N = 1 of
+// variants of large batches (k_step2d<.., VAR>: from 45 056 / 32 768 / 24 576 envs; k_step3d<.., VAR>: from 24 576); everything else -- tree edges with gathered rows, the other layout variants, N = 1 of
 // the single-env classes -- stays on k_transition2d / 3d / k_transition.
 
 // VAR: the layout variants of snac_env_desc (rows of a.ld values: the 451-value rows of the PPO copies are what a trainer that steps
@@ -3268,7 +3268,11 @@ __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
 
 typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));   // a 16-byte global access at a 2-byte aligned address
 
-template <bool DYN, typename OT, int WPB>
+// VAR: the layout variants (rows of a.ld values: 451 with the plan tail of the PPO copies): the heads (window, scalar slots, position,
+// record) leave in groups of 16 envs through the staging tile, lane = value; the plan tail of an env is its plan row itself -- 50
+// lanes load it 16 bytes each, convert their 8 cells, and the 3200 (1600) bytes are turned through the staging tile into 16-byte
+// pieces in row order; eight envs' loads are issued before the first of their stores (a load behind stores waits for them).
+template <bool DYN, typename OT, int WPB, bool VAR = false>
 __global__ __launch_bounds__(WPB * 64) void k_step3d(const KArgs a) {
     using K = K3D<DYN, 8>;
     constexpr int E = 64, GE = K::GE;
@@ -3419,8 +3423,75 @@ __global__ __launch_bounds__(WPB * 64) void k_step3d(const KArgs a) {
         for (int el = 0; el < K::W; ++el) { const int i = el / 7, j = el - 7 * i; cellv[el] = wp[i * RC + j]; }
     }
     const double c0 = (double)s.cb, c1 = (double)s.cs;
-    const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
-    emit_tile<OT>(scr, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv, [&](int el) { return cellv[el]; }, v0, v1);
+    const bool norm = VAR ? (a.sc_norm != 0) : DYN;
+    const double v0 = norm ? c0 / (double)s.tb : c0, v1 = norm ? c1 / (double)a.total_step : c1;
+    if constexpr (!VAR) {
+        emit_tile<OT>(scr, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv, [&](int el) { return cellv[el]; }, v0, v1);
+    } else {
+        typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte global store at a 4-byte aligned address
+        const int LD = a.ld;
+        const int pos_n = (a.tail & SNAC_TAIL_POSITION) ? 2 : 0, plan_n = (a.tail & SNAC_TAIL_PLAN) ? 400 : 0, rec_n = (a.tail & SNAC_TAIL_RECORD) ? 8 : 0;
+        const int NE = K::D + pos_n + rec_n;                         // values of a row beside the plan tail (<= 61)
+        OT* const orow = (OT*)a.obs + (size_t)env0 * LD;
+        // ---- heads: 16 envs at a time, each lane of the group files its NE values, then one env per store, lane = value
+        const int rv[8] = {reward, done ? 1 : 0, s.r, s.c, s.cb, s.cs, s.tb, s.pidx};   // SNAC_TAIL_RECORD's values (record_value)
+        const int dst = lane < K::D + pos_n ? lane : lane + plan_n;  // the record lies behind the plan tail
+        for (int g0 = 0; g0 < nenv; g0 += 16) {
+            if (lane >= g0 && lane < g0 + 16) {
+                OT* const S = (OT*)scr + (lane - g0) * NE;
+#pragma unroll
+                for (int el = 0; el < K::W; ++el) S[el] = (OT)(double)cellv[el];
+                S[K::W] = (OT)v0; S[K::W + 1] = (OT)v1;
+                OT* q = S + K::D;
+                if (pos_n) { q[0] = (OT)(double)rv[2]; q[1] = (OT)(double)rv[3]; q += 2; }
+                if (rec_n) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) q[j] = (OT)(double)rv[j];
+                }
+            }
+            const int ge = min(16, nenv - g0);
+            OT hv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hv[r] = ((const OT*)scr)[r * NE + min(lane, NE - 1)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (r < ge && lane < NE) orow[(size_t)(g0 + r) * LD + dst] = hv[r];
+        }
+        // ---- plan tails: eight envs' rows loaded, then each turned through the staging tile into pieces in row order
+        if (plan_n) {
+            constexpr int CP = 16 / (int)sizeof(OT);                 // cells per 16-byte piece of the output: 2 / 4
+            constexpr int NPC = 400 / CP;                            // pieces per tail: 200 / 100
+            for (int b0 = 0; b0 < nenv; b0 += 8) {
+                uint4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int pe = __builtin_amdgcn_readlane(s.pidx, min(b0 + u, nenv - 1));
+                    t[u] = ((const uint4*)((const int16_t*)a.plans + (size_t)pe * 400))[min(lane, 49)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (b0 + u < nenv) {                             // wave-uniform
+                        if (lane < 50) {
+                            const uint32_t w4[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+                            OT* const S = (OT*)scr + lane * 8;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) S[c] = (OT)(double)(int)(int16_t)(w4[c >> 1] >> ((c & 1) * 16));
+                        }
+                        char* const gq = (char*)(orow + (size_t)(b0 + u) * LD + K::D + pos_n);
+                        uint4 pv[(NPC + 63) / 64];
+#pragma unroll
+                        for (int k = 0; k < (NPC + 63) / 64; ++k) pv[k] = ((const uint4*)scr)[min(lane + 64 * k, NPC - 1)];
+#pragma unroll
+                        for (int k = 0; k < (NPC + 63) / 64; ++k)
+                            if (lane + 64 * k < NPC) {
+                                u32x4_a4 o; o.x = pv[k].x; o.y = pv[k].y; o.z = pv[k].z; o.w = pv[k].w;
+                                *(u32x4_a4*)(gq + (size_t)(lane + 64 * k) * 16) = o;
+                            }
+                    }
+                }
+            }
+        }
+    }
 }
 
 // reset(mask, plan_idx_in) / observe / iou on the same tile machinery
@@ -4112,6 +4183,12 @@ bool step_var_ok(const KArgs& a, bool f32) {
     static const int nmin = [] { const char* e = std::getenv("SNAC_STEP_VAR_MIN"); return e ? std::atoi(e) : 0; }();   // (tuning)
     return a.n >= (nmin ? nmin : ((a.tail & SNAC_TAIL_PLAN) ? (f32 ? 32768 : 45056) : 24576));
 }
+// 3D: k_step3d<.., VAR>.  PPO rows, us per tick at 16 384 / 65 536 envs: 37.8 / 42.8 against k_transition's 34.2 / 112.6 (float32 rows
+// at 524 288 envs: 403 against 1032) (profiles/r04_step_layouts.txt).  SNAC_STEP_VAR3_MIN=n moves the limit.
+bool step_var3_ok(const KArgs& a) {
+    static const int nmin = [] { const char* e = std::getenv("SNAC_STEP_VAR3_MIN"); return e ? std::atoi(e) : 24576; }();   // (tuning)
+    return a.n >= nmin && a.frame_val == -1;
+}
 template <int KIND>
 void launch_step_tile(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
@@ -4123,6 +4200,9 @@ void launch_step_tile(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     } else if (KIND == 2) {
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4>), grid, block, 0, s, a); }
+    } else if (a.variant) {
+        if (dyn) { if (f32) hipLaunchKernelGGL((k_step3d<true, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<true, double, 4, true>), grid, block, 0, s, a); }
+        else { if (f32) hipLaunchKernelGGL((k_step3d<false, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<false, double, 4, true>), grid, block, 0, s, a); }
     } else {
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step3d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<true, double, 4>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step3d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<false, double, 4>), grid, block, 0, s, a); }
@@ -4209,7 +4289,7 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
             if (op == OP_ROLLOUT && roll3db_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout3db"; launch_roll3db(d, a, s); break; }
             if (op == OP_ROLLOUT && E == 8 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && !pipeline_off()) { g_kernel = "k_rollout3d"; launch_roll3d(d, a, s); break; }
-            if (op == OP_TRANSITION && !a.variant && !pipeline_off() && step_stage_ok(a)) { g_kernel = "k_step3d"; launch_step_tile<3>(d, a, s); break; }
+            if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var3_ok(a))) { g_kernel = "k_step3d"; launch_step_tile<3>(d, a, s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { g_kernel = "k_transition3d"; launch_trans3d(d, a, s); break; }
             if (E == 8 && a.n < 8192) dyn ? launch_dt<K3D, true, 8, 1>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 1>(op, d->obs_dtype, a, s);
             else if (E == 8) dyn ? launch_dt<K3D, true, 8, 4>(op, d->obs_dtype, a, s) : launch_dt<K3D, false, 8, 4>(op, d->obs_dtype, a, s);

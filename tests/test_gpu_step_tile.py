@@ -157,15 +157,18 @@ def test_fast_path_revalidates_tensors_that_were_changed_in_place():
 
 
 STEP_VARIANTS = [
-    (False, dict(layout="lnet2d")),                                  # 53 values, frame value 2, normalised scalars on a static plan
-    (True, dict(layout="ppo")),                                      # 451 values: window, raw counters, the 400 plan cells
-    (True, dict(obs_tail=("position", "plan", "record"), frame_value=2, obs_scalars="raw")),   # 461
+    (2, False, dict(layout="lnet2d")),                               # 53 values, frame value 2, normalised scalars on a static plan
+    (2, True, dict(layout="ppo")),                                   # 451 values: window, raw counters, the 400 plan cells
+    (2, True, dict(obs_tail=("position", "plan", "record"), frame_value=2, obs_scalars="raw")),   # 461
+    (3, True, dict(layout="ppo")),                                   # 3D: 451 values, the plan tail is the 400 plan heights
+    (3, False, dict(obs_tail=("position", "plan", "record"), obs_scalars="norm")),   # 461 on the static plan
+    (3, True, dict(obs_tail=("position", "record"))),                # 61: no plan tail
 ]
 
 
 @pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
-@pytest.mark.parametrize("dyn,kw", STEP_VARIANTS, ids=["lnet2d", "ppo", "all"])
-def test_layout_variants_of_large_batches_step_on_the_tile_form(dyn, kw, f32):
+@pytest.mark.parametrize("dim,dyn,kw", STEP_VARIANTS, ids=["lnet2d", "ppo", "all", "ppo3d", "all3d", "short3d"])
+def test_layout_variants_of_large_batches_step_on_the_tile_form(dim, dyn, kw, f32):
     """snac_step with a layout variant (rows of 53 .. 461 values) takes k_step2d<.., VAR> from 45 056 envs (rows with the plan tail;
     float32 rows: 32 768) / 24 576 (short rows): 40 ticks with auto-reset at a time limit of 9 against the oracle configured the same
     way -- counter-RNG ticks, then explicit inputs --, a ragged last tile (45 056 + 36 envs); a batch below the limits on k_transition
@@ -173,20 +176,21 @@ def test_layout_variants_of_large_batches_step_on_the_tile_form(dyn, kw, f32):
     import torch
     from snac_amd import BatchedDMPEnv, _lib
 
-    n = 45056 + 36
-    table = helpers.plan_table(2, dyn, "dense_train" if dyn else "p0")
+    n = (45056 if dim == 2 else 24576) + 36                          # 3D: k_step3d<.., VAR> from 24 576 envs
+    table = helpers.plan_table(dim, dyn, "dense_train" if dyn else "p0")
     dt = torch.float32 if f32 else torch.float64
     cast = (lambda x: x.astype(np.float32)) if f32 else (lambda x: x)
-    for nn, kern in ((n, "k_step2d"), (4100, "k_transition")):
-        env = BatchedDMPEnv(2, dyn, nn, plans=table.reshape(len(table), 26, 26), seed=3, total_step=9, obs_dtype=dt, **kw)
-        orc = helpers.oracle().OracleBatch(2, dyn, nn, table, seed=3)
+    A = 5 if dim == 2 else 8
+    for nn, kern in ((n, "k_step%dd" % dim), (4100, "k_transition")):
+        env = BatchedDMPEnv(dim, dyn, nn, plans=table.reshape(len(table), 26, 26), seed=3, total_step=9, obs_dtype=dt, **kw)
+        orc = helpers.oracle().OracleBatch(dim, dyn, nn, table, seed=3)
         orc.configure(obs_norm={None: dyn, "raw": False, "norm": True}[env.obs_scalars], frame=env.frame_value, tail=env.obs_tail)
         orc.set_total_step(9)
         assert env.reset().cpu().numpy().tobytes() == cast(orc.reset()).tobytes()
         rng = np.random.default_rng(2)
         for t in range(40 if nn == n else 12):
             if t % 3 == 2:
-                acts, ks = rng.integers(0, 5, nn).astype(np.int8), rng.integers(1, 4, nn).astype(np.int8)
+                acts, ks = rng.integers(0, A, nn).astype(np.int8), rng.integers(1, 4, nn).astype(np.int8)
                 og, rg, dg = env.step(torch.from_numpy(acts).to(env.device), torch.from_numpy(ks).to(env.device), auto_reset=True)
                 oc, rc, dc = orc.step(t, acts, ks, auto_reset=True, nthreads=16)
             else:
