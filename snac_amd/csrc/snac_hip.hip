@@ -3127,18 +3127,20 @@ __global__ __launch_bounds__(WPB * 64) void k_transition2d(const KArgs a) {
 //       record / scratch LDS, whose values are in registers by then.  Episodic sums by no-return atomics (nothing waits for them).
 // Write-back: the header, the episode counter of an env that was reset, the ONE changed row word / cell (a reset env: its record).
 // Identity rows only (snac_step, snac_step_scalar), N % 4 == 0 and a 16-byte aligned obs; the canonical layout, in 2D also the layout
-// variants of large batches (k_step2d<.., VAR>: from 45 056 / 32 768 / 24 576 envs; k_step3d<.., VAR>: from 24 576); everything else -- tree edges with gathered rows, the other layout variants, N = 1 of
+// variants of large batches (k_step2d<.., VAR>: from 45 056 / 32 769 / 24 576 envs, half-filled tiles for 24 577 .. 32 768; k_step3d<.., VAR>:
+// from 24 576); everything else -- tree edges with gathered rows, the other layout variants, N = 1 of
 // the single-env classes -- stays on k_transition2d / 3d / k_transition.
 
 // VAR: the layout variants of snac_env_desc (rows of a.ld values: the 451-value rows of the PPO copies are what a trainer that steps
 // tens of thousands of envs per tick reads): the rows leave through emit_rows_var (k_rollout2d's row assembly), the plan tail from the
 // lanes' plan rows in LDS.  25 KB of LDS per wave, one block of four waves per CU -- 65 536 envs are exactly one round.
-template <bool DYN, typename OT, int WPB, bool VAR = false>
+// TE = 32: half-filled tiles (lanes 32 .. 63 idle) -- twice the waves for batches that do not fill the CUs with 64 rows of kilobytes per wave.
+template <bool DYN, typename OT, int WPB, bool VAR = false, int TE = 64>
 __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
     using K = K2D<DYN, 64>;
-    constexpr int E = 64, GE = K::GE;
+    constexpr int E = TE, GE = K::GE;
     static_assert(E * GE * 4 <= TILE_STG_BYTES, "the records fit the staging tile");
-    constexpr int PLW = VAR ? GE * 65 : 0, CMPW = VAR ? E * VAR_CMP_WORDS : 0;            // the envs' plan rows [row][65], emit_rows_var's records
+    constexpr int PLW = VAR ? GE * 65 : 0, CMPW = VAR ? 64 * VAR_CMP_WORDS : 0;           // the envs' plan rows [row][65], emit_rows_var's records
     constexpr int WAVE_WORDS = (VAR ? VAR_STG_BYTES : TILE_STG_BYTES) / 4 + PLW + CMPW;
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * WAVE_WORDS];
     const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
@@ -4181,7 +4183,17 @@ bool step_stage_ok(const KArgs& a) {
 // the limits.
 bool step_var_ok(const KArgs& a, bool f32) {
     static const int nmin = [] { const char* e = std::getenv("SNAC_STEP_VAR_MIN"); return e ? std::atoi(e) : 0; }();   // (tuning)
-    return a.n >= (nmin ? nmin : ((a.tail & SNAC_TAIL_PLAN) ? (f32 ? 32768 : 45056) : 24576));
+    if (nmin) return a.n >= nmin;
+    if (!(a.tail & SNAC_TAIL_PLAN)) return a.n >= 24576;
+    // rows with the plan tail: half-filled tiles for 24 577 .. 32 768 envs (one round of 1024 waves: 22.7 us at 32 768 envs against
+    // k_transition's 28.8 and the full tiles' 36.6; float32 18.2 / 23.7 / 26.7), full tiles from 45 056 (float32: above 32 768)
+    return (a.n > 24576 && a.n <= 32768) || a.n >= (f32 ? 32769 : 45056);
+}
+// half-filled tiles for rows with the plan tail up to 32 768 envs (SNAC_STEP_VAR_HALF=0 / 1 forces)
+bool step_var_half(const KArgs& a) {
+    static const int force = [] { const char* e = std::getenv("SNAC_STEP_VAR_HALF"); return e ? std::atoi(e) : -1; }();   // (tuning)
+    if (force >= 0) return force != 0;
+    return (a.tail & SNAC_TAIL_PLAN) && a.n <= 32768;
 }
 // 3D: k_step3d<.., VAR>.  PPO rows, us per tick at 16 384 / 65 536 envs: 37.8 / 42.8 against k_transition's 34.2 / 112.6 (float32 rows
 // at 524 288 envs: 403 against 1032) (profiles/r04_step_layouts.txt).  SNAC_STEP_VAR3_MIN=n moves the limit.
@@ -4194,7 +4206,11 @@ void launch_step_tile(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
     const int tiles = (a.n + 63) / 64;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    if (KIND == 2 && a.variant) {
+    if (KIND == 2 && a.variant && step_var_half(a)) {
+        const dim3 grid2((unsigned)(((a.n + 31) / 32 + 3) / 4));
+        if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, true, 32>), grid2, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, true, 32>), grid2, block, 0, s, a); }
+        else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, true, 32>), grid2, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, true, 32>), grid2, block, 0, s, a); }
+    } else if (KIND == 2 && a.variant) {
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, true>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, true>), grid, block, 0, s, a); }
     } else if (KIND == 2) {

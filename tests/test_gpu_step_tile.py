@@ -181,14 +181,17 @@ def test_layout_variants_of_large_batches_step_on_the_tile_form(dim, dyn, kw, f3
     dt = torch.float32 if f32 else torch.float64
     cast = (lambda x: x.astype(np.float32)) if f32 else (lambda x: x)
     A = 5 if dim == 2 else 8
-    for nn, kern in ((n, "k_step%dd" % dim), (4100, "k_transition")):
+    sizes = [(n, "k_step%dd" % dim), (4100, "k_transition")]
+    if dim == 2 and (kw.get("layout") == "ppo" or "plan" in (kw.get("obs_tail") or ())):
+        sizes.append((32768 - 28, "k_step2d"))                       # half-filled tiles (rows with the plan tail, 24 577 .. 32 768 envs), a ragged last one
+    for nn, kern in sizes:
         env = BatchedDMPEnv(dim, dyn, nn, plans=table.reshape(len(table), 26, 26), seed=3, total_step=9, obs_dtype=dt, **kw)
         orc = helpers.oracle().OracleBatch(dim, dyn, nn, table, seed=3)
         orc.configure(obs_norm={None: dyn, "raw": False, "norm": True}[env.obs_scalars], frame=env.frame_value, tail=env.obs_tail)
         orc.set_total_step(9)
         assert env.reset().cpu().numpy().tobytes() == cast(orc.reset()).tobytes()
         rng = np.random.default_rng(2)
-        for t in range(40 if nn == n else 12):
+        for t in range(40 if nn == n else (20 if nn > 20000 else 12)):
             if t % 3 == 2:
                 acts, ks = rng.integers(0, A, nn).astype(np.int8), rng.integers(1, 4, nn).astype(np.int8)
                 og, rg, dg = env.step(torch.from_numpy(acts).to(env.device), torch.from_numpy(ks).to(env.device), auto_reset=True)
