@@ -285,18 +285,25 @@ def main():
         sys.stderr.write("bench.py: %d RCCL ranks need %d GPUs, this node shows %d\n" % (world, world, ndev))
         sys.exit(2)
     local = local % max(ndev, 1) if backend != "nccl" else local
-    if world > 1:
+    # SNAC_BENCH_FORCE_DIST=1: a ONE-rank run initialises the process group all the same and takes the N > 1 code path for every
+    # exchange (RCCL group of one: the async all_reduce on RCCL's stream, work.wait(), the barriers) -- the way to execute that path
+    # on a box with one GPU.  The reduced sums must then equal the local ones (`collective_check`).
+    use_dist = world > 1 or os.environ.get("SNAC_BENCH_FORCE_DIST", "0") == "1"
+    if use_dist:
+        kw = {}
+        if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:   # (forced one-rank group without a launcher)
+            kw = dict(init_method="tcp://127.0.0.1:%d" % _free_port(), rank=rank, world_size=world)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), **kw)   # before any GPU call of this process
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
         assert dist.get_world_size() == args.gpus, "process group size %d != --gpus %d" % (dist.get_world_size(), args.gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     def allreduce_(t, op=None):
         op = op or dist.ReduceOp.SUM
-        if world == 1:
+        if not use_dist:
             return t
         if backend == "nccl":
             dist.all_reduce(t, op=op)
@@ -400,7 +407,7 @@ def main():
         one_pass()
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -412,10 +419,10 @@ def main():
         ev[i][0].record()
         env.rollout(T, obs="all", out=obs)
         ev[i][1].record()
-        s = env.stats_tensor(out=stats) if world == 1 else env.stats_tensor()   # one rank: the sums land where they are kept
-        if world == 1:
+        s = env.stats_tensor(out=stats) if not use_dist else env.stats_tensor()   # no group: the sums land where they are kept
+        if not use_dist:
             continue
-        if world > 1 and backend == "nccl":
+        if backend == "nccl":
             # the pass's one exchange (24 bytes, RCCL): enqueued behind the rollout on RCCL's stream, it overlaps the next
             # pass instead of holding it up; every pass still performs it and all are complete before the clock stops
             try:
@@ -431,6 +438,8 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     dt = float(allreduce_(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
+    # a group of one: what came back from the collective must be this rank's own sums
+    collective_check = bool(torch.equal(stats, env.stats_tensor())) if (use_dist and world == 1) else None
     per_step_ms = [a.elapsed_time(b) for a, b in ev]
     kern_ms = sum(per_step_ms) / max(args.steps, 1)
     # every rank's own kernel time (events on its launch stream), and the proof of how many ranks the collective saw
@@ -511,7 +520,7 @@ def main():
         sys.stderr.write("bench.py: %d RCCL ranks on %d distinct GPUs (%r) -- the measurement is INVALID\n" % (world, len(set(ranks_devices)), ranks_devices))
 
     # ... and every row of one more pass against a SECOND kernel: a twin of the batch rolls out through the tile kernel k_rollout
-    # (an output that is not 16-byte aligned cannot take k_rollout2d's 16-byte stores, snac_hip.hip roll2d_ok) into ordinary memory;
+    # (an output that is not 16-byte aligned cannot take k_rollout2d's 16-byte stores, snac_hip.hip roll2d_ok()) into ordinary memory;
     # all T x N rows, rewards and done flags of the two passes must be equal.  After the clock has stopped; one GPU, rank 0.
     full_check = None
     if world == 1 and os.environ.get("SNAC_BENCH_FULLCHECK", "1") != "0":
@@ -573,16 +582,39 @@ def main():
                 return None
             return flat[:nb].view(dt).view(shape)
 
+        GROUPS = 5
+
         def timed(fn, reps):
-            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            """Device time of one call of fn(): GROUPS groups of `reps` back-to-back calls, every group bracketed by its own pair of
+            events on the launch stream; the MEDIAN group's mean is the figure, min / max are reported beside it, and a run whose
+            slowest group is more than 1.5 x the median is marked `outlier` (round 4: one group of 100 launches once carried a single
+            36 ms stall on the driver's box -- the SMI sampler, a clock event -- and read as 396 instead of 38 us per tick)."""
             for _ in range(max(3, reps // 4)):
                 fn()
-            a_.record()
-            for _ in range(reps):
-                fn()
-            b_.record()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(GROUPS)]
+            for a_, b_ in evs:
+                a_.record()
+                for _ in range(reps):
+                    fn()
+                b_.record()
             torch.cuda.synchronize()
-            return a_.elapsed_time(b_) / reps
+            per = sorted(a_.elapsed_time(b_) / reps for a_, b_ in evs)
+            spread.append({"min": per[0], "median": per[GROUPS // 2], "max": per[-1], "groups": GROUPS, "launches_per_group": reps,
+                           "outlier": bool(per[-1] > 1.5 * per[GROUPS // 2])})
+            return per[GROUPS // 2]
+
+        spread = []                                                # timed()'s last account: spread[-1] goes into the entry it belongs to
+
+        def host_timed(loop, steps):
+            """Host-timed loops (the single-env facade, the numpy wrapper): GROUPS repetitions of `steps` calls, median rate."""
+            per = []
+            for _ in range(GROUPS):
+                t0 = time.perf_counter()
+                loop(steps)
+                per.append((time.perf_counter() - t0) / steps)
+            per.sort()
+            return per[GROUPS // 2], {"min_us": per[0] * 1e6, "median_us": per[GROUPS // 2] * 1e6, "max_us": per[-1] * 1e6, "groups": GROUPS,
+                                      "calls_per_group": steps, "outlier": bool(per[-1] > 1.5 * per[GROUPS // 2])}
 
         res = {}
 
@@ -615,7 +647,7 @@ def main():
             gbs = algb * nn * TT / (ms * 1e-3) / 1e9
             res[name] = {"kernel": last_kernel(), "kernel_ms": ms, "vector_steps": TT, "values_per_row": e.obs_dim, "plans": e.num_plans,
                          "env_steps_per_s": nn * TT / (ms * 1e-3), "written_GBs": written * nn * TT / (ms * 1e-3) / 1e9,
-                         "alg_bytes_per_env_step": algb, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": reps}
+                         "alg_bytes_per_env_step": algb, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": GROUPS * reps, "timing": spread[-1]}
             if note:
                 res[name]["note"] = note
 
@@ -647,7 +679,7 @@ def main():
             algb = 2 * rec + e.obs_dim * 8 + 5 + 8 + 1
             gbs = algb * m / (ms * 1e-3) / 1e9
             res[name] = {"kernel": last_kernel(), "kernel_ms": ms, "edges_per_s": m / (ms * 1e-3), "alg_bytes_per_edge": algb, "achieved_GBs": gbs,
-                         "frac": gbs / HBM_PEAK_GBS, "launches": reps, "note": "random parents in a 2^20-row pool, one child per parent into fresh rows"}
+                         "frac": gbs / HBM_PEAK_GBS, "launches": GROUPS * reps, "timing": spread[-1], "note": "random parents in a 2^20-row pool, one child per parent into fresh rows"}
 
         def gather_cfg(name, nn, cap, batch, reps):
             """snac_replay_gather (row f1; script/DQN/2d/DQN_2d_dynamic.py:145-166): float32 (s, s', plan) minibatch of `batch` random
@@ -673,11 +705,12 @@ def main():
                                                      vp(slot32), vp(ei32), batch, vp(so), vp(sn), vp(pl), e._stream()))
 
             ms = timed(call, reps)
+            tm = spread[-1]
             ms_wrapped = timed(lambda: ring.gather(slot, ei), reps)
             algb = 2 * 408 + 2 * 204 + 1600 + 8 + 3                  # two f64 rows in, two f32 rows + 400 f32 plan cells out, indices, flags
             gbs = algb * batch / (ms * 1e-3) / 1e9
             res[name] = {"kernel": "k_gather", "kernel_ms": ms, "samples_per_s": batch / (ms * 1e-3), "alg_bytes_per_sample": algb, "achieved_GBs": gbs,
-                         "frac": gbs / HBM_PEAK_GBS, "launches": reps, "wrapper_ms": ms_wrapped,
+                         "frac": gbs / HBM_PEAK_GBS, "launches": GROUPS * reps, "timing": tm, "wrapper_ms": ms_wrapped,
                          "note": "kernel_ms: snac_replay_gather alone (raw C ABI); wrapper_ms: ReplayRing.gather, which also gathers action / reward / done with torch"}
 
         def facade_cfg(name, steps=3000):
@@ -696,12 +729,14 @@ def main():
             for i in range(200):
                 if e.step(int(acts[i]))[2]:
                     e.reset()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                if e.step(int(acts[i]))[2]:
-                    e.reset()
-            rate = steps / (time.perf_counter() - t0)
-            res[name] = {"facade_steps_per_s": rate, "us_per_step": 1e6 / rate, "reference_steps_per_s_one_core": 110300.0,
+            def loop(k):
+                for i in range(k):
+                    if e.step(int(acts[i]))[2]:
+                        e.reset()
+
+            per, tm = host_timed(loop, steps)
+            rate = 1.0 / per
+            res[name] = {"facade_steps_per_s": rate, "us_per_step": 1e6 / rate, "reference_steps_per_s_one_core": 110300.0, "timing": tm,
                          "note": "deep_mobile_printing_2d1r(data_path).step(a) of snac_amd.envs, one env, host-timed; reference figure: BASELINE.md section 2 "
                                  "(measured in the build container, other CPU); the drop-in classes are the parity surface, BatchedDMPEnv the throughput surface"}
 
@@ -720,11 +755,13 @@ def main():
             acts = np.random.RandomState(0).randint(0, 5, (steps + 100, nn))
             for i in range(100):
                 w.step(acts[i])
-            t0 = time.perf_counter()
-            for i in range(steps):
-                w.step(acts[100 + i])
-            dt_ = time.perf_counter() - t0
-            res[name] = {"vector_steps_per_s": steps / dt_, "env_steps_per_s": steps * nn / dt_, "us_per_vector_step": 1e6 * dt_ / steps, "num_envs": nn,
+            def loop(k):
+                for i in range(k):
+                    w.step(acts[100 + i])
+
+            per, tm = host_timed(loop, steps)
+            dt_ = per * steps
+            res[name] = {"vector_steps_per_s": steps / dt_, "env_steps_per_s": steps * nn / dt_, "us_per_vector_step": 1e6 * dt_ / steps, "num_envs": nn, "timing": tm,
                          "reference_env_steps_per_s_one_core": 110300.0,
                          "note": "snac_amd.vector.VectorizedEnvWrapper.step(actions): host numpy in and out, no auto-reset (stepped past done like the "
                                  "reference's loop); the reference's wrapper does its N env.step() calls in turn on one core"}
@@ -737,7 +774,7 @@ def main():
             algb = CONTRACT_BYTES[(kind, "f64")] + (e.obs_dim - (7 if kind == 1 else 51)) * 8    # a layout variant's tail is written too
             gbs = algb * nn / (ms * 1e-3) / 1e9
             res[name] = {"kernel": last_kernel(), "us_per_tick": ms * 1e3, "values_per_row": e.obs_dim, "env_steps_per_s": nn / (ms * 1e-3), "alg_bytes_per_env_step": algb, "achieved_GBs": gbs,
-                         "frac": gbs / HBM_PEAK_GBS, "launches": reps,
+                         "frac": gbs / HBM_PEAK_GBS, "launches": GROUPS * reps, "timing": spread[-1],
                          "note": "device time per tick, launches enqueued back to back" + ("" if nn >= 262144 else "; at this batch size the host's enqueue rate is part of it")}
 
         rollout_cfg("c2_1d_static_n4096_T750", 1, False, 4096, False, 40,
@@ -799,15 +836,12 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         headline = (args.kind, dynamic, n, T, dkey) == (2, True, 65536, 600, "f64")
         if os.path.exists(tfile) and headline:
-            import hashlib
-
             with open(tfile) as fh:
                 tj = json.load(fh)
-            with open(os.path.join(ROOT, "snac_amd", "csrc", "snac_hip.hip"), "rb") as fh:
-                now = hashlib.sha256(fh.read()).hexdigest()[:16]
+            now = _lib.kernel_source_sha16()
             if tj.get("source_sha16") == now:                    # the counters were taken with THIS kernel source
                 traffic = tj["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
-                traffic_source = "profiles/traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, snac_hip.hip sha256 %s), bytes per launch / the live kernel time" % now
+                traffic_source = "profiles/traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, kernel source (snac_dev.h + k_roll2d.hip) sha256 %s), bytes per launch / the live kernel time" % now
             else:
                 traffic_source = "none: profiles/traffic.json belongs to kernel source %s, this library was built from %s" % (tj.get("source_sha16"), now)
         written = WRITTEN_BYTES[(args.kind, dkey)] * n * T / (kern_ms * 1e-3) / 1e9
@@ -841,8 +875,10 @@ def main():
                                       "frac": achieved_contract / HBM_PEAK_GBS,
                                       "note": "SURVEY.md 8d's un-fused per-step figure (state, window and scalars through HBM every step); "
                                               "rounds 1-2 reported this as achieved / frac (0.83-0.86 then)"}},
-            "backend": backend if world > 1 else None,
-            "rccl_ranks": ranks_seen if (world > 1 and backend == "nccl") else None,
+            "backend": backend if use_dist else None,
+            "rccl_ranks": ranks_seen if (use_dist and backend == "nccl") else None,
+            "collective_check": collective_check,                 # SNAC_BENCH_FORCE_DIST=1 at one rank: reduced sums == local sums
+            "rccl_async_exchanges": len(pending) if use_dist else None,   # per-pass all_reduce(async_op=True) calls that completed
             "ranks": ranks_seen,
             "kernel_ms_per_rank": per_rank,
             "ranks_devices": ranks_devices,                       # every rank's cuda:<local> PCI bus id: N ranks on N distinct GPUs
@@ -863,10 +899,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.kind, dynamic, n, T, 1)
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    if not (traj_ok and all_ok and devices_ok) or parity_all is False:
+    if not (traj_ok and all_ok and devices_ok) or parity_all is False or collective_check is False:
         sys.exit(4)
 
 

@@ -66,10 +66,25 @@ class SnacError(RuntimeError):
 
 def build(force=False):
     """Compile libsnac_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    src = [os.path.join(CSRC, f) for f in ("snac_hip.hip", "snac_traj.hip", "snac_common.h")] + [os.path.join(INCLUDE, "snac_hip.h")]
+    src = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".inc")) or f == "Makefile"]
+    src.append(os.path.join(INCLUDE, "snac_hip.h"))
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
-        subprocess.check_call(["make", "-s", "-C", CSRC] + (["-B"] if force else []) + ["../libsnac_hip.so"])
+        # one object per translation unit, compiled in parallel (snac_amd/csrc/Makefile: `fast`)
+        jobs = str(max(1, min(8, os.cpu_count() or 1)))
+        subprocess.check_call(["make", "-s", "-C", CSRC, "JOBS=" + jobs] + (["clean", "fast"] if force else ["fast"]))
     return LIB_PATH
+
+
+def kernel_source_sha16():
+    """First 16 hex digits of the sha256 over the headline kernel's source (snac_dev.h + k_roll2d.hip): what profiles/traffic.json
+    is stamped with, so that bench.py reports counter traffic only for the kernel source the counters were taken with."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("snac_dev.h", "k_roll2d.hip"):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 _lib = None

@@ -136,3 +136,23 @@ print("OK")
 '''
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-300:], r.stderr[-800:])
+
+
+def test_bench_takes_its_rccl_path_with_one_rank():
+    """SNAC_BENCH_FORCE_DIST=1: bench.py initialises the RCCL ("nccl") process group before any GPU call although there is one
+    rank, and every pass performs the N > 1 exchange exactly as an 8-rank run does -- all_reduce(async_op=True) of the three int64
+    sums on RCCL's stream behind the rollout, work.wait() for all of them before the clock stops, the barriers either side, the
+    MAX over ranks of the wall time.  What came back must be the rank's own sums, and the line must say RCCL saw one rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SNAC_BENCH_FORCE_DIST="1", SNAC_BENCH_BACKEND="nccl")
+    cmd = [sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--envs", "8192", "--T", "120", "--no-cpu"]
+    out = subprocess.run(cmd, cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    forced = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert forced["backend"] == "nccl" and forced["rccl_ranks"] == 1 and forced["ranks"] == 1 and forced["n_gpus"] == 1
+    assert forced["collective_check"] is True and forced["rccl_async_exchanges"] == 4
+    assert forced["ranks_on_distinct_devices"] is True and forced["parity_vs_oracle"] is True and forced["trajectory_check"] is True
+    env.pop("SNAC_BENCH_FORCE_DIST")
+    plain = _run(cmd, env={"SNAC_BENCH_FORCE_DIST": "0"})
+    assert plain["backend"] is None and plain["rccl_ranks"] is None and plain["collective_check"] is None
+    assert plain["episodic"] == forced["episodic"]                    # the same passes, with and without the group

@@ -77,10 +77,13 @@ def test_config5_3d_dynamic_dense_16384_envs_full_pass():
     assert e["episodes"] > 16384 * 20                             # random agents box themselves in every ~22 steps
 
 
-def test_config4_shard_of_524288_envs():
-    """BASELINE configs[3]: rank 5 of 8 x 65536 envs -- the shard's global ids key the counter RNG."""
-    env, orc = _pair(2, True, 65536, "dense_train", base=5 * 65536)
-    _compare_chunks(env, orc, 120, 40)
+@pytest.mark.parametrize("rank", [0, 5, 7])
+def test_config4_shard_of_524288_envs(rank):
+    """BASELINE configs[3]: ranks 0, 5 and 7 of 8 x 65536 envs, every one of the pass's 600 ticks -- the shard's global ids key
+    the counter RNG, so what a rank computes does not depend on the ranks beside it."""
+    env, orc = _pair(2, True, 65536, "dense_train", base=rank * 65536)
+    e = _compare_chunks(env, orc, 600, 40)
+    assert e["episodes"] > 65536
 
 
 @pytest.mark.parametrize("kind", [(1, False), (1, True), (2, False), (2, True), (3, False), (3, True)], ids=str)

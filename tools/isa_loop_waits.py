@@ -3,7 +3,7 @@ in a loop that stores observation rows also waits for the rows stored before it 
 value is first USED: a value loaded before the loop and first used in a rare branch of the loop (the episode counter in the reset
 branch), or the join behind a rare path that loads, silently becomes a `vmcnt(0)` in the loop (round 3: both happened).
 
-    hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -fno-strict-aliasing --cuda-device-only -S -o /tmp/snac.s snac_amd/csrc/snac_hip.hip
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -fno-strict-aliasing --cuda-device-only -S -o /tmp/snac.s snac_amd/csrc/k_roll2d.hip   (any k_*.hip unit)
     python tools/isa_loop_waits.py [name fragments ...]
 prints, per kernel: the loop with the most stores, its store / load instruction counts and the vmcnt waits inside it."""
 import re, sys

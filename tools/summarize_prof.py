@@ -92,9 +92,9 @@ for fam, v in sorted(vals.items()):
                  note="2*FETCH_SIZE + WRITE_SIZE (KiB) per launch; separate --pmc passes; gfx950 read correction x2")
         if fam.startswith("k_rollout"):
             # which kernel source the counters belong to: bench.py drops `roofline.traffic` when the library has changed since
-            import hashlib
-            src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "snac_amd", "csrc", "snac_hip.hip")
-            t["source_sha16"] = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from snac_amd import _lib
+            t["source_sha16"] = _lib.kernel_source_sha16()
             with open(os.path.join(out, "traffic.json"), "w") as fh:
                 json.dump(t, fh, indent=1)
         print("== traffic:", t)
