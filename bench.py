@@ -777,6 +777,31 @@ def main():
                          "frac": gbs / HBM_PEAK_GBS, "launches": GROUPS * reps, "timing": spread[-1],
                          "note": "device time per tick, launches enqueued back to back" + ("" if nn >= 262144 else "; at this batch size the host's enqueue rate is part of it")}
 
+        def default_alloc_cfg(name, reps):
+            """The headline pass as a user calls it -- env.rollout(T) with NO out= --: the observation tensor comes from the cache of
+            measured trajectory blocks (snac_amd/trajmem.py cached_empty: built on the first call, recycled afterwards)."""
+            from snac_amd import trajmem
+
+            e = BatchedDMPEnv(2, True, n, device=dev, seed=1)
+            e.reset()
+            c0 = trajmem.cache_stats()
+            t0 = time.perf_counter()
+            o = e.rollout(T)[0]
+            torch.cuda.synchronize()
+            first = time.perf_counter() - t0
+            lay = trajmem.layout_of(o)
+            del o
+            ms = timed(lambda: e.rollout(T), reps)
+            c1 = trajmem.cache_stats()
+            algb = 413 + 2.0 * STATE_BYTES[2] / T
+            gbs = algb * n * T / (ms * 1e-3) / 1e9
+            res[name] = {"kernel": last_kernel(), "kernel_ms": ms, "vs_headline": ms / kern_ms, "first_call_s": first, "block_layout": lay,
+                         "blocks_built": c1["built"] - c0["built"], "blocks_reused": c1["reused"] - c0["reused"],
+                         "env_steps_per_s": n * T / (ms * 1e-3), "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": GROUPS * reps,
+                         "timing": spread[-1], "note": "BatchedDMPEnv.rollout(T) without out=: rows, reward and done allocated by the call itself"}
+            trajmem.cache_trim()
+
+        default_alloc_cfg("headline_default_alloc", 12)
         rollout_cfg("c2_1d_static_n4096_T750", 1, False, 4096, False, 40,
                     "time-parallel kernel k_rollout1dt (one wave per env, lane = tick, the rows of 16 envs through an LDS tile as 896-byte runs: "
                     "0.29 -> 0.05 ms); the pass writes only 187 MB and is bound by instruction issue (7.3 per env-step by the counters), not by the HBM rate")

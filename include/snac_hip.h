@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define SNAC_ABI_VERSION 6
+#define SNAC_ABI_VERSION 7
 
 typedef enum snac_status {
     SNAC_OK = 0,
@@ -357,6 +357,21 @@ int snac_replay_gather_tiled(const snac_env_desc* desc, const snac_state* st, in
  * np.random's vertices in).  2D total_brick = max(area, 30); 3D plan = mask * 6, total_brick = 6 area. */
 int snac_make_plans(const snac_env_desc* desc, const snac_state* st, int32_t first, int32_t count, int32_t sparse,
                     uint64_t seed, int64_t plan_id_base, const int8_t* vertices, int32_t* area_out, void* stream);
+
+/* ---- hindsight relabelling on the device: the DRQN_hindsight scripts replay a finished episode on a
+ * second env whose plan has been overwritten with the episode's own final grid
+ * (script/DRQN_hindsight/2d/DRQN_hindsight_2D_dynamic.py:270-282: env_hindsight.plan[3:23, 3:23] =
+ *  env_train.environment_memory[3:23, 3:23]; 1D: script/DRQN_hindsight/1d/DRQN_hindsight_1D_static.py:243).  That overwrite as one
+ * launch: for i in [0, m)
+ *     plan row first + i of st  <-  max(interior of grid i, 0)          (2D: the 0 / 1 board; 1D / 3D: the heights)
+ *     st->plan_tb[first + i]    <-  total_brick[i], or (NULL) the total_brick in the header of source env i
+ * The grids come EITHER from the packed records of a batch -- src (its grid and hdr; src_envs rows; src_rows int32[m] picks the
+ * envs, NULL: env i) -- OR from environment_memory double[m][env_height][env_width] in the reference's own format (frame values
+ * are ignored; total_brick is then required).  st and src may be the same batch.  The relabel rollout is then snac_rollout on a
+ * batch whose env i was reset onto row first + i with the recorded actions and step sizes (snac_amd/hindsight.py). */
+int snac_plans_from_grids(const snac_env_desc* desc, const snac_state* st, int32_t m, int32_t first, const snac_state* src,
+                          int32_t src_envs, const int32_t* src_rows, const double* environment_memory,
+                          const int32_t* total_brick, void* stream);
 
 /* current observation of every env without stepping: observation_() + the hstack of
  * Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:64-72 */

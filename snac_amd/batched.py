@@ -42,6 +42,8 @@ class BatchedDMPEnv:
     seed      counter-RNG seed (include/snac_hip.h); env_id_base: global id of local env 0 (multi-GPU shards)
     brick_gt / time_gt   the strict termination tests of the env copies under script/PPO (SNAC_RULE_* in snac_hip.h):
               done when count_brick > total_brick / count_step > total_step instead of >=
+    empty_plans   P: a device plan table of P empty rows (total_brick 1) that plans_from_grids() / generate_plans() fill on the
+              device -- nothing is packed or uploaded by the host (the hindsight relabel path)
     layout    observation layout of the reference's env copies, produced by the same kernels (snac_env_desc.frame_value /
               obs_scalars / obs_tail): None = the canonical classes; "lnet1d" (Env/1D/DMP_Env_1D_static_Lnet.py: position
               appended, 8 values), "lnet2d" (Env/2D/DMP_Env_2D_static_Lnet.py: frame cells 2, normalised scalars), "ppo"
@@ -56,7 +58,8 @@ class BatchedDMPEnv:
 
     def __init__(self, kind, dynamic, num_envs, plans=None, plan_choose=0, density="dense", split="train",
                  device="cuda", seed=1, obs_dtype=torch.float64, env_id_base=0, total_step=None, plan_tb=None,
-                 brick_gt=False, time_gt=False, layout=None, frame_value=None, obs_scalars=None, obs_tail=None, static_plan=0):
+                 brick_gt=False, time_gt=False, layout=None, frame_value=None, obs_scalars=None, obs_tail=None, static_plan=0,
+                 empty_plans=None):
         if not torch.cuda.is_available():
             raise _lib.SnacError("BatchedDMPEnv needs a ROCm GPU: there is no CPU fallback")
         self.kind = _KINDS[kind]
@@ -89,21 +92,31 @@ class BatchedDMPEnv:
             tail = sum(self._TAILS[t] for t in set(tail))
         self.obs_tail = int(tail)
         self.total_step = int(total_step) if total_step else sz.total_step   # override: the 3D L-Net variant (1300)
-        if plans is None:
-            if self.dynamic:
-                plans = _plans.dataset(self.kind, density, split)
-            else:
-                plans = _plans.static_plan(self.kind, plan_choose)[None]
-        self.plans_full = np.array(plans, np.float64)          # own copy: set_plan_row() edits it
-        packed, tb = _plans.pack_plans(self.kind, self.plans_full)
-        if plan_tb is not None:                                # caller-supplied total_brick per plan row (hindsight relabel)
-            tb = np.asarray(plan_tb).astype(np.int16)
-            if tb.shape != (len(packed),) or tb.min() < 1:
-                raise ValueError("plan_tb must hold one positive total_brick per plan")
-        self.num_plans = len(packed)
         dev, N = self.device, self.num_envs
-        self._plans = torch.from_numpy(packed.view(np.int32) if self.kind == 2 else packed).to(dev)
-        self._plan_tb = torch.from_numpy(tb).to(dev)
+        if empty_plans is not None:
+            P = int(empty_plans)
+            if plans is not None or not 1 <= P <= 32767:
+                raise ValueError("empty_plans: 1 .. 32767 rows, without `plans`")
+            self.num_plans = P
+            self.plans_full = None                                 # decoded from the device table when someone asks (_sync_plans_full)
+            self._plans_stale = True
+            self._plans = torch.zeros((P, sz.plan_elems), dtype=torch.int32 if self.kind == 2 else torch.int16, device=dev)
+            self._plan_tb = torch.ones((P,), dtype=torch.int16, device=dev)
+        else:
+            if plans is None:
+                if self.dynamic:
+                    plans = _plans.dataset(self.kind, density, split)
+                else:
+                    plans = _plans.static_plan(self.kind, plan_choose)[None]
+            self.plans_full = np.array(plans, np.float64)          # own copy: set_plan_row() edits it
+            packed, tb = _plans.pack_plans(self.kind, self.plans_full)
+            if plan_tb is not None:                                # caller-supplied total_brick per plan row (hindsight relabel)
+                tb = np.asarray(plan_tb).astype(np.int16)
+                if tb.shape != (len(packed),) or tb.min() < 1:
+                    raise ValueError("plan_tb must hold one positive total_brick per plan")
+            self.num_plans = len(packed)
+            self._plans = torch.from_numpy(packed.view(np.int32) if self.kind == 2 else packed).to(dev)
+            self._plan_tb = torch.from_numpy(tb).to(dev)
         self._hdr = torch.zeros((N, 4), dtype=torch.int32, device=dev)
         self._episode = torch.full((N,), -1, dtype=torch.int32, device=dev)
         self._grid = torch.zeros((N, sz.grid_elems), dtype=_GRID_DTYPE[self.kind], device=dev)
@@ -196,9 +209,10 @@ class BatchedDMPEnv:
         return out
 
     # ---- API -----------------------------------------------------------------------------------
-    def reset(self, mask=None, plan_idx=None):
+    def reset(self, mask=None, plan_idx=None, want_obs=True, check=True):
         """Reset all envs (or those with mask != 0).  plan_idx: per-env plan row; default counter RNG (dynamic)
-        or the single static plan.  Returns the observation of every env [N, obs_dim]."""
+        or the single static plan.  Returns the observation of every env [N, obs_dim] (want_obs=False: None).  check=False skips
+        the range test of plan_idx -- a device-to-host round trip -- for indices the caller built itself."""
         N = self.num_envs
         m = p = None
         if mask is not None:
@@ -210,10 +224,10 @@ class BatchedDMPEnv:
             p = torch.as_tensor(plan_idx, device=self.device)
             if tuple(p.shape) != (N,):
                 raise ValueError("plan_idx must have shape (N,)")
-            if int(p.min()) < 0 or int(p.max()) >= self.num_plans:
+            if check and (int(p.min()) < 0 or int(p.max()) >= self.num_plans):
                 raise ValueError("plan_idx out of range")
             p = p.to(torch.int16).contiguous()
-        obs = self._new_obs()
+        obs = self._new_obs() if want_obs else None
         with torch.cuda.device(self.device):
             _lib.check(self._lib.snac_reset(C.byref(self._desc), C.byref(self._state), _ptr(m), _ptr(p), _ptr(obs),
                                             self._stream()))
@@ -358,7 +372,7 @@ class BatchedDMPEnv:
                     raise ValueError("out must be a contiguous %s tensor of shape %s on %s" % (self.obs_dtype, shape, self.device))
                 o = out
             else:
-                o = torch.empty(shape, dtype=self.obs_dtype, device=self.device)
+                o = self._traj_out(shape)
         if reward_out is not None:
             reward = self._buf(reward_out, (T, N), torch.float32, "reward_out")
         else:
@@ -386,6 +400,28 @@ class BatchedDMPEnv:
                                                       C.byref(rec) if rec is not None else None, self._stream()))
         self.t += T
         return o, reward, (done.view(torch.bool) if done is not None else None)
+
+    # outputs of a GiB and more that rollout() allocates itself come from the cache of measured trajectory blocks (snac_amd/trajmem.py
+    # cached_empty: chunks of two slices of the physical address space taking turns -- 7.0 instead of 5.7-6.0 TB/s for the rows of a
+    # headline pass; built on first use (0.1-5 s), recycled afterwards); anything smaller, or a box where that fails: torch.empty
+    TRAJ_MIN_BYTES = 1 << 30
+
+    def _traj_out(self, shape):
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        if numel * (8 if self.obs_dtype == torch.float64 else 4) >= self.TRAJ_MIN_BYTES and not getattr(self, "_traj_failed", False):
+            try:
+                from . import trajmem
+
+                if trajmem._cache_limit() > 0:
+                    return trajmem.cached_empty(shape, self.obs_dtype, self.device)
+            except (RuntimeError, OSError) as e:                    # SnacError is a RuntimeError: no such block on this box / out of ranges
+                import warnings
+
+                self._traj_failed = True
+                warnings.warn("rollout(): no trajectory block (%s); its outputs come from torch.empty from now on" % (e,))
+        return torch.empty(shape, dtype=self.obs_dtype, device=self.device)
 
     def alloc_trajectory(self, T, candidates=2, reps=3, layout="ticks", memory="vmm"):
         """The [T, N, obs_dim] output tensor of rollout(T, out=...), allocated where this batch's rollout writes fastest.  On
@@ -431,6 +467,7 @@ class BatchedDMPEnv:
         index = int(index)
         if not 0 <= index < self.num_plans:
             raise ValueError("plan index out of range")
+        self._sync_plans_full()
         full = np.asarray(full_plan, np.float64)
         packed, tb = _plans.pack_plans(self.kind, full[None])
         row = torch.from_numpy(packed.view(np.int32) if self.kind == 2 else packed)[0]
@@ -439,6 +476,40 @@ class BatchedDMPEnv:
         self.plans_full[index] = full
         if update_tb:
             self._plan_tb[index] = int(tb[0])
+
+
+    def plans_from_grids(self, src=None, rows=None, environment_memory=None, total_brick=None, first=0):
+        """Plan rows [first, first + m) of THIS batch's device table <- the grids of finished episodes, on the device
+        (snac_plans_from_grids): what the DRQN_hindsight scripts do to the hindsight env's plan before they replay an episode
+        (script/DRQN_hindsight/2d/DRQN_hindsight_2D_dynamic.py:270-282).  Either src (a BatchedDMPEnv of the same kind: its current
+        grids; rows int[m] picks envs, None: all of them in order) or environment_memory (float64 [m, ...] in the reference's format,
+        a device tensor).  total_brick int[m]: the rows' total_brick (None with src: each source env's own, from its header).
+        Envs keep stepping on their current row: reset them to pick the new plans up."""
+        tb = None
+        if total_brick is not None:
+            tb = torch.as_tensor(total_brick, device=self.device).to(torch.int32).contiguous()
+        ri = None
+        if src is not None:
+            if src.kind != self.kind or src.device != self.device:
+                raise ValueError("src must be a batch of the same kind on the same device")
+            if rows is not None:
+                ri = torch.as_tensor(rows, device=self.device).to(torch.int32).contiguous()
+            m = int(ri.numel()) if ri is not None else src.num_envs
+            mem, sstate, sn = None, C.byref(src._state), src.num_envs
+        else:
+            sz = self.sizes
+            mem = torch.as_tensor(environment_memory, device=self.device).to(torch.float64).reshape(-1, sz.env_height, sz.env_width).contiguous()
+            m, sstate, sn = int(mem.shape[0]), None, 0
+            if tb is None:
+                raise ValueError("environment_memory needs total_brick")
+        if tb is not None and tuple(tb.shape) != (m,):
+            raise ValueError("total_brick must have shape (%d,)" % m)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.snac_plans_from_grids(C.byref(self._desc), C.byref(self._state), m, int(first), sstate, sn, _ptr(ri),
+                                                       _ptr(mem), _ptr(tb), self._stream()))
+        self._plans_stale = True
+        self._table_version += 1
+        return m
 
     # ---- plan generators on the device ---------------------------------------------------------------
     def generate_plans(self, first=0, count=None, sparse=False, seed=None, id_base=0, vertices=None):

@@ -353,6 +353,63 @@ __global__ __launch_bounds__(256) void k_gather(const GArgs g) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// plan rows from grids (hindsight relabelling): the DRQN_hindsight scripts overwrite the hindsight env's
+// plan with the finished episode's own final grid and replay the recorded actions against it
+// (script/DRQN_hindsight/2d/DRQN_hindsight_2D_dynamic.py:270-282: plan[3:23, 3:23] = environment_memory[3:23, 3:23]).  Here the
+// "overwrite" is one launch: plan row first + i <- max(interior of grid src_rows[i], 0), taken from the packed records of a batch
+// (its state arrays) or from environment_memory in the reference's own format; total_brick of the row from the caller, or the source
+// env's header (the total_brick its episode ran with).  One wave per plan row.
+struct FArgs {
+    int32_t m, src_envs, first;
+    const int32_t* src_rows;   // [m] env of the source batch (NULL: i)
+    const void* grid;          // packed records of the source batch, or NULL
+    const int4* hdr;           // its headers (total_brick when tb is NULL), or NULL
+    const double* mem;         // [m][H][W] environment_memory with its frame (when grid is NULL)
+    const int32_t* tb;         // [m] total_brick per row or NULL
+    void* plans;
+    int16_t* plan_tb;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_plans_from_grids(const FArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (i >= g.m) return;
+    const int src = g.src_rows ? min(max(g.src_rows[i], 0), g.src_envs - 1) : i;
+    const size_t row = (size_t)(g.first + i);
+    if constexpr (KIND == 1) {
+        int16_t* const dst = (int16_t*)g.plans + row * 32;
+        if (lane < 32) {
+            int v = 0;
+            if (lane < 30) v = g.grid ? (int)((const int16_t*)g.grid)[(size_t)src * 32 + lane] : (int)g.mem[(size_t)i * 34 + lane + 2];
+            dst[lane] = (int16_t)min(max(v, 0), CNT_MAX);
+        }
+    } else if constexpr (KIND == 2) {
+        uint32_t* const dst = (uint32_t*)g.plans + row * 20;
+        if (lane < 20) {
+            uint32_t w = 0u;
+            if (g.grid) w = ((const uint32_t*)g.grid)[(size_t)src * 20 + lane] & 0xFFFFFu;
+            else {
+                const double* const mr = g.mem + (size_t)i * 676 + (size_t)(lane + 3) * 26 + 3;
+                for (int c = 0; c < 20; ++c) w |= (mr[c] > 0.0 ? 1u : 0u) << c;
+            }
+            dst[lane] = w;
+        }
+    } else {
+        int16_t* const dst = (int16_t*)g.plans + row * 400;
+        for (int cell = lane; cell < 400; cell += 64) {
+            const int r = cell / 20, c = cell - 20 * r;
+            const int v = g.grid ? (int)((const int16_t*)g.grid)[(size_t)src * 400 + cell] : (int)g.mem[(size_t)i * 676 + (size_t)(r + 3) * 26 + c + 3];
+            dst[cell] = (int16_t)min(max(v, 0), CNT_MAX);
+        }
+    }
+    if (lane == 0) {
+        int tb = g.tb ? g.tb[i] : (g.hdr ? (int)(int16_t)(g.hdr[src].z & 0xffff) : 1);
+        g.plan_tb[row] = (int16_t)min(max(tb, 1), CNT_MAX);          // the step kernels divide by it
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -482,6 +539,31 @@ int snac_export_grid(const snac_env_desc* d, const snac_state* st, double* out, 
     else hipLaunchKernelGGL((k_export<3>), dim3(grid), dim3(block), 0, s, a, total);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "export launch");
+    return SNAC_OK;
+}
+
+int snac_plans_from_grids(const snac_env_desc* d, const snac_state* st, int32_t m, int32_t first, const snac_state* src,
+                          int32_t src_envs, const int32_t* src_rows, const double* environment_memory, const int32_t* total_brick,
+                          void* stream) {
+    if (int rc = check_common(d, st)) return rc;
+    if (m < 0 || first < 0 || (int64_t)first + m > d->num_plans) return fail(SNAC_ERR_ARG, "plan rows out of range");
+    if ((src != nullptr) == (environment_memory != nullptr)) return fail(SNAC_ERR_ARG, "exactly one of src / environment_memory");
+    if (src && (!src->grid || !src->hdr || src_envs <= 0)) return fail(SNAC_ERR_ARG, "src needs grid, hdr and src_envs > 0");
+    if (src && !src_rows && m > src_envs) return fail(SNAC_ERR_ARG, "m exceeds the source batch");
+    if (!src && src_rows) return fail(SNAC_ERR_ARG, "src_rows index a source batch");
+    if (!src && !total_brick) return fail(SNAC_ERR_ARG, "environment_memory needs total_brick");
+    if (m == 0) return SNAC_OK;
+    FArgs g;
+    g.m = m; g.src_envs = src ? src_envs : m; g.first = first; g.src_rows = src_rows;
+    g.grid = src ? src->grid : nullptr; g.hdr = src ? (const int4*)src->hdr : nullptr; g.mem = environment_memory; g.tb = total_brick;
+    g.plans = const_cast<void*>(st->plans); g.plan_tb = const_cast<int16_t*>(st->plan_tb);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((m + 3) / 4)), block(256);
+    if (d->kind == SNAC_ENV_1D) hipLaunchKernelGGL((k_plans_from_grids<1>), grid, block, 0, s, g);
+    else if (d->kind == SNAC_ENV_2D) hipLaunchKernelGGL((k_plans_from_grids<2>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((k_plans_from_grids<3>), grid, block, 0, s, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "plans_from_grids launch");
     return SNAC_OK;
 }
 

@@ -67,7 +67,7 @@ def _dl_deleter(mt):
     key = C.addressof(mt.contents)
     ent = _live.pop(key, None)
     if ent is not None:
-        ent[0].free()
+        ent[0].free()                                            # a _Block unmaps, a _Lease returns its block to the cache
 
 
 def _via_dlpack(block):
@@ -125,21 +125,39 @@ def reserved_bytes():
     return int(_lib.lib().snac_traj_reserved_bytes())
 
 
+def _nbytes(shape, dtype):
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    return numel, max(1, numel * torch.empty((), dtype=dtype).element_size())
+
+
+def _view(owner, index, numel, shape, dtype):
+    """A torch tensor of `shape` viewing owner.ptr in place; torch keeps `owner` alive with the storage and owner.free() runs when
+    the last tensor sharing it dies."""
+    try:
+        flat = torch.as_tensor(owner, device=torch.device("cuda", index))
+        if flat.data_ptr() != owner.ptr:                         # a copy instead of a view: not what was asked for
+            raise RuntimeError("__cuda_array_interface__ was copied")
+    except Exception:
+        flat = _via_dlpack(owner)
+    if flat.data_ptr() != owner.ptr or flat.device.index != index:
+        raise RuntimeError("this PyTorch build does not view a foreign device pointer in place")
+    return flat[: numel * torch.empty((), dtype=dtype).element_size()].view(dtype).view(tuple(int(d) for d in shape))
+
+
 def traj_empty(shape, dtype, device, pool_cap=0):
     """torch.empty(shape, dtype=dtype, device=device) on snac_traj_alloc memory (contiguous; it holds the pattern of the library's
     own check, not zeros).  pool_cap: bytes of device memory the slice measurement may hold beyond the block while it runs
     (0 = 64 GiB, never more than half of what is free; snac_traj_alloc_ex).  Raises SnacError when the block cannot be allocated
     or fails its check, and RuntimeError when this PyTorch build cannot view a foreign device pointer.  The block is unmapped when
     the last tensor viewing it dies -- snac_traj_free then waits for the whole device to go idle first, so that garbage collection
-    is where the wait happens."""
+    is where the wait happens.  (cached_empty() is the recycling form: what rollout() uses for its own outputs.)"""
     device = torch.device(device)
     if device.type != "cuda":
         raise _lib.SnacError("trajectory memory lives on a ROCm GPU")
     index = device.index if device.index is not None else torch.cuda.current_device()
-    numel = 1
-    for d in shape:
-        numel *= int(d)
-    nbytes = max(1, numel * torch.empty((), dtype=dtype).element_size())
+    numel, nbytes = _nbytes(shape, dtype)
     with torch.cuda.device(index):
         try:
             block = _Block(nbytes, index, pool_cap)
@@ -154,12 +172,95 @@ def traj_empty(shape, dtype, device, pool_cap=0):
             warnings.warn("snac_traj_alloc could not reserve an address range (%.0f GiB of dead ranges held): falling back to torch.empty"
                           % (reserved_bytes() / 2 ** 30))
             return torch.empty(tuple(int(d) for d in shape), dtype=dtype, device=torch.device("cuda", index))
+        return _view(block, index, numel, shape, dtype)
+
+
+# ---- a cache of measured blocks: rollout()'s own outputs ---------------------------------------------------------------------------
+# A measured block costs 0.1-5 s to build and its address range for the life of the process, so blocks handed out by cached_empty()
+# are RECYCLED: when the last tensor viewing a block dies, the block goes back to a free list (per device and size) instead of being
+# unmapped, and the next request of that size takes it from there -- steady state: no allocation, no probe launch, no new address
+# range.  The free list is bounded (SNAC_TRAJ_CACHE_BYTES, default 40 GiB per device; SNAC_TRAJ_CACHE=0 switches the cache off);
+# what does not fit is unmapped as before.  Same-stream reuse is ordered by the stream; a block last used on another stream is
+# handed out behind a device synchronisation.
+_GRAIN = 32 << 20                                                # blocks are whole 32 MB handles
+_free = {}                                                       # (device index, block bytes) -> [(block, stream it was last used on)]
+_stats = {"built": 0, "reused": 0, "returned": 0, "trimmed": 0}
+
+
+def _cache_limit():
+    import os
+
+    if os.environ.get("SNAC_TRAJ_CACHE", "1") == "0":
+        return 0
+    return int(float(os.environ.get("SNAC_TRAJ_CACHE_BYTES", str(40 << 30))))
+
+
+class _Lease:
+    """What a cached_empty() tensor keeps alive: the block goes back to the free list when the storage dies."""
+
+    def __init__(self, block, stream):
+        self.block, self.stream = block, stream
+        self.ptr, self.nbytes, self.device_index = block.ptr, block.nbytes, block.device_index
+        self.__cuda_array_interface__ = block.__cuda_array_interface__
+
+    def free(self):
+        block, self.block = self.block, None
+        if block is None:
+            return
         try:
-            flat = torch.as_tensor(block, device=torch.device("cuda", index))
-            if flat.data_ptr() != block.ptr:                     # a copy instead of a view: not what was asked for
-                raise RuntimeError("__cuda_array_interface__ was copied")
-        except Exception:
-            flat = _via_dlpack(block)
-        if flat.data_ptr() != block.ptr or flat.device.index != index:
-            raise RuntimeError("this PyTorch build does not view a foreign device pointer in place")
-    return flat[: numel * torch.empty((), dtype=dtype).element_size()].view(dtype).view(tuple(int(d) for d in shape))
+            key = (block.device_index, block.nbytes)
+            held = sum(k[1] * len(v) for k, v in _free.items() if k[0] == block.device_index)
+            if held + block.nbytes <= _cache_limit():
+                _free.setdefault(key, []).append((block, self.stream))
+                _stats["returned"] += 1
+                return
+        except Exception:                                       # interpreter shutdown
+            pass
+        _stats["trimmed"] += 1
+        block.free()
+
+    def __del__(self):
+        self.free()
+
+
+def cached_empty(shape, dtype, device, pool_cap=0):
+    """traj_empty() from the cache of measured blocks (see above): the first request of a size builds a block, later ones reuse it
+    once its tensor has died.  Sizes are rounded up to 32 MB.  Raises like traj_empty (no torch.empty fallback: the caller decides)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.SnacError("trajectory memory lives on a ROCm GPU")
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    numel, nbytes = _nbytes(shape, dtype)
+    nbytes = (nbytes + _GRAIN - 1) // _GRAIN * _GRAIN
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    stream = raw(index) if raw is not None else torch.cuda.current_stream(index).cuda_stream
+    lst = _free.get((index, nbytes))
+    with torch.cuda.device(index):
+        if lst:
+            block, last = lst.pop()
+            if last != stream:
+                torch.cuda.synchronize(index)
+            _stats["reused"] += 1
+        else:
+            block = _Block(nbytes, index, pool_cap)
+            _stats["built"] += 1
+        return _view(_Lease(block, stream), index, numel, shape, dtype)
+
+
+def cache_trim(device=None):
+    """Unmap every block on the free list (of one device index, or all).  Returns the number of bytes released."""
+    n = 0
+    for key in list(_free):
+        if device is None or key[0] == device:
+            for block, _ in _free.pop(key):
+                n += block.nbytes
+                _stats["trimmed"] += 1
+                block.free()
+    return n
+
+
+def cache_stats():
+    """{"built", "reused", "returned", "trimmed", "free_bytes"}: what the cache of measured blocks has done in this process."""
+    d = dict(_stats)
+    d["free_bytes"] = sum(k[1] * len(v) for k, v in _free.items())
+    return d

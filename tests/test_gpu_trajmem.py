@@ -228,3 +228,67 @@ def test_measured_blocks_run_the_headline_rollout_at_the_fast_level_every_time()
     assert max(times) <= 1.04 * min(times), (times, infos)
     assert max(times) <= 2.45, (times, infos)
     assert trajmem.reserved_bytes() > 0
+
+
+def test_cache_of_measured_blocks_recycles_instead_of_reallocating():
+    """cached_empty(): 1000 allocate / release turns of a 1 GiB block build ONE block -- no probe launches, no new address range,
+    snac_traj_reserved_bytes() does not move -- and what is written through one turn's tensor is what the next turn's tensor shows
+    (it is the same memory).  cache_trim() unmaps it."""
+    import torch
+    from snac_amd import trajmem
+
+    trajmem.cache_trim()
+    before, dead0 = trajmem.cache_stats(), None
+    ptr = None
+    for i in range(1000):
+        t = trajmem.cached_empty((1 << 27,), torch.float64, "cuda:0")        # 1 GiB
+        if ptr is None:
+            ptr = t.data_ptr()
+            assert trajmem.layout_of(t) is not None
+            dead0 = trajmem.reserved_bytes()                     # (the build's own probe ranges are dead by now)
+        assert t.data_ptr() == ptr
+        if i % 250 == 0:
+            t[-5:] = float(i)
+            assert t[-1].item() == float(i)
+        del t
+    after = trajmem.cache_stats()
+    assert after["built"] - before["built"] == 1 and after["reused"] - before["reused"] == 999
+    assert after["free_bytes"] == 1 << 30 and trajmem.reserved_bytes() == dead0
+    # two tensors alive at once are two blocks; both come back
+    a = trajmem.cached_empty((1 << 27,), torch.float64, "cuda:0")
+    b = trajmem.cached_empty((1 << 27,), torch.float64, "cuda:0")
+    assert a.data_ptr() != b.data_ptr() and a.data_ptr() == ptr
+    dead1 = trajmem.reserved_bytes()
+    del a, b
+    gc.collect()
+    assert trajmem.cache_stats()["free_bytes"] == 2 << 30 and trajmem.reserved_bytes() == dead1
+    assert trajmem.cache_trim() == 2 << 30 and trajmem.cache_stats()["free_bytes"] == 0
+    assert trajmem.reserved_bytes() >= dead1 + (2 << 30)                     # unmapped ranges stay reserved (never recycled)
+
+
+def test_rollout_allocates_its_own_large_outputs_from_the_cache():
+    """rollout(T) without out= writes rows of a GiB and more into a measured trajectory block (the fast
+    memory is the default, not an opt-in), the block is recycled from call to call, and the rows equal those of an explicit
+    torch.empty output."""
+    import torch
+    from snac_amd import BatchedDMPEnv, trajmem
+
+    trajmem.cache_trim()
+    n, T = 65536, 48                                             # 48 x 65536 x 51 x 8 B = 1.28 GB
+    env = BatchedDMPEnv(2, True, n, seed=9)
+    twin = BatchedDMPEnv(2, True, n, seed=9)
+    env.reset(), twin.reset()
+    built0 = trajmem.cache_stats()["built"]
+    ptrs = set()
+    for turn in range(4):
+        o, r, d = env.rollout(T)
+        assert trajmem.layout_of(o) is not None and o.shape == (T, n, 51) and o.is_contiguous()
+        ptrs.add(o.data_ptr())
+        ref = torch.empty((T, n, 51), dtype=torch.float64, device="cuda")
+        o2, r2, d2 = twin.rollout(T, out=ref)
+        assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2)
+        del o, o2, ref
+    assert len(ptrs) == 1 and trajmem.cache_stats()["built"] - built0 == 1
+    small, _, _ = env.rollout(4)                                 # 107 MB: an ordinary tensor
+    assert trajmem.layout_of(small) is None
+    trajmem.cache_trim()

@@ -110,3 +110,64 @@ def test_batched_relabel_in_one_launch(dim):
         L = len(r["actions"])
         assert np.array_equal(rew[:L, i], r["hindsight_reward"].astype(np.float32)), names[i]
         assert np.array_equal(done[:L, i].astype(np.uint8), r["hindsight_done"]), names[i]
+
+
+def test_hindsight_module_has_no_host_round_trip():
+    """the relabel path keeps grids, plans and rewards on the GPU -- no .cpu(), no numpy."""
+    src = open(os.path.join(helpers.ROOT, "snac_amd", "hindsight.py")).read()
+    code = src.split('"""', 2)[2]                     # the module body behind its docstring
+    for word in (".cpu(", "numpy", "np.", ".item(", ".tolist("):
+        assert word not in code, word
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_relabel_of_a_device_batch_without_synchronising(dim):
+    """relabel_batch: the finished episodes live in a BatchedDMPEnv (their final grids were imported into it here); the plan rows are
+    written from its packed records by snac_plans_from_grids and the recorded actions rolled out -- with torch's sync debug mode
+    set to "error", so any device-to-host copy or .item() in the path would raise.  Rewards / done equal the reference's."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+    from snac_amd.hindsight import relabel_batch
+
+    names = [n for n in _names() if n.startswith("%dd." % dim)]
+    recs = [_rec(n) for n in names]
+    T = max(len(r["actions"]) for r in recs)
+    N = len(recs)
+    A = np.zeros((T, N), np.int8)
+    K = np.ones((T, N), np.int8)
+    for i, r in enumerate(recs):
+        A[:len(r["actions"]), i] = r["actions"]
+        K[:len(r["actions"]), i] = r["step_size"]
+    shape = (N, 1, 34) if dim == 1 else (N, 26, 26)
+    grids = np.stack([r["final_grid"].astype(np.float64) for r in recs]).reshape(shape)
+    holder = BatchedDMPEnv(dim, False, N + 3, plan_choose=0)       # the batch the episodes "ended" in (+ rows that are not picked)
+    holder.reset()
+    pos = np.full((N, 2), 3) if dim != 1 else np.full((N,), 2)
+    rows = np.arange(N)[::-1].copy() + 2                              # scattered over the holder, in reverse order
+    holder.import_states(pos, np.zeros(N, np.int32), np.zeros(N, np.int32), grids, total_brick=np.array([int(r["total_brick"]) for r in recs]),
+                         dst=rows)
+    a_dev, k_dev = torch.from_numpy(A).cuda(), torch.from_numpy(K).cuda()
+    rows_dev = torch.from_numpy(rows).cuda()
+    torch.cuda.synchronize()
+    mode = None
+    try:
+        mode = torch.cuda.get_sync_debug_mode()
+        torch.cuda.set_sync_debug_mode("error")
+    except Exception:
+        mode = None
+    try:
+        rew, done = relabel_batch(holder, a_dev, k_dev, rows=rows_dev, dynamic_rules=False)
+    finally:
+        if mode is not None:
+            torch.cuda.set_sync_debug_mode(mode)
+    rew, done = rew.cpu().numpy(), done.cpu().numpy()
+    for i, r in enumerate(recs):
+        L = len(r["actions"])
+        assert np.array_equal(rew[:L, i], r["hindsight_reward"].astype(np.float32)), names[i]
+        assert np.array_equal(done[:L, i].astype(np.uint8), r["hindsight_done"]), names[i]
+    # the same rows from environment_memory in the reference's format, as a device tensor
+    from snac_amd.hindsight import relabel_rewards
+
+    rew2, done2 = relabel_rewards(dim, torch.from_numpy(grids).cuda(), [int(r["total_brick"]) for r in recs], a_dev, k_dev)
+    assert torch.equal(rew2.cpu(), torch.from_numpy(rew)) and np.array_equal(done2.cpu().numpy(), done)
