@@ -736,9 +736,13 @@ def main():
 
             per, tm = host_timed(loop, steps)
             rate = 1.0 / per
+            mbs = e._env.mailbox_stats()
             res[name] = {"facade_steps_per_s": rate, "us_per_step": 1e6 / rate, "reference_steps_per_s_one_core": 110300.0, "timing": tm,
+                         "path": "mailbox (resident wavefront, snac_mailbox_step)" if getattr(e, "_mbox", False) else "launch (snac_step_scalar + wait)",
+                         "mailbox": mbs,
                          "note": "deep_mobile_printing_2d1r(data_path).step(a) of snac_amd.envs, one env, host-timed; reference figure: BASELINE.md section 2 "
-                                 "(measured in the build container, other CPU); the drop-in classes are the parity surface, BatchedDMPEnv the throughput surface"}
+                                 "(measured in the build container, other CPU); mailbox.last_step_us: the resident wave's own account of its last step "
+                                 "(the rest of a step is the bus: 2.5 us for a bare doorbell echo, tools/bar_probe.hip)"}
 
         def vector_cfg(name, nn, steps=1500):
             """VectorizedEnvWrapper.step(actions) (multiprocess.py:15-32 on the HIP path: numpy in, numpy out, one launch + one wait per

@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define SNAC_ABI_VERSION 7
+#define SNAC_ABI_VERSION 8
 
 typedef enum snac_status {
     SNAC_OK = 0,
@@ -383,6 +383,31 @@ int snac_iou(const snac_env_desc* desc, const snac_state* st, double* out, void*
 
 /* environment_memory as the reference holds it: out is double[N][env_height][env_width] with the -1 frame */
 int snac_export_grid(const snac_env_desc* desc, const snac_state* st, double* out, void* stream);
+
+/* ---- the resident single-env stepper (round 5): what the drop-in classes step through.
+ * The reference's scripts drive ONE env, one env.step(action) per loop turn (script/DQN/2d/DQN_2d_dynamic.py:214;
+ * Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:85-147 is 9 us of Python per step).  Through snac_step_scalar such a step is one launch and
+ * one stream wait (15 us).  A mailbox keeps ONE wavefront resident instead: it polls a doorbell in coherent page-locked host memory,
+ * steps env 0 of an N = 1 batch with the kind's own step rules, writes the observation row (obs_dim values of obs_dtype, layout of desc,
+ * tails included) into the mailbox over the bus, acknowledges, and writes the env's state through to st behind the acknowledgement
+ * (snac_mailbox_settle waits for that: call it before any other entry point reads or changes st).  The wave leaves by itself after idle_us microseconds without a command
+ * (0 = 1000) and on snac_mailbox_quit / _destroy; snac_mailbox_step arms (launches) one when none is resident.
+ *   snac_mailbox_touch   the caller has changed st through another entry point (reset, plan row, import ...) and has waited for it:
+ *                        the wave reloads the records before its next step
+ *   snac_mailbox_step    semantics of snac_step_scalar(desc, st, t, action, step_size, auto_reset = 0, row, NULL, NULL) + a wait;
+ *                        episodic sums are updated like snac_step's.  SNAC_ERR_HIP if no acknowledgement arrives within 2 s
+ *   snac_mailbox_row     the row (host pointer, valid until destroy; also a device pointer: the launch path may write it too)
+ *   snac_mailbox_stats   out[0] launches, out[1] steps served, out[2] a wave is resident, out[3] idle_us, out[4..7] the last step in ticks of
+ *                        the GPU's 100 MHz clock: transition, row stores issued, fence before the acknowledgement, write-through behind it */
+typedef struct snac_mailbox snac_mailbox;
+int snac_mailbox_create(const snac_env_desc* desc, uint32_t idle_us, snac_mailbox** out);
+double* snac_mailbox_row(snac_mailbox* mb);
+int snac_mailbox_touch(snac_mailbox* mb);
+int snac_mailbox_step(snac_mailbox* mb, const snac_env_desc* desc, const snac_state* st, int32_t action, int32_t step_size);
+int snac_mailbox_settle(snac_mailbox* mb);   /* wait until st holds the last acknowledged step (the write-through trails the acknowledgement) */
+int snac_mailbox_quit(snac_mailbox* mb);
+int snac_mailbox_destroy(snac_mailbox* mb);
+int snac_mailbox_stats(const snac_mailbox* mb, uint32_t out[8]);
 
 /* ---- tree search: the MCTS variants of the reference (Env/1D/DMP_Env_1D_{static,dynamic}_MCTS*.py,
  * Env/2D/DMP_ENV_2D_{static,dynamic}_MCTS*.py, Env/3D/DMP_simulator_3d_*_MCTS*.py; nine files) ----

@@ -148,9 +148,21 @@ class BatchedDMPEnv:
         self._ssf = None                                             # step_scalar_wait(): the host row validated by the call before
         self._host_ok = None                                         # the new_host_obs() row validated last
         self._mapped = {}                                            # page-locked host tensors seen by _is_mapped
+        self._mb, self._mb_dirty, self._mb_final = None, False, None  # the resident single-env stepper (mailbox_open)
 
     # ---- helpers -------------------------------------------------------------------------------
+    def _settle(self):
+        """With a resident stepper: wait until the records in HBM hold its last acknowledged step (it writes them through behind the
+        acknowledgement; a microsecond at most).  Every path that reads or changes the records passes here first."""
+        if self._mb is not None:
+            rc = self._lib.snac_mailbox_settle(self._mb)
+            if rc:
+                _lib.check(rc)
+
     def _stream(self):
+        if self._mb is not None:
+            self._settle()
+            self._mb_dirty = True                                    # whoever asks for the stream launches: the resident stepper reloads the records
         raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the handle without building a Stream object (2 us)
         if raw is not None:
             return C.c_void_p(raw(self.device.index))
@@ -252,6 +264,9 @@ class BatchedDMPEnv:
             if (o.data_ptr() if want_obs else 0) == f[4] and r.data_ptr() == f[5] and d.data_ptr() == f[6] \
                     and (actions is None or actions.data_ptr() == f[7]) and (step_size is None or step_size.data_ptr() == f[8]) \
                     and _meta(o if want_obs else None, r, d, actions, step_size) == f[10]:
+                if self._mb is not None:
+                    self._settle()
+                    self._mb_dirty = True
                 rc = self._snac_step(self._desc_ref, self._state_ref, self.t & 0xFFFFFFFF, f[7], f[8], 1 if auto_reset else 0,
                                      f[4] or None, f[5], f[6], _raw_stream(self._dev_index))
                 if rc:
@@ -314,6 +329,9 @@ class BatchedDMPEnv:
         f = self._ssf
         if f is not None and f[0] is out and out.data_ptr() == f[2] and _current_device() == self._dev_index:
             st = _raw_stream(self._dev_index)
+            if self._mb is not None:
+                self._settle()
+                self._mb_dirty = True
             rc = self._snac_step_scalar(self._desc_ref, self._state_ref, self.t & 0xFFFFFFFF, action, step_size, 0, f[1], None, None, st)
             if rc:
                 _lib.check(rc)
@@ -471,7 +489,9 @@ class BatchedDMPEnv:
         full = np.asarray(full_plan, np.float64)
         packed, tb = _plans.pack_plans(self.kind, full[None])
         row = torch.from_numpy(packed.view(np.int32) if self.kind == 2 else packed)[0]
+        self._settle()
         self._plans[index].copy_(row.to(self.device))
+        self._mb_dirty = True
         self._table_version += 1
         self.plans_full[index] = full
         if update_tb:
@@ -510,6 +530,60 @@ class BatchedDMPEnv:
         self._plans_stale = True
         self._table_version += 1
         return m
+
+
+    # ---- the resident single-env stepper (snac_mailbox_*: what the drop-in classes step through) ------------------------------
+    def mailbox_open(self, idle_us=0):
+        """N = 1 only.  Creates the mailbox of this env (coherent page-locked host memory + a stream of its own) and returns its row:
+        a host tensor [1, obs_dim] of obs_dtype that mailbox_step() fills -- and that reset_scalar() / step_scalar() accept as `out`
+        (it is page-locked: the launch path writes it over the bus too).  A wavefront becomes resident at the first mailbox_step()
+        and leaves by itself after idle_us (0: 1000) microseconds without a step, at mailbox_close() and at interpreter exit."""
+        import weakref
+
+        if self._mb is not None:
+            return self._mb_row
+        mb = C.c_void_p()
+        _lib.check(self._lib.snac_mailbox_create(C.byref(self._desc), int(idle_us), C.byref(mb)))
+        ptr = self._lib.snac_mailbox_row(mb)
+        n = self.obs_dim
+        if self.obs_dtype == torch.float64:
+            arr = np.ctypeslib.as_array((C.c_double * n).from_address(ptr))
+        else:
+            arr = np.ctypeslib.as_array((C.c_float * n).from_address(ptr))
+        row = torch.from_numpy(arr.reshape(1, n))
+        self._mapped[id(row)] = row                                  # page-locked and mapped: a valid `out` of the launch path
+        self._mb, self._mb_row, self._mb_dirty = mb, row, True
+        self._mb_step = self._lib.snac_mailbox_step
+        self._mb_final = weakref.finalize(self, self._lib.snac_mailbox_destroy, mb)    # gc and interpreter exit: the wave is told to leave
+        return row
+
+    def mailbox_step(self, action, step_size):
+        """One step of the env through its resident wave (semantics of step_scalar(action, step_size) + sync(), no auto-reset);
+        the row of mailbox_open() holds the result when this returns."""
+        if self._mb_dirty:                                           # another entry point has touched the records: wait for it, then say so
+            _lib.check(self._lib.snac_stream_sync(C.c_void_p(_raw_stream(self._dev_index) if _raw_stream is not None
+                                                              else torch.cuda.current_stream(self.device).cuda_stream)))
+            _lib.check(self._lib.snac_mailbox_touch(self._mb))
+            self._mb_dirty = False
+        rc = self._mb_step(self._mb, self._desc_ref, self._state_ref, action, step_size)
+        if rc:
+            _lib.check(rc)
+        self.t += 1
+
+    def mailbox_stats(self):
+        """dict(launches, steps_served, alive, idle_us, last_step_us: the wave's own timing of its last step) of this env's mailbox (None without one)."""
+        if self._mb is None:
+            return None
+        out = (C.c_uint32 * 8)()
+        _lib.check(self._lib.snac_mailbox_stats(self._mb, C.byref(out)))
+        return dict(launches=int(out[0]), steps_served=int(out[1]), alive=bool(out[2]), idle_us=int(out[3]),
+                    last_step_us=dict(transition=out[4] / 100.0, row_stores=out[5] / 100.0, fence=out[6] / 100.0, write_through=out[7] / 100.0))
+
+    def mailbox_close(self):
+        """Ends the resident wave and frees the mailbox (its row tensor must not be used afterwards)."""
+        if self._mb is not None:
+            self._mb_final()                                         # snac_mailbox_destroy, once
+            self._mb, self._mb_row = None, None
 
     # ---- plan generators on the device ---------------------------------------------------------------
     def generate_plans(self, first=0, count=None, sparse=False, seed=None, id_base=0, vertices=None):
@@ -593,6 +667,7 @@ class BatchedDMPEnv:
         means nothing without the table it indexes."""
         # the table is cloned once per VERSION of it, not once per snapshot (tree search snapshots per node; a generated 3D table is
         # 26 MB): every snapshot of an unchanged table shares one read-only clone
+        self._settle()
         snap = self._table_snapshot
         if snap is None or snap[0] != self._table_version:
             snap = self._table_snapshot = (self._table_version, self._plans.clone(), self._plan_tb.clone())
@@ -611,7 +686,9 @@ class BatchedDMPEnv:
                 self._plans.copy_(sd["plans"]); self._plan_tb.copy_(sd["plan_tb"])   # (a snapshot of the current table: nothing to copy)
                 self._table_version += 1
                 self._plans_stale = True                           # plans_full is re-decoded from the device table when it is needed
+        self._settle()
         self._hdr.copy_(sd["hdr"]); self._episode.copy_(sd["episode"]); self._grid.copy_(sd["grid"]); self._stats.copy_(sd["stats"])
+        self._mb_dirty = True
         self.t = int(sd["t"])
         self._was_reset = True
 
@@ -620,6 +697,7 @@ class BatchedDMPEnv:
         children and step each child with its own action -- the batched form of the MCTS variants' functional
         transition(state, action).  Episodic sums start at zero; counter-RNG streams are keyed by the NEW local index."""
         index = torch.as_tensor(index, device=self.device, dtype=torch.long)
+        self._settle()
         self._sync_plans_full()
         child = BatchedDMPEnv(self.kind, self.dynamic, int(index.numel()), plans=self.plans_full, device=self.device, seed=self.seed,
                               obs_dtype=self.obs_dtype, env_id_base=self.env_id_base, total_step=self.total_step,
@@ -789,9 +867,11 @@ class BatchedDMPEnv:
 
     # ---- state views (decoded from the packed 16-byte header) -------------------------------------
     def _h8(self):
+        self._settle()
         return self._hdr.view(torch.int8)
 
     def _h16(self):
+        self._settle()
         return self._hdr.view(torch.int16)
 
     @property
@@ -825,6 +905,7 @@ class BatchedDMPEnv:
 
     @property
     def episode(self):
+        self._settle()
         return self._episode.to(torch.int64)
 
     def plan(self):
@@ -841,12 +922,14 @@ class BatchedDMPEnv:
 
     def episodic_stats(self):
         """Local sums over finished episodes: dict(episodes, return_sum, iou_fx_sum) of python ints (iou in 2^-40 units)."""
+        self._settle()
         s = self._stats.sum(dim=1).tolist()
         return dict(episodes=int(s[0]), return_sum=int(s[1]), iou_fx_sum=int(s[2]))
 
     def stats_tensor(self, out=None):
         """int64 [3] on device: [episodes, return_sum, iou_fx_sum]; what snac_amd.dist all-reduces.  out: a preallocated int64 [3]
         tensor on this device that receives the sums (one kernel instead of sum + copy)."""
+        self._settle()
         if out is None:
             return self._stats.sum(dim=1)
         return torch.sum(self._stats, dim=1, out=out)

@@ -62,7 +62,18 @@ class _Facade(_Base):
         self._table = np.asarray(plans_full, np.float64)
         # the row lives in page-locked host memory: the kernel writes it over the bus, the host waits for the stream -- a
         # step is one launch and one wait, no copy command (tools/facade_time.py: 22 -> 16 us per step)
-        self._row = self._env.new_host_obs()
+        # ... and since round 5 not even a launch: the row is the env's MAILBOX (snac_mailbox_*: a resident wavefront polls a doorbell in
+        # coherent page-locked memory, steps, writes the row back and acknowledges -- BatchedDMPEnv.mailbox_step).  SNAC_MAILBOX=0, or a
+        # box where the mailbox cannot be had, keeps the launch path (step_scalar_wait).
+        self._row = None
+        if os.environ.get("SNAC_MAILBOX", "1") != "0":
+            try:
+                self._row = self._env.mailbox_open()
+            except Exception:                                      # no coherent host memory / no second queue: the launch path it is
+                self._row = None
+        self._mbox = self._row is not None
+        if self._row is None:
+            self._row = self._env.new_host_obs()
         self._row_np = self._row.numpy()
         self._nobs = self._env.obs_dim - 8                     # the observation proper (with the variant's own tail)
 
@@ -71,9 +82,9 @@ class _Facade(_Base):
         """The one wait of a reset() / step() (step_scalar_wait() has waited already): -> (obs [1, n], reward, done, r, c, cb, cs, tb)."""
         if wait:
             self._env.sync()
-        row = self._row_np.copy()                              # the buffer is rewritten by the next launch
-        rec = row[0, self._nobs:]
-        return row[:, :self._nobs], float(rec[0]), bool(rec[1]), int(rec[2]), int(rec[3]), int(rec[4]), int(rec[5]), int(rec[6])
+        row = self._row_np.copy()                              # the buffer is rewritten by the next step
+        rec = row[0, self._nobs:].tolist()                     # one conversion for the eight record values (integers, exact in float64)
+        return row[:, :self._nobs], rec[0], rec[1] != 0.0, int(rec[2]), int(rec[3]), int(rec[4]), int(rec[5]), int(rec[6])
 
     def _do_reset(self, plan_idx):
         if getattr(self, "_plan_dirty", False):                # a hindsight relabel changed the device row: restore it
@@ -97,7 +108,10 @@ class _Facade(_Base):
             self.step_size = int(step_size)                    # hindsight variants: injected by the caller
         a = int(action)
         bad = not (0 <= a < self.action_dim) and self._dim != 3
-        self._env.step_scalar_wait(a if -2 ** 31 <= a < 2 ** 31 else -1, self.step_size, self._row)   # launch + the step's one wait
+        if self._mbox:
+            self._env.mailbox_step(a if -2 ** 31 <= a < 2 ** 31 else -1, self.step_size)   # doorbell + the acknowledgement (raises without one)
+        else:
+            self._env.step_scalar_wait(a if -2 ** 31 <= a < 2 ** 31 else -1, self.step_size, self._row)   # launch + the step's one wait
         if bad:  # the reference leaves `position` unbound here, after count_step and the RNG have advanced
             self.count_step += 1
             raise UnboundLocalError("local variable 'position' referenced before assignment")
@@ -108,6 +122,17 @@ class _Facade(_Base):
 
     def _set_cb(self, cb):
         self.count_brick = cb
+
+    def close(self):
+        """gym.Env.close(): the env's resident wavefront (if one is up) is told to leave and the mailbox is freed; the object stays
+        usable -- further steps take the launch path."""
+        env = getattr(self, "_env", None)
+        if env is not None and getattr(self, "_mbox", False):
+            self._mbox = False
+            row = env.new_host_obs()
+            row.copy_(self._row)
+            self._row, self._row_np = row, row.numpy()
+            env.mailbox_close()
 
     def _sync_plan(self):
         """Hindsight relabelling (script/DRQN_hindsight/2d/DRQN_hindsight_2D_static.py:245-252): after reset() the
