@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define SNAC_ABI_VERSION 8
+#define SNAC_ABI_VERSION 9
 
 typedef enum snac_status {
     SNAC_OK = 0,
@@ -159,6 +159,9 @@ const char* snac_last_error(void);
  * the tile kernels, ...): diagnostics -- which of the specialised kernels a call took depends on batch size, alignment, layout and
  * the tuning switches, and a measurement should name what it measured (bench.py's roofline.kernel) */
 const char* snac_last_kernel(void);
+/* the dispatch table: one line "ENV_VARIABLE=value  # what it decides" per batch-size threshold / switch that selects a kernel
+ * (effective values: the defaults measured on the build pool, or their environment overrides); tools/retune.py re-measures them */
+int snac_tuning(char* out, int32_t cap);
 
 /* constants of (kind, dynamic); replaces the attribute reads of the reference constructors */
 int snac_env_sizes(int kind, int dynamic, snac_sizes* out);

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SNAC_OK = 0
-ABI_VERSION = 8
+ABI_VERSION = 9
 ENV_1D, ENV_2D, ENV_3D = 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 OBS_NONE, OBS_ALL, OBS_LAST, OBS_TILED = 0, 1, 2, 3
@@ -24,7 +24,7 @@ EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_obs_dim", 
            "snac_rollout_rec", "snac_replay_gather", "snac_make_plans", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
            "snac_import_state", "snac_obs_equal", "snac_plans_from_grids", "snac_mailbox_create", "snac_mailbox_row", "snac_mailbox_touch", "snac_mailbox_step",
            "snac_mailbox_quit", "snac_mailbox_settle", "snac_mailbox_destroy", "snac_mailbox_stats", "snac_stream_sync", "snac_rollout_tiled", "snac_replay_gather_tiled", "snac_traj_alloc",
-           "snac_traj_alloc_ex", "snac_traj_free", "snac_traj_layout", "snac_traj_describe", "snac_traj_reserved_bytes", "snac_last_kernel")
+           "snac_traj_alloc_ex", "snac_traj_free", "snac_traj_layout", "snac_traj_describe", "snac_traj_reserved_bytes", "snac_last_kernel", "snac_tuning")
 
 
 class Sizes(C.Structure):
@@ -148,6 +148,18 @@ def lib():
             raise SnacError("libsnac_hip.so ABI version mismatch")
         _lib = L
     return _lib
+
+
+def tuning():
+    """The library's dispatch table as {environment variable: (effective value, what it decides)} (snac_tuning)."""
+    buf = C.create_string_buffer(16384)
+    check(lib().snac_tuning(buf, len(buf)))
+    out = {}
+    for ln in buf.value.decode().splitlines():
+        kv, _, what = ln.partition("  # ")
+        k, _, v = kv.partition("=")
+        out[k] = (int(v), what)
+    return out
 
 
 def check(rc):

@@ -292,7 +292,7 @@ void launch_roll1dt_w(const KArgs& a, hipStream_t s) {
         }
         return;
     }
-    static const int emin = [] { const char* e = std::getenv("SNAC_1D_TP_EB16"); return e ? std::atoi(e) : 3584; }();   // (tuning)
+    const int emin = snac_detail::tune(snac_detail::TN_1D_TP_EB16);
     if (a.n >= emin) launch_roll1dt_e<DYN, OT, 16>(a, s);      // 16 envs per block: runs of 896 / 448 bytes per tick (3072 envs: 0.048 against 0.041 ms; 3584: level)
     else launch_roll1dt_e<DYN, OT, 4>(a, s);                        // small batches: more blocks than CUs first
 }

@@ -493,7 +493,7 @@ void launch_roll2dt_var(const KArgs& a, hipStream_t s) {
 template <bool DYN, typename OT>
 void launch_roll2dt_w(const KArgs& a, hipStream_t s) {
     if (a.variant) { launch_roll2dt_var<DYN, OT>(a, s); return; }
-    static const int emin = [] { const char* e = std::getenv("SNAC_2D_TP_EB8"); return e ? std::atoi(e) : 1025; }();   // (tuning)
+    const int emin = snac_detail::tune(snac_detail::TN_2D_TP_EB8);
     if (a.n >= emin) launch_roll2dt_e<DYN, OT, 8>(a, s);       // 8 envs per block: runs of 3264 / 1632 bytes per tick
     else launch_roll2dt_e<DYN, OT, 4>(a, s);                        // up to 1024 envs: a block per CU first (1536 envs: 0.097 against 0.086 ms)
 }

@@ -471,7 +471,7 @@ __global__ __launch_bounds__(WPB * 64) void k_transition2d(const KArgs a) {
 // small batches take 16 so that a step() on 4096 envs is still 256 waves.  SNAC_T2D_E overrides (tuning).
 template <bool DYN, typename OT>
 void launch_trans2d_e(const KArgs& a, hipStream_t s) {
-    static const int forced = [] { const char* e = std::getenv("SNAC_T2D_E"); return e ? std::atoi(e) : 0; }();
+    const int forced = snac_detail::tune(snac_detail::TN_T2D_E);
     const int E = (forced == 16 || forced == 32 || forced == 64) ? forced : (a.n >= 65536 ? 32 : 16);
     const int tiles = (a.n + E - 1) / E;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
@@ -495,7 +495,7 @@ void launch_trans3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     }
     // gathered / scattered rows (tree edges): the records through LDS, every memory instruction wide (k_edges3d); SNAC_EDGES3D=0 keeps
     // them on k_transition3d (A/B timing, tests of both paths)
-    static const bool edges_off = [] { const char* e = std::getenv("SNAC_EDGES3D"); return e && e[0] == '0'; }();
+    const bool edges_off = tune(TN_EDGES3D) == 0;
     if (!edges_off && a.obs && (a.n & 3) == 0 && ((uintptr_t)a.obs & 15) == 0) {
         g_kernel = "k_edges3d";
         const dim3 g2((unsigned)((tiles + 1) / 2)), b2(128);     // two waves per block: 51 KB of LDS, three blocks per CU

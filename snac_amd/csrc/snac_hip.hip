@@ -62,9 +62,65 @@ KArgs make_args(const snac_env_desc* d, const snac_state* st) {
 }
 
 
-// tile size: enough tiles to give every SIMD of the 256 CUs a few waves; SNAC_TILE overrides (tuning)
+// ------------------------------------------------------------------------------------------------
+// THE DISPATCH TABLE: every batch-size threshold and switch that decides which kernel a call runs on, in one place.  Each entry is
+// (environment variable, default, what it decides); the defaults are what was measured on the MI355X boxes of the build pool
+// (profiles/ files named per entry).  Overrides are read once per process.  snac_tuning() prints the effective values;
+// tools/retune.py re-measures the crossovers on the box it runs on and prints the overrides that would move them.
+struct Knob { const char* env; int def; const char* what; };
+const Knob KNOBS[TN_COUNT] = {
+    /* TN_PIPELINE        */ {"SNAC_3D_PIPELINE", 1, "0: every launch on the generic tile kernels (k_rollout / k_transition / k_aux)"},
+    /* TN_TILE            */ {"SNAC_TILE", 0, "envs per wave of the tile kernels (8 / 16 / 32 / 64; 0: by batch size, pick_tile)"},
+    /* TN_3D_BLOCK        */ {"SNAC_3D_BLOCK", 1, "0: 3D rollouts stay on k_rollout3d instead of the block kernel k_rollout3db"},
+    /* TN_3D_BLOCK_MIN    */ {"SNAC_3D_BLOCK_MIN", -1, "k_rollout3db from this many envs (-1: the two defaults below)"},
+    /* TN_3D_BLOCK_MIN_F64*/ {"SNAC_3D_BLOCK_MIN_F64", 4096, "k_rollout3db, float64 rows, from (4096 envs: 0.982 against k_rollout3d's 1.031 ms per 1000 ticks, 2048: 0.986 / 0.974; r05_retune.txt)"},
+    /* TN_3D_BLOCK_MIN_F32*/ {"SNAC_3D_BLOCK_MIN_F32", 4096, "k_rollout3db, float32 rows, from (4096 envs: 1.02 against 0.97 ms)"},
+    /* TN_2D_STAGE        */ {"SNAC_2D_STAGE", 1, "0: 2D rollouts stay on the tile kernel instead of k_rollout2d"},
+    /* TN_2D_STAGE_MIN    */ {"SNAC_2D_STAGE_MIN", 0, "k_rollout2d from this many envs (0: the two defaults below)"},
+    /* TN_2D_STAGE_MIN_F64*/ {"SNAC_2D_STAGE_MIN_F64", 32769, "k_rollout2d, float64 rows, from (40 960 envs: 1.56 against 1.99 ms; 32 768: 1.43 against 1.25; r04_2d_midrange.txt)"},
+    /* TN_2D_STAGE_MIN_F32*/ {"SNAC_2D_STAGE_MIN_F32", 32768, "k_rollout2d, float32 rows, from (32 768 envs: 0.81 against 1.06 ms)"},
+    /* TN_2D_TP           */ {"SNAC_2D_TP", 1, "0: 2D rollouts stay off the time-parallel k_rollout2dt"},
+    /* TN_2D_TP_MAX       */ {"SNAC_2D_TP_MAX", 0, "k_rollout2dt up to this many envs (0: the defaults below)"},
+    /* TN_2D_TP_MAX_F64   */ {"SNAC_2D_TP_MAX_F64", 19456, "k_rollout2dt, float64 rows, up to (18 432 envs: 5.8 against 5.2 TB/s; r04_2d_midrange.txt part 3)"},
+    /* TN_2D_TP_GAP_LO    */ {"SNAC_2D_TP_GAP_LO", 15873, "... except from here ..."},
+    /* TN_2D_TP_GAP_HI    */ {"SNAC_2D_TP_GAP_HI", 16384, "... to here, where the tile kernel's 256 waves fill the chip exactly (5.8 against 5.55 TB/s)"},
+    /* TN_2D_TP_MAX_F32   */ {"SNAC_2D_TP_MAX_F32", 30719, "k_rollout2dt, float32 rows, up to (16 384 envs: 4.2 against 2.9 TB/s)"},
+    /* TN_2D_TP_MAX_ODD   */ {"SNAC_2D_TP_MAX_ODD", 8192, "k_rollout2dt for batches whose per-tick runs are not 16-byte pieces, up to"},
+    /* TN_2D_TP_VAR_MAX   */ {"SNAC_2D_TP_VAR_MAX", 0, "k_rollout2dt<VAR> (layout variants) up to this many envs (0: the two defaults below)"},
+    /* TN_2D_TP_VAR_PLAN  */ {"SNAC_2D_TP_VAR_MAX_PLAN", 49152, "rows with the plan tail (451 values) on k_rollout2dt<VAR> up to (r04_2d_layouts.txt part 3)"},
+    /* TN_2D_TP_VAR_SHORT */ {"SNAC_2D_TP_VAR_MAX_SHORT", 6144, "short variant rows (53-61 values) on k_rollout2dt<VAR> up to"},
+    /* TN_2D_TP_EB8       */ {"SNAC_2D_TP_EB8", 1025, "k_rollout2dt blocks hold 8 envs instead of 4 from (1536 envs: 0.086 against 0.097 ms)"},
+    /* TN_1D_TP           */ {"SNAC_1D_TP", 1, "0: 1D rollouts stay on the tile kernel instead of k_rollout1dt"},
+    /* TN_1D_TP_MAX       */ {"SNAC_1D_TP_MAX", 0, "k_rollout1dt up to this many envs (0: the two defaults below)"},
+    /* TN_1D_TP_MAX_F64   */ {"SNAC_1D_TP_MAX_F64", 57344, "k_rollout1dt, float64 rows, up to (57 344 envs: 0.64 against 0.77 ms per 750 ticks, 65 536: 0.92 / 0.72; r05_retune.txt)"},
+    /* TN_1D_TP_MAX_F32   */ {"SNAC_1D_TP_MAX_F32", 65536, "k_rollout1dt, float32 rows, up to (65 536 envs: 0.65 against 0.73 ms)"},
+    /* TN_1D_TP_VAR_MAX   */ {"SNAC_1D_TP_VAR_MAX", 65536, "k_rollout1dt<VAR> (layout variants) up to (r04_1d_layouts.txt)"},
+    /* TN_1D_TP_EB16      */ {"SNAC_1D_TP_EB16", 3584, "k_rollout1dt blocks hold 16 envs instead of 4 from (3072 envs: 0.048 against 0.041 ms; 3584: level)"},
+    /* TN_STEP_STAGE      */ {"SNAC_STEP_STAGE", 1, "0: snac_step stays on k_transition2d / 3d instead of k_step2d / 3d"},
+    /* TN_STEP_VAR_MIN    */ {"SNAC_STEP_VAR_MIN", 0, "2D steps with a layout variant on k_step2d<VAR> from this many envs (0: the defaults below)"},
+    /* TN_STEP_VAR_SHORT  */ {"SNAC_STEP_VAR_MIN_SHORT", 24576, "short variant rows on k_step2d<VAR> from (24 576 envs: 8.3 against 8.5 us per tick; r04_step_layouts.txt)"},
+    /* TN_STEP_VAR_HALF_LO*/ {"SNAC_STEP_VAR_HALF_LO", 24577, "rows with the plan tail on half-filled tiles of k_step2d<VAR> from ..."},
+    /* TN_STEP_VAR_HALF_HI*/ {"SNAC_STEP_VAR_HALF_HI", 32768, "... to (32 768 envs: 22.7 us against k_transition's 28.8 and the full tiles' 36.6)"},
+    /* TN_STEP_VAR_F64    */ {"SNAC_STEP_VAR_FULL_F64", 45056, "rows with the plan tail, float64, on full tiles of k_step2d<VAR> from (49 152 envs: 36.8 against 40.8 us)"},
+    /* TN_STEP_VAR_F32    */ {"SNAC_STEP_VAR_FULL_F32", 32769, "the same, float32 rows (32 768 envs: 26.7 against 32.0 us)"},
+    /* TN_STEP_VAR_HALF   */ {"SNAC_STEP_VAR_HALF", -1, "0 / 1: never / always half-filled tiles for rows with the plan tail (-1: the range above)"},
+    /* TN_STEP_VAR3_MIN   */ {"SNAC_STEP_VAR3_MIN", 24576, "3D steps with a layout variant on k_step3d<VAR> from (65 536 envs: 42.8 against 112.6 us)"},
+    /* TN_T2D_E           */ {"SNAC_T2D_E", 0, "edges per wave of k_transition2d (16 / 32 / 64; 0: 32 from 65 536 edges, else 16)"},
+    /* TN_EDGES3D         */ {"SNAC_EDGES3D", 1, "0: 3D tree edges with gathered rows stay on k_transition3d instead of k_edges3d"},
+};
+
+int tune(int id) {
+    static int v[TN_COUNT];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int i = 0; i < TN_COUNT; ++i) { const char* e = std::getenv(KNOBS[i].env); v[i] = e ? std::atoi(e) : KNOBS[i].def; }
+    });
+    return v[id];
+}
+
+// tile size of the tile kernels: enough tiles to give every SIMD of the 256 CUs a few waves
 int pick_tile(int kind, int n) {
-    static const int forced = [] { const char* e = std::getenv("SNAC_TILE"); return e ? std::atoi(e) : 0; }();
+    const int forced = tune(TN_TILE);
     if (kind == SNAC_ENV_3D) return forced == 16 ? 16 : 8;   // 8: 17 KB of LDS per wave, 9 waves per CU; measured +10-15 % over 16
     if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
     // measured per kind (tools/ab_time.py sweeps): 2D wants large tiles early (E x 408-byte store runs),
@@ -76,109 +132,59 @@ int pick_tile(int kind, int n) {
     return 8;                        // small batches: one-wave blocks of 8 envs, so that 4096 envs still reach every CU
 }
 
-// SNAC_3D_PIPELINE=0 keeps every launch on the generic tile kernels (A/B timing, tests of both paths)
-bool pipeline_off() {
-    static const bool off = [] { const char* e = std::getenv("SNAC_3D_PIPELINE"); return e && e[0] == '0'; }();
-    return off;
-}
+bool pipeline_off() { return tune(TN_PIPELINE) == 0; }
+inline bool every_row(const KArgs& a) { return a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED; }
+inline bool pieces16(const KArgs& a) { return (a.n & 3) == 0 && (((uintptr_t)a.obs) & 15) == 0; }
 
-// 3D rollouts by blocks of 64 envs; SNAC_3D_BLOCK=0 keeps them on k_rollout3d (A/B timing, tests of both paths)
+// 3D rollouts by blocks of 64 envs (k_rollout3db): every row written, canonical layout, <= TB_MAX plans, 16-byte pieces
 bool roll3db_ok(const KArgs& a, bool f32) {
-    static const bool off = [] { const char* e = std::getenv("SNAC_3D_BLOCK"); return e && e[0] == '0'; }();
-    static const int nmin = [] { const char* e = std::getenv("SNAC_3D_BLOCK_MIN"); return e ? std::atoi(e) : -1; }();   // (tuning)
-    // where k_rollout3d's one-wave blocks stop being faster: float64 rows 4096 envs 1.02 against 1.04 ms, 6144 level, 8192 1.08 against
-    // 1.04; float32 rows 4096 envs 1.02 against 0.97 already
-    const int lim = nmin >= 0 ? nmin : (f32 ? 4096 : 6144);
-    return !off && a.n >= lim && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && (a.n & 3) == 0 &&
-           (((uintptr_t)a.obs) & 15) == 0 && !pipeline_off();
+    const int lim = tune(TN_3D_BLOCK_MIN) >= 0 ? tune(TN_3D_BLOCK_MIN) : tune(f32 ? TN_3D_BLOCK_MIN_F32 : TN_3D_BLOCK_MIN_F64);
+    return tune(TN_3D_BLOCK) != 0 && a.n >= lim && !a.variant && every_row(a) && a.num_plans <= TB_MAX && pieces16(a) && !pipeline_off();
 }
 
-// SNAC_2D_STAGE=0 keeps 2D rollouts on the tile kernel (A/B timing, tests of both paths)
-bool stage2d_off() {
-    static const bool off = [] { const char* e = std::getenv("SNAC_2D_STAGE"); return e && e[0] == '0'; }();
-    return off;
-}
+// the headline kernel k_rollout2d: tiles of 64 envs, every row written, 16-byte pieces
 bool roll2d_ok(const KArgs& a, int E) {
-    return E == 64 && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) &&
-           (a.n & 3) == 0 && ((uintptr_t)a.obs & 15) == 0 && !pipeline_off() && !stage2d_off();
+    return E == 64 && every_row(a) && pieces16(a) && !pipeline_off() && tune(TN_2D_STAGE) != 0;
 }
+int roll2d_from(bool f32) { return tune(TN_2D_STAGE_MIN) ? tune(TN_2D_STAGE_MIN) : tune(f32 ? TN_2D_STAGE_MIN_F32 : TN_2D_STAGE_MIN_F64); }
 
-// time-parallel 2D rollouts (one wave per env, lane = tick): small and middle batches, where the lane-per-env kernels are bound by the
-// chain of their ticks (0.5-0.7 ms per 600 ticks at every N <= 16 384) or leave CUs empty (one wave of 64 envs per CU at N = 16 384).
-// Where it stops paying was measured on trajectory memory (profiles/r04_2d_midrange.txt, part 3): float64 rows up to 19 456 envs --
-// except just below 16 384, where the tile kernel's 256 waves fill the chip exactly (5.8 against 5.55 TB/s) --, float32 rows up to
-// 30 719 (16 384 envs: 4.2 against 2.9 TB/s); batches whose per-tick runs are not 16-byte pieces (odd N) only up to 8192.
-// SNAC_2D_TP=0 keeps every 2D rollout off this kernel (A/B timing, tests of both paths), SNAC_2D_TP_MAX=n replaces the limits by n
+// time-parallel 2D rollouts (k_rollout2dt: one wave per env, lane = tick): small and middle batches, where the lane-per-env kernels are
+// bound by the chain of their ticks (0.5-0.7 ms per 600 ticks at every N <= 16 384) or leave CUs empty
 bool roll2dt_ok(const KArgs& a, bool f32) {
-    static const bool off = [] { const char* e = std::getenv("SNAC_2D_TP"); return e && e[0] == '0'; }();
-    static const int nmax = [] { const char* e = std::getenv("SNAC_2D_TP_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
-    if (off || !(a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) || pipeline_off()) return false;
-    if (a.variant) {
-        // the layout variants (rows of a.ld values: k_rollout2dt<.., VAR>): whole groups of four envs and 16-byte pieces only.  Where
-        // the lane-per-env kernels take over again was measured with the 451-value rows of the PPO copies (profiles/r04_2d_layouts.txt)
-        // (profiles/r04_2d_layouts.txt, part 3): 6.0-6.4 TB/s from 1024 envs on against k_rollout2d's 5.45 at 49 152 envs and 7.2 at 65 536;
-        // short rows (no plan tail: 53 .. 61 values) level off at 5.8e9 env-steps/s and hand over near 6144 envs
-        static const int vmax = [] { const char* e = std::getenv("SNAC_2D_TP_VAR_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
-        const int lim = vmax ? vmax : ((a.tail & SNAC_TAIL_PLAN) ? 49152 : 6144);
-        return (a.n & 3) == 0 && (((uintptr_t)a.obs) & 15) == 0 && a.n <= lim;
+    if (tune(TN_2D_TP) == 0 || !every_row(a) || pipeline_off()) return false;
+    if (a.variant) {   // k_rollout2dt<.., VAR>: whole groups of four envs and 16-byte pieces only
+        const int lim = tune(TN_2D_TP_VAR_MAX) ? tune(TN_2D_TP_VAR_MAX) : tune((a.tail & SNAC_TAIL_PLAN) ? TN_2D_TP_VAR_PLAN : TN_2D_TP_VAR_SHORT);
+        return pieces16(a) && a.n <= lim;
     }
-    if (nmax) return a.n <= nmax;
+    if (tune(TN_2D_TP_MAX)) return a.n <= tune(TN_2D_TP_MAX);
     const size_t rowb = (size_t)K2D<true, 64>::D * (f32 ? 4 : 8);
     const bool pieces = (((uintptr_t)a.obs) & 15) == 0 && (a.obs_mode == SNAC_OBS_TILED || (((size_t)a.n * rowb) & 15) == 0);
-    if (!pieces) return a.n <= 8192;
-    if (f32) return a.n < 30720;
-    return a.n <= 15872 || (a.n > 16384 && a.n <= 19456);
+    if (!pieces) return a.n <= tune(TN_2D_TP_MAX_ODD);
+    if (f32) return a.n <= tune(TN_2D_TP_MAX_F32);
+    return a.n <= tune(TN_2D_TP_MAX_F64) && !(a.n >= tune(TN_2D_TP_GAP_LO) && a.n <= tune(TN_2D_TP_GAP_HI));
 }
 
-// time-parallel 1D rollouts (one wave per env, lane = tick).  Its rate levels off at 6-7e10 env-steps/s (instruction issue: ~9 per
-// env-step), the tile kernel's keeps growing with the batch: float64 rows 49 152 envs 0.54 against 0.68 ms per 750 ticks, 65 536
-// 0.72-0.87 against 0.72; float32 rows 65 536 envs 0.65 against 0.73, 131 072 1.35 against 0.94 (profiles/r03_1d_time_parallel.txt).
-// SNAC_1D_TP=0 keeps every 1D rollout on the tile kernel (A/B timing)
+// time-parallel 1D rollouts (k_rollout1dt).  Its rate levels off at 6-7e10 env-steps/s (instruction issue), the tile kernel's keeps growing
 bool roll1dt_ok(const KArgs& a, bool f32) {
-    static const bool off = [] { const char* e = std::getenv("SNAC_1D_TP"); return e && e[0] == '0'; }();
-    static const int nmax = [] { const char* e = std::getenv("SNAC_1D_TP_MAX"); return e ? std::atoi(e) : 0; }();   // (tuning)
-    const int lim = nmax ? nmax : (f32 ? 65536 : 49152);
-    if (off || !(a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) || pipeline_off()) return false;
-    if (a.variant) {
-        // the layout variants (k_rollout1dt<.., VAR>: blocks of four envs, one per CU): whole groups of four envs and 16-byte pieces;
-        // it levels off at 1.2e10 env-steps/s with the 37-value PPO rows (the tile kernel: 8.6e9 at 65 536 envs) and at 4.4-5.1e10 with the
-        // 8-value L-Net rows (the tile kernel: 3.1e10 at 65 536 envs) (profiles/r04_1d_layouts.txt)
-        static const int vmax = [] { const char* e = std::getenv("SNAC_1D_TP_VAR_MAX"); return e ? std::atoi(e) : 65536; }();   // (tuning)
-        return (a.n & 3) == 0 && (((uintptr_t)a.obs) & 15) == 0 && a.n <= vmax;
-    }
-    return a.n <= lim;
+    if (tune(TN_1D_TP) == 0 || !every_row(a) || pipeline_off()) return false;
+    if (a.variant) return pieces16(a) && a.n <= tune(TN_1D_TP_VAR_MAX);   // k_rollout1dt<.., VAR>: blocks of four envs
+    return a.n <= (tune(TN_1D_TP_MAX) ? tune(TN_1D_TP_MAX) : tune(f32 ? TN_1D_TP_MAX_F32 : TN_1D_TP_MAX_F64));
 }
 
-// SNAC_STEP_STAGE=0 keeps snac_step on k_transition2d / k_transition3d (A/B timing, tests of both paths)
-bool step_stage_ok(const KArgs& a) {
-    static const bool off = [] { const char* e = std::getenv("SNAC_STEP_STAGE"); return e && e[0] == '0'; }();
-    return !off && !a.src_index && !a.dst_index && (a.n & 3) == 0 && ((uintptr_t)a.obs & 15) == 0;
-}
-// the layout variants on k_step2d<.., VAR>: 64 envs per wave are 64 rows of kilobytes per wave -- batches large enough to fill the
-// CUs that way; below, the 8-env tiles of k_transition spread the rows over more waves.  PPO rows (451 values), us per tick at
-// 40 960 / 49 152 / 65 536 envs: 36.7 / 36.8 / 37.7 against 35.4 / 40.8 / 88 (float32 rows at 32 768: 26.7 against 32.0); L-Net rows
-// 24 576 / 32 768 / 65 536: 8.3 / 8.8 / 9.9 against 8.5 / 10.5 / 20.2 (profiles/r04_step_layouts.txt).  SNAC_STEP_VAR_MIN=n replaces
-// the limits.
+// snac_step on identity rows: k_step2d / k_step3d (wide loads, rows through emit_tile)
+bool step_stage_ok(const KArgs& a) { return tune(TN_STEP_STAGE) != 0 && !a.src_index && !a.dst_index && pieces16(a); }
+// ... with a layout variant: 64 envs per wave are 64 rows of kilobytes per wave -- batches large enough to fill the CUs that way;
+// below, the 8-env tiles of k_transition spread the rows over more waves
 bool step_var_ok(const KArgs& a, bool f32) {
-    static const int nmin = [] { const char* e = std::getenv("SNAC_STEP_VAR_MIN"); return e ? std::atoi(e) : 0; }();   // (tuning)
-    if (nmin) return a.n >= nmin;
-    if (!(a.tail & SNAC_TAIL_PLAN)) return a.n >= 24576;
-    // rows with the plan tail: half-filled tiles for 24 577 .. 32 768 envs (one round of 1024 waves: 22.7 us at 32 768 envs against
-    // k_transition's 28.8 and the full tiles' 36.6; float32 18.2 / 23.7 / 26.7), full tiles from 45 056 (float32: above 32 768)
-    return (a.n > 24576 && a.n <= 32768) || a.n >= (f32 ? 32769 : 45056);
+    if (tune(TN_STEP_VAR_MIN)) return a.n >= tune(TN_STEP_VAR_MIN);
+    if (!(a.tail & SNAC_TAIL_PLAN)) return a.n >= tune(TN_STEP_VAR_SHORT);
+    return (a.n >= tune(TN_STEP_VAR_HALF_LO) && a.n <= tune(TN_STEP_VAR_HALF_HI)) || a.n >= tune(f32 ? TN_STEP_VAR_F32 : TN_STEP_VAR_F64);
 }
-// half-filled tiles for rows with the plan tail up to 32 768 envs (SNAC_STEP_VAR_HALF=0 / 1 forces)
 bool step_var_half(const KArgs& a) {
-    static const int force = [] { const char* e = std::getenv("SNAC_STEP_VAR_HALF"); return e ? std::atoi(e) : -1; }();   // (tuning)
-    if (force >= 0) return force != 0;
-    return (a.tail & SNAC_TAIL_PLAN) && a.n <= 32768;
+    if (tune(TN_STEP_VAR_HALF) >= 0) return tune(TN_STEP_VAR_HALF) != 0;
+    return (a.tail & SNAC_TAIL_PLAN) && a.n <= tune(TN_STEP_VAR_HALF_HI);
 }
-// 3D: k_step3d<.., VAR>.  PPO rows, us per tick at 16 384 / 65 536 envs: 37.8 / 42.8 against k_transition's 34.2 / 112.6 (float32 rows
-// at 524 288 envs: 403 against 1032) (profiles/r04_step_layouts.txt).  SNAC_STEP_VAR3_MIN=n moves the limit.
-bool step_var3_ok(const KArgs& a) {
-    static const int nmin = [] { const char* e = std::getenv("SNAC_STEP_VAR3_MIN"); return e ? std::atoi(e) : 24576; }();   // (tuning)
-    return a.n >= nmin && a.frame_val == -1;
-}
+bool step_var3_ok(const KArgs& a) { return a.n >= tune(TN_STEP_VAR3_MIN) && a.frame_val == -1; }
 
 int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -194,18 +200,8 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
         case SNAC_ENV_2D:
             if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var_ok(a, d->obs_dtype == SNAC_OBS_F32))) { g_kernel = "k_step2d"; launch_step2d(d, a, a.variant && step_var_half(a), s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { g_kernel = "k_transition2d"; launch_trans2d(d, a, s); break; }
-            // float32 rows from N = 32 768: 512 staged waves (1.05 -> 0.74 ms per 600 ticks); float64 rows there are level (1.26-1.60 ms
-            // by box for either kernel) and stay on 32-env tiles
             if (op == OP_ROLLOUT && roll2dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout2dt"; launch_roll2dt(d, a, s); break; }
-            {
-                // float64 rows from 32 769 envs (40 960: 1.56 against 1.99 ms per 600 ticks for the tile kernel's 32-env tiles, 49 152: 1.75 / 2.08,
-                // 57 344: 2.05 / 2.26; at 32 768 and below the tile kernel's 1024 waves of 32 envs are ahead: 1.25 against 1.43), float32
-                // rows from 32 768 (0.81 against 1.06); half-filled tiles -- 32 envs per wave on twice the waves -- were tried for
-                // 24 576 .. 32 768 envs and lose on trajectory memory (profiles/r04_2d_midrange.txt).  SNAC_2D_STAGE_MIN=n moves the limit.
-                static const int stage_min = [] { const char* e = std::getenv("SNAC_2D_STAGE_MIN"); return e ? std::atoi(e) : 0; }();
-                const int from = stage_min ? stage_min : (d->obs_dtype == SNAC_OBS_F32 ? 32768 : 32769);
-                if (op == OP_ROLLOUT && roll2d_ok(a, a.n >= from ? 64 : E)) { g_kernel = "k_rollout2d"; launch_roll2d(d, a, s); break; }
-            }
+            if (op == OP_ROLLOUT && roll2d_ok(a, a.n >= roll2d_from(d->obs_dtype == SNAC_OBS_F32) ? 64 : E)) { g_kernel = "k_rollout2d"; launch_roll2d(d, a, s); break; }
             launch_tile2d(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
             if (op == OP_ROLLOUT && roll3db_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout3db"; launch_roll3db(d, a, s); break; }
@@ -231,6 +227,14 @@ int snac_version(void) { return SNAC_ABI_VERSION; }
 const char* snac_last_error(void) { return g_err; }
 
 const char* snac_last_kernel(void) { return g_kernel; }
+
+int snac_tuning(char* out, int32_t cap) {
+    if (!out || cap <= 0) return fail(SNAC_ERR_ARG, "null / empty buffer");
+    int n = 0;
+    for (int i = 0; i < TN_COUNT && n < cap - 1; ++i)
+        n += std::snprintf(out + n, (size_t)(cap - n), "%s=%d  # %s%s\n", KNOBS[i].env, tune(i), tune(i) != KNOBS[i].def ? "(overridden) " : "", KNOBS[i].what);
+    return n < cap ? SNAC_OK : fail(SNAC_ERR_ARG, "buffer too small");
+}
 
 int snac_stream_sync(void* stream) {
     const hipError_t e = hipStreamSynchronize((hipStream_t)stream);

@@ -142,11 +142,11 @@ def test_time_parallel_kernel_segments_inside_a_chunk(dyn, total_step, time_gt):
         _end_state(env, orc)
 
 
-@pytest.mark.parametrize("n,f32", [(2050, False), (2051, False), (3586, False), (3587, False), (4100, True), (4102, True), (49152, False), (49168, False), (65536, True), (65552, True)])
+@pytest.mark.parametrize("n,f32", [(2050, False), (2051, False), (3586, False), (3587, False), (4100, True), (4102, True), (57344, False), (57360, False), (65536, True), (65552, True)])
 def test_staged_rows_alignments_layouts_and_the_switch_to_the_tile_kernel(n, f32):
     """Rows of a block leave as 16-byte pieces when every run of a tick starts and ends on 16 bytes (float64: even N; float32:
     N % 4 = 0) and element by element otherwise -- also when the output itself is not 16-byte aligned; tile-major outputs hold the
-    same rows at [env // 64, t, env % 64].  49 152 / 65 536 are the largest batches of the time-parallel kernel (float64 / float32
+    same rows at [env // 64, t, env % 64].  57 344 / 65 536 are the largest batches of the time-parallel kernel (float64 / float32
     rows), 16 envs more run on the tile kernel: the same rows either way."""
     import torch
 

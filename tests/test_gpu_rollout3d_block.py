@@ -1,6 +1,6 @@
 """GPU: the block-cooperative 3D rollout kernel (k_rollout3db, round 3: 64 envs per block, one stepper wave with an env per lane,
 eight writer waves that own the height maps, one barrier per tick, the stepper's reads patched for the tick they lag) against the
-CPU oracle.  The kernel takes 3D rollouts of N >= 6144 envs (float32 rows: 4096; N % 4 = 0, 16-byte aligned output) that write every observation: full
+CPU oracle.  The kernel takes 3D rollouts of N >= 4096 envs ( N % 4 = 0, 16-byte aligned output) that write every observation: full
 blocks and a ragged last block (down to one writer wave with 4 envs), float64 and float32 rows, static and dataset plans,
 [T][N][D] and tile-major outputs, launches of 1 / 2 / 37 steps, explicit actions / step sizes, the `>` rule bits, time limits of
 1 .. 3 (an env starts over every tick: the stepper then reads no map at all for it, or a map that is a tick behind), the record

@@ -1,0 +1,119 @@
+"""Re-measure the crossovers behind libsnac_hip.so's dispatch table on THIS box and print the overrides that would move them.
+
+The table (snac_amd/csrc/snac_hip.hip KNOBS, `python -c "from snac_amd import _lib; print(_lib.tuning())"`) holds the batch sizes at
+which a call switches from one kernel to another; its defaults were measured on the MI355X boxes of the build pool.  For every
+crossover below this tool times BOTH kernels at a few batch sizes round the default (one subprocess per arm: the table is read once
+per process; the arm is forced with the switch of the same table), reports the two times and where the faster kernel changes, and
+prints `export NAME=value` lines for crossovers that moved by more than one grid step.
+
+    gpurun -- python tools/retune.py [quick]          (quick: fewer batch sizes, ~2 minutes); rollouts are whole episodes (T = total_step) into the memory rollout() itself would use
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import torch
+from snac_amd import BatchedDMPEnv, _lib
+kind, n, T, f32, layout, mode = %(kind)d, %(n)d, %(T)d, %(f32)d, %(layout)r, %(mode)r
+dt = torch.float32 if f32 else torch.float64
+e = BatchedDMPEnv(kind, True, n, seed=1, obs_dtype=dt, **({"layout": layout} if layout else {}))
+e.reset()
+def timed(fn, reps):
+    for _ in range(max(3, reps // 3)): fn()
+    per = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps): fn()
+        b.record(); torch.cuda.synchronize()
+        per.append(a.elapsed_time(b) / reps)
+    return sorted(per)[2]
+if mode == "rollout":
+    T = T or e.total_step
+    obs = e._traj_out((T, n, e.obs_dim))       # where rollout() itself puts its rows: a measured trajectory block from 1 GiB on
+    rw = torch.empty((T, n), dtype=torch.float32, device="cuda"); dn = torch.empty((T, n), dtype=torch.uint8, device="cuda")
+    ms = timed(lambda: e.rollout(T, obs="all", out=obs, reward_out=rw, done_out=dn), max(3, int(40 / max(1, n * T * e.obs_dim * 8 / 6e9))))
+else:
+    out = (torch.empty((n, e.obs_dim), dtype=dt, device="cuda"), torch.empty(n, dtype=torch.float32, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda"))
+    ms = timed(lambda: e.step(auto_reset=True, out=out), 200)
+print(json.dumps({"ms": ms, "kernel": _lib.lib().snac_last_kernel().decode()}))
+'''
+
+# (name of the table entry that holds the crossover, what is compared, workload, env of arm A, env of arm B, direction, batch sizes)
+#   direction "max": kernel A is used UP TO the entry's value; "min": kernel A is used FROM the entry's value
+CROSSOVERS = [
+    ("SNAC_2D_TP_MAX_F64", "k_rollout2dt | tile kernel / k_rollout2d, 2D float64 rows", dict(kind=2, T=0, f32=0, layout=None, mode="rollout"),
+     {"SNAC_2D_TP_MAX": "10000000"}, {"SNAC_2D_TP": "0"}, "max", [12288, 14336, 16384, 18432, 20480, 24576, 28672]),
+    ("SNAC_2D_TP_MAX_F32", "k_rollout2dt | tile kernel / k_rollout2d, 2D float32 rows", dict(kind=2, T=0, f32=1, layout=None, mode="rollout"),
+     {"SNAC_2D_TP_MAX": "10000000"}, {"SNAC_2D_TP": "0"}, "max", [20480, 24576, 28672, 30720, 32768, 40960]),
+    ("SNAC_2D_STAGE_MIN_F64", "k_rollout2d | tile kernel, 2D float64 rows", dict(kind=2, T=0, f32=0, layout=None, mode="rollout"),
+     {"SNAC_2D_STAGE_MIN": "1", "SNAC_2D_TP": "0"}, {"SNAC_2D_STAGE": "0", "SNAC_2D_TP": "0"}, "min", [24576, 28672, 32768, 36864, 40960, 49152]),
+    ("SNAC_1D_TP_MAX_F64", "k_rollout1dt | tile kernel, 1D float64 rows", dict(kind=1, T=0, f32=0, layout=None, mode="rollout"),
+     {"SNAC_1D_TP_MAX": "10000000"}, {"SNAC_1D_TP": "0"}, "max", [32768, 40960, 49152, 57344, 65536, 81920]),
+    ("SNAC_3D_BLOCK_MIN_F64", "k_rollout3db | k_rollout3d, 3D float64 rows", dict(kind=3, T=0, f32=0, layout=None, mode="rollout"),
+     {"SNAC_3D_BLOCK_MIN": "0"}, {"SNAC_3D_BLOCK": "0"}, "min", [2048, 4096, 6144, 8192, 12288]),
+    ("SNAC_STEP_VAR_FULL_F64", "k_step2d<VAR> | k_transition, 2D PPO rows per tick", dict(kind=2, T=1, f32=0, layout="ppo", mode="step"),
+     {"SNAC_STEP_VAR_MIN": "1", "SNAC_STEP_VAR_HALF": "0"}, {"SNAC_STEP_VAR_MIN": "100000000"}, "min", [32768, 40960, 45056, 49152, 65536]),
+    ("SNAC_STEP_VAR3_MIN", "k_step3d<VAR> | k_transition, 3D PPO rows per tick", dict(kind=3, T=1, f32=0, layout="ppo", mode="step"),
+     {"SNAC_STEP_VAR3_MIN": "1"}, {"SNAC_STEP_VAR3_MIN": "100000000"}, "min", [8192, 16384, 24576, 32768, 65536]),
+]
+
+
+def run(work, n, env):
+    e = dict(os.environ)
+    e.update(env)
+    code = WORKER % dict(root=ROOT, n=n, **work)
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    if out.returncode:
+        raise RuntimeError(out.stderr[-800:])
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def main():
+    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    sys.path.insert(0, ROOT)
+    from snac_amd import _lib
+
+    table = _lib.tuning()
+    exports = []
+    for name, what, work, env_a, env_b, direction, sizes in CROSSOVERS:
+        if quick:
+            sizes = sizes[1:-1:2] if len(sizes) > 4 else sizes[::2]
+        cur = table[name][0]
+        print("== %s (now %d): %s" % (name, cur, what), flush=True)
+        rows = []
+        for n in sizes:
+            a, b = run(work, n, env_a), run(work, n, env_b)
+            rows.append((n, a["ms"], b["ms"]))
+            print("   N = %7d   %-14s %8.4f ms    %-14s %8.4f ms    %s" % (n, a["kernel"], a["ms"], b["kernel"], b["ms"], "A" if a["ms"] <= b["ms"] else "B"), flush=True)
+        # the crossover: direction max -> the largest N up to which A wins everywhere below; min -> the smallest N from which A wins everywhere above
+        if direction == "max":
+            good = [n for n, x, y in rows if x <= y]
+            bad = [n for n, x, y in rows if x > y]
+            new = max([n for n in good if not any(m < n for m in bad)], default=None)
+            moved = new is not None and not (new <= cur < min([m for m in bad if m > new], default=1 << 30))
+        else:
+            good = [n for n, x, y in rows if x <= y]
+            bad = [n for n, x, y in rows if x > y]
+            new = min([n for n in good if not any(m > n for m in bad)], default=None)
+            moved = new is not None and not (max([m for m in bad if m < new], default=0) < cur <= new)
+        if new is None:
+            print("   -> kernel A wins at none of these sizes on this box (entry left alone)")
+        elif moved:
+            print("   -> crossover on this box: %d (the table says %d)" % (new, cur))
+            exports.append("export %s=%d" % (name, new))
+        else:
+            print("   -> the table's value stands")
+    print("\n# overrides for this box (none: the table's defaults hold here)")
+    for ln in exports:
+        print(ln)
+
+
+if __name__ == "__main__":
+    main()
