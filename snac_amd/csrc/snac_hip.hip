@@ -71,6 +71,7 @@ struct Knob { const char* env; int def; const char* what; };
 const Knob KNOBS[TN_COUNT] = {
     /* TN_PIPELINE        */ {"SNAC_3D_PIPELINE", 1, "0: every launch on the generic tile kernels (k_rollout / k_transition / k_aux)"},
     /* TN_TILE            */ {"SNAC_TILE", 0, "envs per wave of the tile kernels (8 / 16 / 32 / 64; 0: by batch size, pick_tile)"},
+    /* TN_2D_TILE32_MIN   */ {"SNAC_2D_TILE32_MIN", 22528, "2D rollouts on the tile kernel take 32 envs per wave from (24 576 envs: 1.05 against 1.12 ms per 600 ticks with 16; 28 672: 1.06 / 1.21; 20 480: 1.05 / 0.97; r05_midrange.txt)"},
     /* TN_3D_BLOCK        */ {"SNAC_3D_BLOCK", 1, "0: 3D rollouts stay on k_rollout3d instead of the block kernel k_rollout3db"},
     /* TN_3D_BLOCK_MIN    */ {"SNAC_3D_BLOCK_MIN", -1, "k_rollout3db from this many envs (-1: the two defaults below)"},
     /* TN_3D_BLOCK_MIN_F64*/ {"SNAC_3D_BLOCK_MIN_F64", 4096, "k_rollout3db, float64 rows, from (4096 envs: 0.982 against k_rollout3d's 1.031 ms per 1000 ticks, 2048: 0.986 / 0.974; r05_retune.txt)"},
@@ -189,7 +190,8 @@ bool step_var3_ok(const KArgs& a) { return a.n >= tune(TN_STEP_VAR3_MIN) && a.fr
 int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool dyn = d->dynamic != 0;
-    const int E = pick_tile(d->kind, a.n);
+    int E = pick_tile(d->kind, a.n);
+    if (d->kind == SNAC_ENV_2D && op == OP_ROLLOUT && E == 16 && tune(TN_TILE) == 0 && a.n >= tune(TN_2D_TILE32_MIN)) E = 32;   // one wave of 32 per SIMD beats 1.5 of 16
     const char* const tile_name = op == OP_ROLLOUT ? "k_rollout" : (op == OP_TRANSITION ? "k_transition" : "k_aux");
     g_kernel = tile_name;
     switch (d->kind) {
