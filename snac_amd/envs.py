@@ -30,6 +30,48 @@ _KNOWN = {
 }
 
 
+def _make_step_size_draw():
+    """np.random.randint(1, 4) -- the draw every reference step() makes (Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:87) -- from numpy's
+    GLOBAL stream, without randint's 1.8 us of argument handling: for a range of 3 numpy takes 32-bit words of the global MT19937
+    and rejects (word & 3) == 3 (numpy/random/_bounded_integers: masked rejection), so the same words are taken here
+    straight from the global RandomState's bit generator (0.26 us).  The generator object is the one np.random.seed() re-seeds in
+    place.  Checked at import against randint itself on a scratch generator; any difference (another numpy) falls back to randint."""
+    try:
+        raw = np.random.mtrand._rand._bit_generator.random_raw
+
+        def draw():
+            while True:
+                v = raw() & 3
+                if v != 3:
+                    return 1 + v
+
+        probe = np.random.RandomState(12345)
+        want = [int(probe.randint(1, 4)) for _ in range(64)]
+        probe = np.random.RandomState(12345)
+        praw = probe._bit_generator.random_raw
+        got = []
+        while len(got) < 64:
+            v = praw() & 3
+            if v != 3:
+                got.append(1 + v)
+        if got != want or int(probe.randint(0, 400)) != _after(want):   # the same values, and the stream left where randint leaves it
+            raise RuntimeError("stream mismatch")
+        return draw
+    except Exception:
+        return lambda: int(np.random.randint(1, 4))
+
+
+def _after(want):
+    """The draw that follows 64 step-size draws on the scratch generator (the fast path must leave the stream where randint leaves it)."""
+    probe = np.random.RandomState(12345)
+    for _ in want:
+        probe.randint(1, 4)
+    return int(probe.randint(0, 400))
+
+
+_draw_step_size = _make_step_size_draw()
+
+
 def _load_dataset(dim, data_path):
     """joblib pickle as in the reference; when the file is absent but names one of the reference's 15 datasets,
     the converted copy shipped in snac_amd/data/plans.npz is used."""
@@ -103,7 +145,7 @@ class _Facade(_Base):
 
     def _do_step(self, action, step_size=None):
         if step_size is None:
-            self.step_size = int(np.random.randint(1, 4))      # drawn on EVERY step, like the reference
+            self.step_size = _draw_step_size()                 # np.random.randint(1, 4), drawn on EVERY step like the reference
         else:
             self.step_size = int(step_size)                    # hindsight variants: injected by the caller
         a = int(action)
