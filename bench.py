@@ -745,9 +745,9 @@ def main():
                                  "(the rest of a step is the bus: 2.5 us for a bare doorbell echo, tools/bar_probe.hip)"}
 
         def vector_cfg(name, nn, steps=1500):
-            """VectorizedEnvWrapper.step(actions) (multiprocess.py:15-32 on the HIP path: numpy in, numpy out, one launch + one wait per
-            vector step), host-timed, with the reference's default --num_envs 3 and a batch a trainer would use.  The reference wrapper
-            steps its N envs one after the other at ~9 us each."""
+            """VectorizedEnvWrapper.step(actions) (multiprocess.py:15-32 on the HIP path: numpy in, numpy out), host-timed, with the
+            reference's default --num_envs 3, 64 envs (the largest batch of the resident-wave path) and 256 (one launch + one wait per
+            vector step).  The reference wrapper steps its N envs one after the other at ~9 us each."""
             import numpy as np
 
             from snac_amd.vector import VectorizedEnvWrapper
@@ -766,6 +766,7 @@ def main():
             per, tm = host_timed(loop, steps)
             dt_ = per * steps
             res[name] = {"vector_steps_per_s": steps / dt_, "env_steps_per_s": steps * nn / dt_, "us_per_vector_step": 1e6 * dt_ / steps, "num_envs": nn, "timing": tm,
+                         "path": "mailbox (resident wavefront, an env per lane: snac_mailbox_step_n)" if w._mrows is not None else "launch (snac_step + wait)",
                          "reference_env_steps_per_s_one_core": 110300.0,
                          "note": "snac_amd.vector.VectorizedEnvWrapper.step(actions): host numpy in and out, no auto-reset (stepped past done like the "
                                  "reference's loop); the reference's wrapper does its N env.step() calls in turn on one core"}
@@ -832,6 +833,7 @@ def main():
         gather_cfg("replay_gather_65536", 65536, 64, 65536, 20)
         facade_cfg("facade_2d_dynamic_one_env")
         vector_cfg("vector_wrapper_3_envs", 3)
+        vector_cfg("vector_wrapper_64_envs", 64)
         vector_cfg("vector_wrapper_256_envs", 256)
         return res
 

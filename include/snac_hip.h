@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define SNAC_ABI_VERSION 9
+#define SNAC_ABI_VERSION 10
 
 typedef enum snac_status {
     SNAC_OK = 0,
@@ -391,7 +391,7 @@ int snac_export_grid(const snac_env_desc* desc, const snac_state* st, double* ou
  * The reference's scripts drive ONE env, one env.step(action) per loop turn (script/DQN/2d/DQN_2d_dynamic.py:214;
  * Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:85-147 is 9 us of Python per step).  Through snac_step_scalar such a step is one launch and
  * one stream wait (15 us).  A mailbox keeps ONE wavefront resident instead: it polls a doorbell in coherent page-locked host memory,
- * steps env 0 of an N = 1 batch with the kind's own step rules, writes the observation row (obs_dim values of obs_dtype, layout of desc,
+ * steps the envs of a small batch (N = 1: the drop-in classes; up to 64: an env per lane) with the kind's own step rules, writes the observation row (obs_dim values of obs_dtype, layout of desc,
  * tails included) into the mailbox over the bus, acknowledges, and writes the env's state through to st behind the acknowledgement
  * (snac_mailbox_settle waits for that: call it before any other entry point reads or changes st).  The wave leaves by itself after idle_us microseconds without a command
  * (0 = 1000) and on snac_mailbox_quit / _destroy; snac_mailbox_step arms (launches) one when none is resident.
@@ -407,6 +407,12 @@ int snac_mailbox_create(const snac_env_desc* desc, uint32_t idle_us, snac_mailbo
 double* snac_mailbox_row(snac_mailbox* mb);
 int snac_mailbox_touch(snac_mailbox* mb);
 int snac_mailbox_step(snac_mailbox* mb, const snac_env_desc* desc, const snac_state* st, int32_t action, int32_t step_size);
+/* the same for a batch of up to 64 envs (desc->num_envs <= 64: one wavefront, env e on lane e) -- the reference's VectorizedEnvWrapper
+ * (multiprocess.py:15-32, default --num_envs 3): actions / step_size int8[num_envs] in host memory; rows [num_envs][obs_dim] in
+ * snac_mailbox_row, rewards float[num_envs] in snac_mailbox_reward, done flags uint8[num_envs] in snac_mailbox_done */
+int snac_mailbox_step_n(snac_mailbox* mb, const snac_env_desc* desc, const snac_state* st, const int8_t* actions, const int8_t* step_size);
+float* snac_mailbox_reward(snac_mailbox* mb);
+uint8_t* snac_mailbox_done(snac_mailbox* mb);
 int snac_mailbox_settle(snac_mailbox* mb);   /* wait until st holds the last acknowledged step (the write-through trails the acknowledgement) */
 int snac_mailbox_quit(snac_mailbox* mb);
 int snac_mailbox_destroy(snac_mailbox* mb);

@@ -534,9 +534,10 @@ class BatchedDMPEnv:
 
     # ---- the resident single-env stepper (snac_mailbox_*: what the drop-in classes step through) ------------------------------
     def mailbox_open(self, idle_us=0):
-        """N = 1 only.  Creates the mailbox of this env (coherent page-locked host memory + a stream of its own) and returns its row:
-        a host tensor [1, obs_dim] of obs_dtype that mailbox_step() fills -- and that reset_scalar() / step_scalar() accept as `out`
-        (it is page-locked: the launch path writes it over the bus too).  A wavefront becomes resident at the first mailbox_step()
+        """N <= 64 (one wavefront, an env per lane; the drop-in classes: N = 1).  Creates the mailbox of this batch (coherent page-locked
+        host memory + a stream of its own) and returns its rows: a host tensor [N, obs_dim] of obs_dtype that mailbox_step() /
+        mailbox_step_n() fill -- and that reset_scalar() / step_scalar() accept as `out` (it is page-locked: the launch path writes it
+        over the bus too).  A wavefront becomes resident at the first mailbox_step()
         and leaves by itself after idle_us (0: 1000) microseconds without a step, at mailbox_close() and at interpreter exit."""
         import weakref
 
@@ -545,12 +546,16 @@ class BatchedDMPEnv:
         mb = C.c_void_p()
         _lib.check(self._lib.snac_mailbox_create(C.byref(self._desc), int(idle_us), C.byref(mb)))
         ptr = self._lib.snac_mailbox_row(mb)
-        n = self.obs_dim
+        n = self.obs_dim * self.num_envs
         if self.obs_dtype == torch.float64:
             arr = np.ctypeslib.as_array((C.c_double * n).from_address(ptr))
         else:
             arr = np.ctypeslib.as_array((C.c_float * n).from_address(ptr))
-        row = torch.from_numpy(arr.reshape(1, n))
+        row = torch.from_numpy(arr.reshape(self.num_envs, self.obs_dim))
+        N = self.num_envs
+        self._mb_reward = np.ctypeslib.as_array((C.c_float * N).from_address(self._lib.snac_mailbox_reward(mb)))
+        self._mb_done = np.ctypeslib.as_array((C.c_uint8 * N).from_address(self._lib.snac_mailbox_done(mb)))
+        self._mb_step_n = self._lib.snac_mailbox_step_n
         self._mapped[id(row)] = row                                  # page-locked and mapped: a valid `out` of the launch path
         self._mb, self._mb_row, self._mb_dirty = mb, row, True
         self._mb_step = self._lib.snac_mailbox_step
@@ -569,6 +574,24 @@ class BatchedDMPEnv:
         if rc:
             _lib.check(rc)
         self.t += 1
+
+    def mailbox_step_n(self, actions, step_size):
+        """One vector step of the batch (N <= 64) through its resident wave: actions / step_size contiguous int8 numpy arrays [N]
+        (host memory).  When this returns the rows of mailbox_open() hold the observations and mailbox_outputs() the rewards and
+        done flags; no auto-reset (the reference's wrapper has none)."""
+        if self._mb_dirty:
+            _lib.check(self._lib.snac_stream_sync(C.c_void_p(_raw_stream(self._dev_index) if _raw_stream is not None
+                                                              else torch.cuda.current_stream(self.device).cuda_stream)))
+            _lib.check(self._lib.snac_mailbox_touch(self._mb))
+            self._mb_dirty = False
+        rc = self._mb_step_n(self._mb, self._desc_ref, self._state_ref, actions.ctypes.data, step_size.ctypes.data)
+        if rc:
+            _lib.check(rc)
+        self.t += 1
+
+    def mailbox_outputs(self):
+        """(reward float32 [N], done uint8 [N]) numpy views of the mailbox, rewritten by every mailbox step."""
+        return self._mb_reward, self._mb_done
 
     def mailbox_stats(self):
         """dict(launches, steps_served, alive, idle_us, last_step_us: the wave's own timing of its last step) of this env's mailbox (None without one)."""

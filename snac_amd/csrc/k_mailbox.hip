@@ -30,6 +30,10 @@ struct snac_mailbox {
     //   bits 0-31 sequence number | 32-39 op (MB_STEP / MB_QUIT) | 40-47 action (int8) | 48-51 step size | 52-63 state generation
     uint64_t cmd;
     uint32_t pad0[14];
+    // a batch of 2 .. 64 envs (one env per lane): its actions and step sizes, written by the host BEFORE the command word (which then
+    // carries no action); the wave fetches both lines with one trip
+    int8_t actions[64];
+    int8_t steps[64];
     // ---- device -> host (its own cache line)
     uint32_t ack_seq;            // = the command's sequence number once the row below is complete
     uint32_t alive;              // 1 while a wave is resident, 0 stored as its last act
@@ -37,18 +41,21 @@ struct snac_mailbox {
     uint32_t wt_seq;             // = ack_seq once the env's records in HBM are complete too (written behind the acknowledgement)
     uint32_t dbg[4];             // ticks of the 100 MHz clock of the last step: command seen -> stepped -> row stored -> fenced (+ the write-through)
     uint32_t pad1[8];
+    float reward[64];            // per env, written with the rows
+    uint8_t done[64];
     // ---- host side bookkeeping (never read by the device)
     hipStream_t stream;
     uint32_t req_seq, state_gen; // the host's own copies of what it last posted
     int32_t armed;               // a launch has been made and not yet seen to end
     int32_t launches;
-    int32_t row_values;
+    int32_t row_values;          // values per row
     int32_t device;
     uint32_t idle_us;
-    uint32_t pad2[7];
-    double row[512];             // the observation row (obs_dim <= 459 values), written by the device
+    int32_t num_envs;
+    uint32_t pad2[6];
+    double row[512];             // the observation rows [num_envs][row_values] of obs_dtype, written by the device (the allocation extends past 512 values when they need it)
 };
-static_assert(offsetof(snac_mailbox, ack_seq) == 64 && offsetof(snac_mailbox, row) % 64 == 0, "mailbox cache lines");
+static_assert(offsetof(snac_mailbox, actions) == 64 && offsetof(snac_mailbox, ack_seq) == 192 && offsetof(snac_mailbox, row) % 64 == 0, "mailbox cache lines");
 
 namespace {
 
@@ -59,19 +66,22 @@ __device__ __forceinline__ T sys_load(const T* p) { return __hip_atomic_load(p, 
 template <typename T>
 __device__ __forceinline__ void sys_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-// One wave, env 0 of an N = 1 batch.  VAR layout always (the facades carry the record tail), OT = the batch's observation type.
-template <class K, typename OT>
+// One wave, env e of the batch on lane e (N <= K::E <= 64; the facades: N = 1).  VAR: the batch's layout is a variant (the facades carry
+// the record tail), OT = its observation type.
+template <class K, typename OT, bool VAR>
 __global__ __launch_bounds__(64) void k_mailbox(const KArgs a, snac_mailbox* mb, long long idle_ticks) {
     const int lane = threadIdx.x & 63;
+    const int nenv = a.n;
+    const bool active = lane < nenv;
     uint32_t* lds = wave_lds<K, 1>();
     Lane s;
     int episode = 0;
     auto load_state = [&]() {
         s.clear();
         s.r = 3; s.c = 3;
-        if (lane == 0) { s.unpack(a.hdr[0]); episode = a.episode[0]; }
-        K::load_grid(lds, a, 0, 1, lane);
-        K::load_plan(lds, a, 0, __builtin_amdgcn_readlane(s.pidx, 0), lane);
+        if (active) { s.unpack(a.hdr[lane]); episode = a.episode[lane]; }
+        K::load_grid(lds, a, 0, nenv, lane);
+        for (int e = 0; e < nenv; ++e) K::load_plan(lds, a, e, __builtin_amdgcn_readlane(s.pidx, e), lane);
     };
     uint32_t seen = sys_load(&mb->ack_seq);                          // the host sets ack = req before it arms: nothing pending is lost
     uint32_t gen = 0xFFFFFFFFu, served = sys_load(&mb->steps_served);
@@ -82,8 +92,7 @@ __global__ __launch_bounds__(64) void k_mailbox(const KArgs a, snac_mailbox* mb,
         const uint64_t cmd = sys_load(&mb->cmd);
         if (wt_pending) {
             // the write-through of the step before: its stores were issued behind that step's acknowledgement and have had this poll's
-            // trip over the bus to complete -- fenced and reported here, they cost the next step nothing (fenced right behind the
-            // acknowledgement they kept the wave from polling for 2 us: 5.2 instead of 3.6 us per step)
+            // trip over the bus to complete -- fenced and reported here, they cost the next step nothing
             const long long w0 = wall_clock64();
             __threadfence_system();
             if (lane == 0) {
@@ -101,8 +110,13 @@ __global__ __launch_bounds__(64) void k_mailbox(const KArgs a, snac_mailbox* mb,
         }
         const int op = (int)((cmd >> 32) & 0xffu);
         if (op == MB_QUIT) { seen = req; break; }
-        const int act = (int)(int8_t)((cmd >> 40) & 0xffu);
-        const int k = min(max((int)((cmd >> 48) & 0xfu), 1), 3);
+        int act = (int)(int8_t)((cmd >> 40) & 0xffu);
+        int k = (int)((cmd >> 48) & 0xfu);
+        if (nenv > 1) {                                              // a batch: every lane its own action and step size (one more trip)
+            act = (int)sys_load(&mb->actions[active ? lane : 0]);
+            k = (int)sys_load(&mb->steps[active ? lane : 0]);
+        }
+        k = min(max(k, 1), 3);
         const uint32_t g = (uint32_t)(cmd >> 52);
         if (g != gen) {                                              // first command of this wave, or the records were changed under it
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");             // (system scope: nothing stale from this CU's caches)
@@ -112,28 +126,29 @@ __global__ __launch_bounds__(64) void k_mailbox(const KArgs a, snac_mailbox* mb,
         int reward = 0;
         bool done = false;
         const long long c0 = wall_clock64();
-        if (lane == 0) {
+        if (active) {
             K::step(lds, a, s, act, k, a.ts_done, a.brick_gt, lane, reward, done);
             s.ep_ret = clamp16(s.ep_ret + reward);
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
         }
         const long long c1 = wall_clock64();
-        emit_obs<K, OT, true, K::A != 8>(lds, (OT*)mb->row, 1, s, a, lane, StepOut{reward, done ? 1 : 0});
+        emit_obs<K, OT, VAR, VAR && K::A != 8>(lds, (OT*)mb->row, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
+        if (active) { mb->reward[lane] = (float)reward; mb->done[lane] = done ? 1 : 0; }
         const long long c2 = wall_clock64();
-        __threadfence_system();                                      // the row has left before the acknowledgement does
+        __threadfence_system();                                      // the rows have left before the acknowledgement does
         const long long c3 = wall_clock64();
         if (lane == 0) __hip_atomic_store(&mb->ack_seq, req, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         // ---- behind the acknowledgement, off the host's critical path: the episodic sums and the write-through of the records
-        if (__any(done)) {                                           // snac_step's episodic sums (the plan is in LDS; 3D: the running sum)
-            const double v = K::iou(lds, s, 0);
+        if (__any(done)) {                                           // snac_step's episodic sums (the plans are in LDS; 3D: the running sum)
+            const double v = K::iou(lds, s, active ? lane : 0);
             if (done) {
-                a.stat_episodes[0] += 1;
-                a.stat_return[0] += s.ep_ret;
-                a.stat_iou_fx[0] += __double2ll_rn(v * FX40);
+                a.stat_episodes[lane] += 1;
+                a.stat_return[lane] += s.ep_ret;
+                a.stat_iou_fx[lane] += __double2ll_rn(v * FX40);
             }
         }
-        K::store_grid(lds, a, 0, 1, lane);
-        if (lane == 0) { a.hdr[0] = s.pack(); a.episode[0] = episode; }
+        K::store_grid(lds, a, 0, nenv, lane);
+        if (active) { a.hdr[lane] = s.pack(); a.episode[lane] = episode; }
         served += 1u;
         if (lane == 0) { sys_store(&mb->dbg[0], (uint32_t)(c1 - c0)); sys_store(&mb->dbg[1], (uint32_t)(c2 - c1)); sys_store(&mb->dbg[2], (uint32_t)(c3 - c2)); }
         seen = req;
@@ -150,11 +165,18 @@ __global__ __launch_bounds__(64) void k_mailbox(const KArgs a, snac_mailbox* mb,
     }
 }
 
+template <class K>
+void launch_mb_k(const snac_env_desc* d, const KArgs& a, snac_mailbox* mb, long long ticks) {
+    const bool f32 = d->obs_dtype == SNAC_OBS_F32;
+    const dim3 g(1), b(64);
+    if (a.variant) { if (f32) hipLaunchKernelGGL((k_mailbox<K, float, true>), g, b, 0, mb->stream, a, mb, ticks); else hipLaunchKernelGGL((k_mailbox<K, double, true>), g, b, 0, mb->stream, a, mb, ticks); }
+    else { if (f32) hipLaunchKernelGGL((k_mailbox<K, float, false>), g, b, 0, mb->stream, a, mb, ticks); else hipLaunchKernelGGL((k_mailbox<K, double, false>), g, b, 0, mb->stream, a, mb, ticks); }
+}
 template <template <bool, int> class KT>
 void launch_mb(const snac_env_desc* d, const KArgs& a, snac_mailbox* mb, long long ticks) {
-    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
-    if (dyn) { if (f32) hipLaunchKernelGGL((k_mailbox<KT<true, 8>, float>), dim3(1), dim3(64), 0, mb->stream, a, mb, ticks); else hipLaunchKernelGGL((k_mailbox<KT<true, 8>, double>), dim3(1), dim3(64), 0, mb->stream, a, mb, ticks); }
-    else { if (f32) hipLaunchKernelGGL((k_mailbox<KT<false, 8>, float>), dim3(1), dim3(64), 0, mb->stream, a, mb, ticks); else hipLaunchKernelGGL((k_mailbox<KT<false, 8>, double>), dim3(1), dim3(64), 0, mb->stream, a, mb, ticks); }
+    // the facades' single env keeps the 8-env LDS image (a 64-env 3D image is 87 KB to set up); batches take the 64-env one
+    if (a.n <= 8) { if (d->dynamic) launch_mb_k<KT<true, 8>>(d, a, mb, ticks); else launch_mb_k<KT<false, 8>>(d, a, mb, ticks); }
+    else { if (d->dynamic) launch_mb_k<KT<true, 64>>(d, a, mb, ticks); else launch_mb_k<KT<false, 64>>(d, a, mb, ticks); }
 }
 
 inline uint32_t host_load(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
@@ -178,7 +200,7 @@ int arm(snac_mailbox* mb, const snac_env_desc* d, const snac_state* st) {
         mb->armed = 0;
     }
     KArgs a = make_args(d, st);
-    a.pool = 1; a.stats_on = 1; a.T = 1; a.obs_mode = SNAC_OBS_ALL;
+    a.pool = d->num_envs; a.stats_on = 1; a.T = 1; a.obs_mode = SNAC_OBS_ALL;
     __atomic_store_n(&mb->alive, 1u, __ATOMIC_RELEASE);             // (the wave clears it as its last act)
     const long long ticks = (long long)mb->idle_us * 100;           // wall_clock64(): the constant 100 MHz counter
     if (d->kind == SNAC_ENV_1D) launch_mb<K1D>(d, a, mb, ticks);
@@ -199,16 +221,19 @@ extern "C" {
 int snac_mailbox_create(const snac_env_desc* d, uint32_t idle_us, snac_mailbox** out) {
     using namespace snac_detail;
     if (!d || !out) return fail(SNAC_ERR_ARG, "null desc / out");
-    if (d->num_envs != 1) return fail(SNAC_ERR_UNSUPPORTED, "the mailbox steps a batch of ONE env");
+    if (d->num_envs < 1 || d->num_envs > 64) return fail(SNAC_ERR_UNSUPPORTED, "the mailbox steps a batch of 1 .. 64 envs (one wavefront, an env per lane)");
+    if (d->kind < SNAC_ENV_1D || d->kind > SNAC_ENV_3D) return fail(SNAC_ERR_ARG, "unknown env kind");
     if (int rc = check_layout(d)) return rc;
     const int ld = base_obs_dim(d->kind) + tail_len(d->kind, d->obs_tail);
-    if (ld > 512) return fail(SNAC_ERR_UNSUPPORTED, "observation row too long for the mailbox");
+    const size_t row_bytes = (size_t)d->num_envs * (size_t)ld * sizeof(double);
+    const size_t total = sizeof(snac_mailbox) + (row_bytes > sizeof(((snac_mailbox*)nullptr)->row) ? row_bytes - sizeof(((snac_mailbox*)nullptr)->row) : 0);
     snac_mailbox* mb = nullptr;
     // coherent (fine-grained) page-locked memory, mapped: device stores and host stores are visible to the other side while the
     // wave runs -- what the doorbell and the acknowledgement need (plain pinned memory is only guaranteed at kernel boundaries)
-    hipError_t e = hipHostMalloc((void**)&mb, sizeof(snac_mailbox), hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable);
+    hipError_t e = hipHostMalloc((void**)&mb, total, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable);
     if (e != hipSuccess) return fail_hip(e, "hipHostMalloc(mailbox)");
-    std::memset(mb, 0, sizeof(*mb));
+    std::memset(mb, 0, total);
+    mb->num_envs = d->num_envs;
     e = hipStreamCreateWithFlags(&mb->stream, hipStreamNonBlocking);  // its own queue: a resident wave must not sit in front of anyone's work
     if (e != hipSuccess) { (void)hipHostFree(mb); return fail_hip(e, "hipStreamCreate(mailbox)"); }
     mb->row_values = ld;
@@ -219,6 +244,8 @@ int snac_mailbox_create(const snac_env_desc* d, uint32_t idle_us, snac_mailbox**
 }
 
 double* snac_mailbox_row(snac_mailbox* mb) { return mb ? mb->row : nullptr; }
+float* snac_mailbox_reward(snac_mailbox* mb) { return mb ? mb->reward : nullptr; }
+uint8_t* snac_mailbox_done(snac_mailbox* mb) { return mb ? mb->done : nullptr; }
 
 int snac_mailbox_touch(snac_mailbox* mb) {
     if (!mb) return snac_detail::fail(SNAC_ERR_ARG, "null mailbox");
@@ -226,17 +253,12 @@ int snac_mailbox_touch(snac_mailbox* mb) {
     return SNAC_OK;
 }
 
-// One step of env 0: posts (action, step_size), arms the wave if none is resident, spins until the row is acknowledged.
-// Returns SNAC_OK with the row in snac_mailbox_row(); SNAC_ERR_HIP if no acknowledgement arrives within ~2 s (the caller falls
-// back to snac_step_scalar: the state in HBM is as the last acknowledged step left it).
-int snac_mailbox_step(snac_mailbox* mb, const snac_env_desc* d, const snac_state* st, int32_t action, int32_t step_size) {
+static int await_ack(snac_mailbox* mb, const snac_env_desc* d, const snac_state* st) {
     using namespace snac_detail;
-    if (!mb) return fail(SNAC_ERR_ARG, "null mailbox");
-    const int lim = d->kind == SNAC_ENV_1D ? 3 : (d->kind == SNAC_ENV_2D ? 5 : 8);
-    post(mb, MB_STEP, (action >= 0 && action < lim) ? action : -1, step_size < 1 ? 1 : (step_size > 3 ? 3 : step_size));   // (every invalid action steps alike)
     const uint32_t req = mb->req_seq;
     if (!host_load(&mb->alive)) {
         if (int rc = check_common(d, st)) return rc;
+        if (d->num_envs != mb->num_envs) return fail(SNAC_ERR_ARG, "mailbox of another batch size");
         if (int rc = arm(mb, d, st)) return rc;
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -250,6 +272,30 @@ int snac_mailbox_step(snac_mailbox* mb, const snac_env_desc* d, const snac_state
         if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
             return fail(SNAC_ERR_HIP, "mailbox: no acknowledgement within 2 s");
     }
+}
+
+// One step of a ONE-env batch: posts (action, step_size), arms the wave if none is resident, spins until the row is acknowledged.
+// Returns SNAC_OK with the row in snac_mailbox_row(); SNAC_ERR_HIP if no acknowledgement arrives within ~2 s (the state in HBM is as
+// the last acknowledged step left it).
+int snac_mailbox_step(snac_mailbox* mb, const snac_env_desc* d, const snac_state* st, int32_t action, int32_t step_size) {
+    using namespace snac_detail;
+    if (!mb) return fail(SNAC_ERR_ARG, "null mailbox");
+    if (mb->num_envs != 1) return fail(SNAC_ERR_ARG, "snac_mailbox_step is for a batch of one env (snac_mailbox_step_n)");
+    const int lim = d->kind == SNAC_ENV_1D ? 3 : (d->kind == SNAC_ENV_2D ? 5 : 8);
+    post(mb, MB_STEP, (action >= 0 && action < lim) ? action : -1, step_size < 1 ? 1 : (step_size > 3 ? 3 : step_size));   // (every invalid action steps alike)
+    return await_ack(mb, d, st);
+}
+
+// One vector step of a batch of 1 .. 64 envs: actions / step_size int8[num_envs] (host memory) are copied into the mailbox, the wave
+// steps env e on lane e and writes rows [num_envs][obs_dim], reward float[num_envs] and done uint8[num_envs] back
+// (snac_mailbox_row / _reward / _done).
+int snac_mailbox_step_n(snac_mailbox* mb, const snac_env_desc* d, const snac_state* st, const int8_t* actions, const int8_t* step_size) {
+    using namespace snac_detail;
+    if (!mb || !actions || !step_size) return fail(SNAC_ERR_ARG, "null mailbox / actions / step_size");
+    std::memcpy(mb->actions, actions, (size_t)mb->num_envs);
+    std::memcpy(mb->steps, step_size, (size_t)mb->num_envs);
+    post(mb, MB_STEP, actions[0], step_size[0] < 1 ? 1 : (step_size[0] > 3 ? 3 : step_size[0]));
+    return await_ack(mb, d, st);
 }
 
 // Waits until the records in HBM hold the last acknowledged step (the wave writes them through BEHIND its acknowledgement): what an

@@ -138,3 +138,42 @@ def test_the_drop_in_class_steps_through_the_mailbox_and_beats_the_reference_rat
     assert not e1._mbox
     o, r, d = e1.step(1)                                         # usable after close(): the launch path
     assert o[0].shape == (1, 51)
+
+
+@pytest.mark.parametrize("dim,dyn,n", [(1, True, 3), (2, True, 64), (2, False, 9), (3, True, 24), (3, False, 64)])
+def test_batches_of_up_to_64_envs_step_through_one_wave(dim, dyn, n):
+    """snac_mailbox_step_n: env e on lane e of the resident wave.  300 vector steps with random actions / step sizes and a masked reset
+    every 50 steps (the launch path, under the resident wave): rows, rewards and done flags equal those of snac_step on a twin batch
+    and of the oracle; the records in HBM and the episodic sums agree afterwards."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(dim, dyn, {1: "sin_train", 2: "dense_train", 3: "dense_train"}[dim] if dyn else "p0")
+    full = table.reshape(len(table), 30) if dim == 1 else table.reshape(len(table), 26, 26)
+    a = BatchedDMPEnv(dim, dyn, n, plans=full, seed=11)
+    b = BatchedDMPEnv(dim, dyn, n, plans=full, seed=11)
+    orc = helpers.oracle().OracleBatch(dim, dyn, n, table, seed=11)
+    rows = a.mailbox_open(idle_us=500).numpy()
+    rew, don = a.mailbox_outputs()
+    rng = np.random.default_rng(2)
+    pidx = rng.integers(0, len(table), size=n).astype(np.int32)
+    o0 = orc.reset(plan_idx=pidx)
+    assert a.reset(plan_idx=pidx).cpu().numpy().tobytes() == o0.tobytes() and b.reset(plan_idx=pidx).cpu().numpy().tobytes() == o0.tobytes()
+    A = a.num_actions
+    for t in range(300):
+        if t and t % 50 == 0:                                    # some envs start over, through another entry point
+            mask = (rng.random(n) < 0.5).astype(np.uint8)
+            pidx = rng.integers(0, len(table), size=n).astype(np.int32)
+            oa, ob = a.reset(mask, pidx), b.reset(mask, pidx)
+            assert torch.equal(oa, ob) and oa.cpu().numpy().tobytes() == orc.reset(mask, pidx).tobytes()
+        act = rng.integers(0, A, size=n).astype(np.int8)
+        k = rng.integers(1, 4, size=n).astype(np.int8)
+        a.mailbox_step_n(act, k)
+        ob, rb, db = b.step(torch.from_numpy(act), torch.from_numpy(k))
+        oc, rc, dc = orc.step(t, act, k)
+        assert rows.tobytes() == ob.cpu().numpy().tobytes() == oc.tobytes(), t
+        assert rew.tobytes() == rb.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(don, dc), t
+    a.sync()
+    assert torch.equal(a._hdr, b._hdr) and torch.equal(a._grid, b._grid) and torch.equal(a._stats, b._stats) and torch.equal(a._episode, b._episode)
+    assert a.mailbox_stats()["steps_served"] == 300
+    a.mailbox_close()

@@ -70,5 +70,30 @@ def main():
             print("2D  drop-in class step(), SNAC_MAILBOX=%s  %6.2f us  (min %.2f max %.2f)" % ((flag,) + med(cls, steps)))
 
 
+def wrapper_times():
+    """VectorizedEnvWrapper.step (numpy in, numpy out): the mailbox path (<= 64 envs) against the launch path."""
+    from snac_amd.vector import VectorizedEnvWrapper
+
+    table = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "snac_amd", "data", "plans.npz"))["2d_dense_train"]
+    for nn in (3, 16, 64):
+        for flag in ("1", "0"):
+            os.environ["SNAC_MAILBOX"] = flag
+            w = VectorizedEnvWrapper((2, True, table), num_envs=nn)
+            np.random.seed(1)
+            w.reset()
+            acts = np.random.RandomState(0).randint(0, 5, (2100, nn))
+
+            def loop(k):
+                for i in range(k):
+                    w.step(acts[i])
+
+            loop(100)
+            m = med(loop, 2000)
+            print("2D  VectorizedEnvWrapper.step, %2d envs, SNAC_MAILBOX=%s  %6.2f us per vector step  = %.3e env-steps/s" % (nn, flag, m[0], nn / m[0] * 1e6))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "wrapper":
+        wrapper_times()
+        sys.exit(0)
     main()
