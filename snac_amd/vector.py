@@ -16,6 +16,7 @@ BatchedDMPEnv for callers that want device tensors, the counter RNG or fused rol
 import numpy as np
 
 from .batched import BatchedDMPEnv
+from .envs import _draw_step_size
 
 
 class VectorizedEnvWrapper:
@@ -88,11 +89,20 @@ class VectorizedEnvWrapper:
 
     def step(self, actions):
         actions = np.asarray(actions)
-        if actions.shape != (self.num_envs,):
-            raise ValueError("actions must have shape (%d,)" % self.num_envs)
-        if actions.min() < 0 or actions.max() >= self.action_dim:
-            raise ValueError("action outside [0, %d)" % self.action_dim)
-        self._k_np[:] = np.random.randint(1, 4, size=self.num_envs)
+        n = self.num_envs
+        if actions.shape != (n,):
+            raise ValueError("actions must have shape (%d,)" % n)
+        if n <= 8:                                               # a handful of envs: python scalars are cheaper than numpy calls
+            al = actions.tolist()
+            if min(al) < 0 or max(al) >= self.action_dim:
+                raise ValueError("action outside [0, %d)" % self.action_dim)
+            k = self._k_np
+            for i in range(n):                                   # np.random.randint(1, 4, size=n): the same words of the global stream, in element order
+                k[i] = _draw_step_size()
+        else:
+            if actions.min() < 0 or actions.max() >= self.action_dim:
+                raise ValueError("action outside [0, %d)" % self.action_dim)
+            self._k_np[:] = np.random.randint(1, 4, size=n)
         self._a_np[:] = actions
         b = self.batched
         if self._mrows is not None:                              # doorbell + acknowledgement of the batch's resident wave
