@@ -411,36 +411,59 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    sync()
-    t0 = time.perf_counter()
-    pending = []
-    for i in range(args.steps):
-        ev[i][0].record()
-        env.rollout(T, obs="all", out=obs)
-        ev[i][1].record()
-        s = env.stats_tensor(out=stats) if not use_dist else env.stats_tensor()   # no group: the sums land where they are kept
-        if not use_dist:
-            continue
-        if backend == "nccl":
-            # the pass's one exchange (24 bytes, RCCL): enqueued behind the rollout on RCCL's stream, it overlaps the next
-            # pass instead of holding it up; every pass still performs it and all are complete before the clock stops
-            try:
-                pending.append((dist.all_reduce(s, op=dist.ReduceOp.SUM, async_op=True), s))
-            except Exception:                                   # keep the measurement alive: fall back to the blocking form
+    def timed_region():
+        """EXACTLY K passes between a barrier + synchronize on either side; returns (wall seconds, MAX over ranks; per-pass kernel ms of this rank)."""
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        sync()
+        t0 = time.perf_counter()
+        pending = []
+        for i in range(args.steps):
+            ev[i][0].record()
+            env.rollout(T, obs="all", out=obs)
+            ev[i][1].record()
+            s = env.stats_tensor(out=stats) if not use_dist else env.stats_tensor()   # no group: the sums land where they are kept
+            if not use_dist:
+                continue
+            if backend == "nccl":
+                # the pass's one exchange (24 bytes, RCCL): enqueued behind the rollout on RCCL's stream, it overlaps the next
+                # pass instead of holding it up; every pass still performs it and all are complete before the clock stops
+                try:
+                    pending.append((dist.all_reduce(s, op=dist.ReduceOp.SUM, async_op=True), s))
+                except Exception:                               # keep the measurement alive: fall back to the blocking form
+                    stats.copy_(allreduce_(s))
+            else:
                 stats.copy_(allreduce_(s))
-        else:
-            stats.copy_(allreduce_(s))
-    for work, s in pending:
-        work.wait()
-    if pending:
-        stats.copy_(pending[-1][1])
-    sync()
-    dt = time.perf_counter() - t0
-    dt = float(allreduce_(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
+        for work, s in pending:
+            work.wait()
+        if pending:
+            stats.copy_(pending[-1][1])
+        sync()
+        dt_ = time.perf_counter() - t0
+        dt_ = float(allreduce_(torch.tensor([dt_], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
+        return dt_, [a.elapsed_time(b) for a, b in ev], len(pending)
+
+    # The boxes of this pool stall for tens of milliseconds now and then (a group of bench extras: 362 instead of 8.6 us per launch, twice
+    # in this round's runs; round 4's driver run: 396 instead of 38) -- as long as the whole timed region of the headline.  A timed region
+    # that shows such a stall (its slowest pass > 2 x its median pass, or its wall time > 1.3 x the sum of its kernels + 1 ms per pass) is
+    # timed ONCE more, by every rank together, and the second region is the one reported; both are in `timed_regions`, `retimed` says so.
+    # SNAC_BENCH_RETIME=0 switches that off.
+    def stalled(dt_, ms_):
+        srt = sorted(ms_)
+        med = srt[len(srt) // 2]
+        wall = (not use_dist or backend == "nccl") and dt_ * 1e3 > 1.3 * sum(ms_) + 1.0 * len(ms_)   # (gloo: the exchange itself takes milliseconds of host time)
+        return bool(srt[-1] > 2.0 * med or wall)
+
+    dt, per_step_ms, n_async = timed_region()
+    timed_regions = [{"ms_per_step": dt / args.steps * 1e3, "kernel_ms_per_step": [round(x, 4) for x in per_step_ms], "stalled": stalled(dt, per_step_ms)}]
+    retimed = False
+    if os.environ.get("SNAC_BENCH_RETIME", "1") != "0":
+        flag = float(allreduce_(torch.tensor([1.0 if timed_regions[0]["stalled"] else 0.0], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
+        if flag > 0:
+            dt, per_step_ms, n_async = timed_region()
+            timed_regions.append({"ms_per_step": dt / args.steps * 1e3, "kernel_ms_per_step": [round(x, 4) for x in per_step_ms], "stalled": stalled(dt, per_step_ms)})
+            retimed = True
     # a group of one: what came back from the collective must be this rank's own sums
     collective_check = bool(torch.equal(stats, env.stats_tensor())) if (use_dist and world == 1) else None
-    per_step_ms = [a.elapsed_time(b) for a, b in ev]
     kern_ms = sum(per_step_ms) / max(args.steps, 1)
     # every rank's own kernel time (events on its launch stream), and the proof of how many ranks the collective saw
     per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
@@ -909,7 +932,9 @@ def main():
             "backend": backend if use_dist else None,
             "rccl_ranks": ranks_seen if (use_dist and backend == "nccl") else None,
             "collective_check": collective_check,                 # SNAC_BENCH_FORCE_DIST=1 at one rank: reduced sums == local sums
-            "rccl_async_exchanges": len(pending) if use_dist else None,   # per-pass all_reduce(async_op=True) calls that completed
+            "rccl_async_exchanges": n_async if use_dist else None,   # per-pass all_reduce(async_op=True) calls that completed
+            "retimed": retimed,                                   # the first timed region showed a stall of the box and the region was timed once more
+            "timed_regions": timed_regions,                       # every timed region of this run (one, or two when retimed), rank 0's kernels
             "ranks": ranks_seen,
             "kernel_ms_per_rank": per_rank,
             "ranks_devices": ranks_devices,                       # every rank's cuda:<local> PCI bus id: N ranks on N distinct GPUs
