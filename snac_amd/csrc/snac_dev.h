@@ -718,42 +718,6 @@ __device__ __forceinline__ void emit_tile(char* stg, char* g, int lane, int nenv
     }
 }
 
-// emit_tile_small: the same through a staging tile of TILE_STG_SMALL = 6 528 bytes, in twice as many parts (float64: 4 parts of 16 envs,
-// float32: 2 of 32) -- for kernels whose occupancy the LDS and the registers bound (k_step2d / k_step3d: 26 KB per block of four waves =
-// six blocks per CU instead of three).  The parts are walked by a loop that is NOT unrolled, and cell(el, salt) receives an opaque zero
-// (an SGPR the compiler cannot see through) to fold into the value's source: unrolled -- or with cells the compiler can prove equal from
-// part to part -- it converts all 49 cells once in front of the parts and keeps 98 registers of float64 values alive across them (138-140
-// VGPRs = 3 waves per SIMD, whatever the LDS allows).  Reads past a part's end are clamped instead of padded.
-constexpr int TILE_STG_SMALL = 16 * 51 * 8;
-
-template <typename OT, class F>
-__device__ __forceinline__ void emit_tile_small(char* stg, char* g, int lane, int nenv, F cell, double v0, double v1) {
-    constexpr int D = 51, W = 49, E = 64;
-    constexpr int PARTS = sizeof(OT) == 8 ? 4 : 2, HE = E / PARTS;
-    constexpr int STG_BYTES = HE * D * (int)sizeof(OT);              // 6 528 B either way
-    constexpr int NF = (STG_BYTES + 1023) / 1024;
-    static_assert(STG_BYTES <= TILE_STG_SMALL && STG_BYTES % 16 == 0, "staging tile");
-#pragma unroll 1
-    for (int h = 0; h < PARTS; ++h) {
-        int salt;
-        asm volatile("s_mov_b32 %0, 0" : "=s"(salt));
-        if ((lane / HE) == h) {                                      // transpose: lane -> row (lane - h * HE) of the staging tile
-            OT* const S = (OT*)stg + (lane - h * HE) * D;
-#pragma unroll
-            for (int el = 0; el < W; ++el) S[el] = (OT)cell(el, salt);
-            S[W] = (OT)v0; S[W + 1] = (OT)v1;
-        }
-        uint4 fv[NF];
-#pragma unroll
-        for (int i = 0; i < NF; ++i) fv[i] = *(const uint4*)(stg + min(i * 1024 + lane * 16, STG_BYTES - 16));
-        char* const gh = g + (size_t)h * STG_BYTES + lane * 16;
-        const int valid = min(max(nenv - h * HE, 0), HE) * D * (int)sizeof(OT);
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-            if (i * 1024 + lane * 16 < valid) *(uint4*)(gh + i * 1024) = fv[i];
-    }
-}
-
 // The same for the layout variants of snac_env_desc (rows of LD = 51 + tail values: 451 for the script/PPO dataset copies, 59 with the
 // record tail, ...).  A tile's rows of one step are still ONE contiguous run of 64 * LD values, 16-byte aligned as a whole (the callers
 // require N % 4 == 0), so it is staged and flushed in GROUPS of G envs -- the largest power of two whose rows fit the staging tile (a

@@ -177,3 +177,37 @@ def test_batches_of_up_to_64_envs_step_through_one_wave(dim, dyn, n):
     assert torch.equal(a._hdr, b._hdr) and torch.equal(a._grid, b._grid) and torch.equal(a._stats, b._stats) and torch.equal(a._episode, b._episode)
     assert a.mailbox_stats()["steps_served"] == 300
     a.mailbox_close()
+
+
+def test_a_script_that_never_closes_its_env_exits_cleanly():
+    """A reference-style script steps its env and simply ends (no close()): the interpreter's exit tells the resident wave to leave
+    (weakref.finalize -> snac_mailbox_destroy) and the process ends at once, with status 0; killed outright (SIGKILL, nothing runs at
+    exit) the wave is gone with the process's queues -- a second process can use the GPU straight away."""
+    import signal
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, time
+sys.path.insert(0, %r)
+import numpy as np
+from snac_amd.envs import deep_mobile_printing_2d1r_dynamic
+e = deep_mobile_printing_2d1r_dynamic("data_2d_dynamic_dense_envplan_500_train.pkl")
+np.random.seed(1); e.reset()
+for i in range(500):
+    if e.step(i %% 5)[2]: e.reset()
+assert e._mbox and e._env.mailbox_stats()["alive"]
+print("STEPPED", flush=True)
+if len(sys.argv) > 1:
+    time.sleep(60)
+''' % helpers.ROOT
+    t0 = time.perf_counter()
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "STEPPED" in out.stdout, out.stderr[-1500:]
+    assert time.perf_counter() - t0 < 60
+    p = subprocess.Popen([sys.executable, "-c", code, "hang"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert "STEPPED" in p.stdout.readline()
+    p.send_signal(signal.SIGKILL)                                # the exact child started here
+    p.wait(timeout=30)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "STEPPED" in out.stdout, out.stderr[-1500:]
