@@ -1,8 +1,8 @@
 """Randomised parity fuzz on the GPU box (not part of the test suite): random env kind, batch size (small, and around the
 dispatch thresholds of the specialised kernels), time limit, rule bits, observation dtype and seed; then a random sequence of
 operations -- fused rollouts (counter RNG or explicit inputs), per-tick step() with and without auto-reset, step_scalar, waves of
-tree-search edges (gathered / scattered and in place), masked resets -- each compared with the CPU oracle bit for bit, the
-full state at the end.  Prints one line per trial; stops at the first difference.
+tree-search edges (gathered / scattered and in place), masked resets, and for batches of up to 64 envs steps through the
+resident wavefront (the mailbox) -- each compared with the CPU oracle bit for bit, the full state at the end.  Prints one line per trial; stops at the first difference.
 
     gpurun -- python tools/fuzz.py [trials] [seed]
 """
@@ -74,7 +74,7 @@ def trial(rng, idx):
     t = 0
     ops = []
     for _ in range(int(rng.integers(2, 7))):
-        op = str(rng.choice(["rollout", "rollout", "rollout_x", "steps", "steps_x", "scalar", "edges", "reset"]))
+        op = str(rng.choice(["rollout", "rollout", "rollout_x", "steps", "steps_x", "scalar", "edges", "reset"] + (["mailbox", "mailbox"] if n <= 64 else [])))
         ops.append(op)
         ctx["ops"] = ops
         if op in ("rollout", "rollout_x"):
@@ -135,6 +135,28 @@ def trial(rng, idx):
                 same(o.cpu().numpy(), cast(oo), "edge obs", ctx)
                 same(r.cpu().numpy(), ro, "edge reward", ctx)
                 same(d.cpu().numpy().view(np.uint8), do, "edge done", ctx)
+        elif op == "mailbox":
+            # the resident wavefront (snac_mailbox_step / _step_n: an env per lane), in between whatever else the trial does to the batch;
+            # short idle times so that waves also leave and come back inside a trial
+            rows = env.mailbox_open(idle_us=int(rng.choice([30, 200, 2000]))).numpy()
+            rew, don = env.mailbox_outputs()
+            for _ in range(int(rng.integers(1, 40))):
+                a = rng.integers(0, A, size=n).astype(np.int8)
+                k = rng.integers(1, 4, size=n).astype(np.int8)
+                if n == 1 and rng.random() < 0.5:
+                    env.mailbox_step(int(a[0]), int(k[0]))
+                    single = True
+                else:
+                    env.mailbox_step_n(a, k)
+                    single = False
+                oc, rc, dc = orc.step(t, a, k, auto_reset=False, nthreads=16)
+                same(rows.copy(), cast(oc), "mailbox rows", ctx)
+                if not (single and "record" in lay.get("obs_tail", ())):      # (a single env with the record tail has them in its row)
+                    same(rew.copy(), rc, "mailbox reward", ctx)
+                    same(don.copy(), dc, "mailbox done", ctx)
+                t += 1
+                if rng.random() < 0.1:
+                    time.sleep(0.001)                                 # long enough for a 30 / 200 us wave to leave
         elif op == "reset":
             mask = (rng.random(n) < 0.4).astype(np.uint8)
             pidx = rng.integers(0, len(table), n).astype(np.int16)
