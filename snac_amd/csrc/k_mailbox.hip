@@ -27,7 +27,7 @@
 struct snac_mailbox {
     // ---- host -> device (one cache line, written by the host only).  The whole command is ONE 8-byte word, stored atomically: every
     // word the wave would have to fetch separately is one more round trip over the bus (a first version with four words: 10.4 us per step)
-    //   bits 0-31 sequence number | 32-39 op (MB_STEP / MB_QUIT) | 40-47 action (int8) | 48-51 step size | 52-63 state generation
+    //   bits 0-31 sequence number | 32-39 op (MB_STEP / MB_STEP_N / MB_QUIT) | 40-47 action (int8) | 48-51 step size | 52-63 state generation
     uint64_t cmd;
     uint32_t pad0[14];
     // a batch of 2 .. 64 envs (one env per lane): its actions and step sizes, written by the host BEFORE the command word (which then
@@ -59,7 +59,7 @@ static_assert(offsetof(snac_mailbox, actions) == 64 && offsetof(snac_mailbox, ac
 
 namespace {
 
-enum { MB_STEP = 1, MB_QUIT = 3 };
+enum { MB_STEP = 1, MB_STEP_N = 2, MB_QUIT = 3 };   // MB_STEP_N: snac_mailbox_step_n -- reward / done always go to their own arrays too
 
 template <typename T>
 __device__ __forceinline__ T sys_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64) void k_mailbox(const KArgs a, snac_mailbox* mb,
         const long long c1 = wall_clock64();
         emit_obs<K, OT, VAR, VAR && K::A != 8>(lds, (OT*)mb->row, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
         // (a single env whose row carries the record tail -- the drop-in classes -- has reward and done in the row: two stores over the bus less)
-        if (active && (nenv > 1 || !(VAR && (a.tail & SNAC_TAIL_RECORD)))) { mb->reward[lane] = (float)reward; mb->done[lane] = done ? 1 : 0; }
+        if (active && (op == MB_STEP_N || !(VAR && (a.tail & SNAC_TAIL_RECORD)))) { mb->reward[lane] = (float)reward; mb->done[lane] = done ? 1 : 0; }
         const long long c2 = wall_clock64();
         __threadfence_system();                                      // the rows have left before the acknowledgement does
         const long long c3 = wall_clock64();
@@ -295,7 +295,7 @@ int snac_mailbox_step_n(snac_mailbox* mb, const snac_env_desc* d, const snac_sta
     if (!mb || !actions || !step_size) return fail(SNAC_ERR_ARG, "null mailbox / actions / step_size");
     std::memcpy(mb->actions, actions, (size_t)mb->num_envs);
     std::memcpy(mb->steps, step_size, (size_t)mb->num_envs);
-    post(mb, MB_STEP, actions[0], step_size[0] < 1 ? 1 : (step_size[0] > 3 ? 3 : step_size[0]));
+    post(mb, MB_STEP_N, actions[0], step_size[0] < 1 ? 1 : (step_size[0] > 3 ? 3 : step_size[0]));
     return await_ack(mb, d, st);
 }
 
