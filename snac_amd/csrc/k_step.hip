@@ -388,6 +388,178 @@ __global__ __launch_bounds__(WPB * 64) void k_step3d(const KArgs a) {
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// k_step3ds (round 5): the canonical 3D step() with COOPERATIVE SPAN LOADS.  k_step3d reads the window as seven 16-byte loads per LANE,
+// every lane in another line (448 scattered requests per wave), and again for every env that moved: what the step pays for is the number
+// of those requests, not their bytes (profiles/r05_step_experiments.txt parts 1-3 and 5: more resident waves do not help, a byte plane buys
+// 9 %, coalesced span loads 37 % in a timing build).  Here the rows a tick can need -- the 7 rows of the window plus the 3 a row move can
+// reach, TEN whole rows = 400 contiguous bytes of the env's record -- are read by 26 neighbouring lanes, 16 bytes each (piece P = it * 64 +
+// lane of the wave's 64 x 26 pieces belongs to env P / 26): coalesced runs, no reload after a move, the action is known before the load
+// and picks the side the extra rows lie on.  The pieces wait in registers; the wave's LDS (the staging tile: 13 312 bytes = 32 spans of
+// 416 bytes exactly) takes them HALF a wave at a time -- iterations 0 .. 12 are envs 0 .. 31, 13 .. 25 envs 32 .. 63 --, and the lanes of
+// that half do their whole tick on it: the six cells of the transition, K3D::step by selects (k_step3d's formulation), the state stores,
+// the 49 window cells round the NEW position (rows and columns outside the map are the frame by their coordinates: no pads, no
+// bounds to trust).  The rows then leave through emit_tile as in k_step3d.  Canonical layout, identity rows, N % 4 = 0, aligned obs.
+template <bool DYN, typename OT, int WPB>
+__global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_step3ds(const KArgs a) {   // three waves per SIMD: what the LDS allows (<= 168 VGPRs)
+    using K = K3D<DYN, 8>;
+    constexpr int E = 64, GE = K::GE, NPC = 26, SPAN = NPC * 16;     // pieces and bytes per env
+    static_assert(32 * SPAN == TILE_STG_BYTES && (E * NPC) % 64 == 0 && (32 * NPC) % 64 == 0, "half a wave's spans fill the staging tile; halves split on whole iterations");
+    __shared__ __attribute__((aligned(16))) char lds_all[WPB * TILE_STG_BYTES];
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const int env0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * WPB + wv) * E);
+    if (env0 >= a.n) return;
+    const int nenv = min(E, a.n - env0);
+    const bool active = lane < nenv;
+    const int env = env0 + (active ? lane : 0);
+    char* const scr = lds_all + wv * TILE_STG_BYTES;
+    Lane s;
+    s.clear();
+    s.r = 3; s.c = 3;
+    int episode = 0;
+    if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
+    const uint64_t gid = (uint64_t)(a.env_id_base + env);
+    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+    if (a.actions && active) act = (int)a.actions[env];
+    if (a.step_size && active) k = (int)a.step_size[env];
+    k = min(max(k, 1), 3);
+    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+    if (nr) {
+        const int old_pidx = s.pidx, old_tb = s.tb;
+        episode += 1;
+        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    }
+    const int d = act & 3;
+    const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
+    const int tr = s.r + dr - 3, tc = s.c + dc - 3;                  // the build target in plan (interior) coordinates
+    const bool inside = (unsigned)tr < 20u && (unsigned)tc < 20u;
+    const int tcell = inside ? tr * 20 + tc : 0;
+    const int pl = ((const int16_t*)a.plans)[(size_t)s.pidx * GE + tcell];
+    // ---- the span: interior rows rlo .. rlo + 9.  The window round (r, c) is rows r - 6 .. r; a move "down" (act 3: row - m) can bring
+    // rows down to r - 9 into the window, a move "up" rows up to r + 3
+    const int rlo = min(max(s.r - 6 - ((act == 3) ? 3 : 0), 0), 10);
+    const int boff = rlo * 40, ab = boff & ~15, mis = boff & 15;      // byte offset of the first row in the record, aligned down; 40 q mod 16 = 0 | 8
+    // ... of which THIS tick can touch rows r - 6 - (3 if the action moves down) .. r + (3 if it moves up), inside the map: pieces outside
+    // that range are not fetched (three quarters of the envs need 7 of the 10 rows)
+    const int qlo = min(max(s.r - 6 - ((act == 3) ? 3 : 0), 0), 19), qhi = min(max(s.r + ((act == 2) ? 3 : 0), 0), 19);
+    const int need_lo = qlo * 40 - ab, need_hi = qhi * 40 + 40 - ab;  // byte range inside the (aligned) span
+    uint4 pc[NPC];
+    {
+        // what the lanes that fetch this env's pieces need to know, in one word: span start (10 bits), the needed byte range inside
+        // it (10 + 10 bits), and whether the env reads at all (a freshly reset env is empty)
+        const int word = ab | (need_lo << 10) | (need_hi << 20) | ((nr || !active) ? (1 << 30) : 0);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int it = 0; it < NPC; ++it) {
+            const int P = it * 64 + lane, e = P / NPC, part = P - NPC * e;
+            const int we = __builtin_amdgcn_ds_bpermute(e << 2, word);
+            const int abe = we & 1023, nle = (we >> 10) & 1023, nhe = (we >> 20) & 1023, sk = we >> 30;
+            const int off = abe + part * 16;
+            pc[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (!sk && off + 16 <= GE * 2 && part * 16 + 16 > nle && part * 16 < nhe) {                         // nontemporal: streamed once per tick (k_step3d's measurement)
+                const u32x4 t = __builtin_nontemporal_load((const u32x4*)((const char*)a.grid + (size_t)(env0 + e) * (GE * 2) + off));
+                pc[it] = make_uint4(t.x, t.y, t.z, t.w);
+            }
+        }
+    }
+    // ---- half a wave at a time: the pieces of envs 32 h .. 32 h + 31 into LDS, then the whole tick of those lanes
+    const char* const mine = scr + (lane & 31) * SPAN + mis - boff;  // + q * 40 + col * 2: the cell (q, col) of this lane's env, q in [rlo, rlo + 10)
+    auto cell_at = [&](int q, int col) -> int {                      // interior coordinates; outside the map: the frame
+        const bool in = (unsigned)q < 20u && (unsigned)col < 20u;
+        const int qq = min(max(q, rlo), rlo + 9), cc = min(max(col, 0), 19);
+        const int v = nr ? 0 : (int)*(const int16_t*)(mine + qq * 40 + cc * 2);
+        return in ? v : -1;
+    };
+    int reward = 0, newh = 0;
+    bool done = false, built = false;
+    int cellv[K::W];
+#pragma unroll
+    for (int el = 0; el < K::W; ++el) cellv[el] = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int it = 0; it < NPC / 2; ++it) ((uint4*)scr)[it * 64 + lane] = pc[h * (NPC / 2) + it];
+        if ((lane >> 5) == h) {
+            const int qa = s.r - 3, ca = s.c - 3;                    // the agent's cell, interior coordinates
+            // ---- K3D::step by selects (the formulation of k_step3d / k_transition3d / Roll3D::tick)
+            const int n0 = cell_at(qa, ca - 1), n1 = cell_at(qa, ca + 1), n2 = cell_at(qa + 1, ca), n3 = cell_at(qa - 1, ca);   // check_sur: left, right, "up" (row + 1), "down"
+            const int c2 = cell_at(qa + 2 * dr, ca + 2 * dc), c3 = cell_at(qa + 3 * dr, ca + 3 * dc);
+            const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
+            const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
+            const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
+            s.cs = min(s.cs + 1, CNT_MAX);
+            const bool can_move = valid && act < 4 && nd == 0;
+            const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;
+            s.r += can_move ? dr * m : 0;
+            s.c += can_move ? dc * m : 0;
+            built = active && is_build && nd != -1;
+            newh = min(nd + 1, CNT_MAX);
+            s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
+            s.cross += (built && newh <= pl) ? 1 : 0;
+            const bool limit = s.cb >= s.tb + a.brick_gt;
+            done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);
+            const int rcheck = newh > pl ? -1 : (newh == pl ? 10 : 1);
+            if (DYN) {
+                const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
+                const bool fin = is_build && (boxed_post || limit);
+                reward = is_build ? (boxed_post ? -100 : ((!limit && built) ? rcheck : 0)) : 0;
+                done = fin ? true : ((is_build && built) ? false : done);
+            } else {
+                const bool fin = is_build && (limit || boxed_pre);
+                reward = (is_build && !fin && built) ? rcheck : 0;
+                done = fin ? true : ((is_build && built) ? false : done);
+            }
+            done = done && active;
+            s.ep_ret = clamp16(s.ep_ret + reward);
+            s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+            if (active) {
+                if (a.reward) a.reward[env] = (float)reward;
+                if (a.done) a.done[env] = done ? 1 : 0;
+                a.hdr[env] = s.pack();
+                if (nr) a.episode[env] = episode;
+                if (built && !nr) ((int16_t*)a.grid)[(size_t)env * GE + tcell] = (int16_t)newh;
+                if (a.stats_on && done) {                            // snac_step: episodic sums
+                    const double v = K::iou(nullptr, s, 0);
+                    stat_add(a.stat_episodes + env, 1);
+                    stat_add(a.stat_return + env, s.ep_ret);
+                    stat_add(a.stat_iou_fx + env, __double2ll_rn(v * FX40));
+                }
+            }
+            if (a.obs) {                                             // the window round the NEW position; the built cell shows (a build does not move)
+                const int q0 = s.r - 6, cl = s.c - 6;
+#pragma unroll
+                for (int el = 0; el < K::W; ++el) {
+                    const int i = el / 7, j = el - 7 * i;
+                    const int v = cell_at(q0 + i, cl + j);
+                    cellv[el] = (built && q0 + i == tr && cl + j == tc) ? newh : v;
+                }
+            }
+        }
+    }
+    for (unsigned long long mk = __ballot(nr); mk; mk &= mk - 1) {   // a reset env's record: empty, but for the cell it built
+        const int e = __ffsll(mk) - 1;
+        const int tp = __builtin_amdgcn_readlane(built ? tcell : -1, e), nh = __builtin_amdgcn_readlane(newh, e);
+        if (lane < 50) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (tp >= 0 && (tp >> 3) == lane) {
+                const int hw = tp & 7;
+                const uint32_t put = ((uint32_t)nh & 0xFFFFu) << ((hw & 1) * 16);
+                if ((hw >> 1) == 0) v.x = put; else if ((hw >> 1) == 1) v.y = put; else if ((hw >> 1) == 2) v.z = put; else v.w = put;
+            }
+            ((uint4*)a.grid)[(size_t)(env0 + e) * 50 + lane] = v;
+        }
+    }
+    if (!a.obs) return;
+    const double c0 = (double)s.cb, c1 = (double)s.cs;
+    const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
+    emit_tile<OT>(scr, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv, [&](int el) { return cellv[el]; }, v0, v1);
+}
+
 }  // namespace
 
 namespace snac_detail {
@@ -416,6 +588,9 @@ void launch_step3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     if (a.variant) {
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step3d<true, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<true, double, 4, true>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step3d<false, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<false, double, 4, true>), grid, block, 0, s, a); }
+    } else if (tune(TN_STEP3D_SPAN) != 0 && a.n >= tune(TN_STEP3D_SPAN_MIN)) {   // the canonical rows of large batches: cooperative span loads (k_step3ds)
+        if (dyn) { if (f32) hipLaunchKernelGGL((k_step3ds<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3ds<true, double, 4>), grid, block, 0, s, a); }
+        else { if (f32) hipLaunchKernelGGL((k_step3ds<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3ds<false, double, 4>), grid, block, 0, s, a); }
     } else {
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step3d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<true, double, 4>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step3d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<false, double, 4>), grid, block, 0, s, a); }

@@ -106,6 +106,8 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_STEP_VAR_F32    */ {"SNAC_STEP_VAR_FULL_F32", 32769, "the same, float32 rows (32 768 envs: 26.7 against 32.0 us)"},
     /* TN_STEP_VAR_HALF   */ {"SNAC_STEP_VAR_HALF", -1, "0 / 1: never / always half-filled tiles for rows with the plan tail (-1: the range above)"},
     /* TN_STEP_VAR3_MIN   */ {"SNAC_STEP_VAR3_MIN", 24576, "3D steps with a layout variant on k_step3d<VAR> from (65 536 envs: 42.8 against 112.6 us)"},
+    /* TN_STEP3D_SPAN     */ {"SNAC_STEP3D_SPAN", 1, "0: the canonical 3D snac_step stays on k_step3d (seven row loads per lane) instead of k_step3ds (cooperative span loads)"},
+    /* TN_STEP3D_SPAN_MIN */ {"SNAC_STEP3D_SPAN_MIN", 81920, "k_step3ds from this many envs (98 304: 21.0 against k_step3d's 25.1 us per tick, 262 144: 41.7 / 53.3, 524 288: 78.6 / 95.4-101; 65 536: 15.9 / 14.1; r05_step_experiments.txt part 6)"},
     /* TN_T2D_E           */ {"SNAC_T2D_E", 0, "edges per wave of k_transition2d (16 / 32 / 64; 0: 32 from 65 536 edges, else 16)"},
     /* TN_EDGES3D         */ {"SNAC_EDGES3D", 1, "0: 3D tree edges with gathered rows stay on k_transition3d instead of k_edges3d"},
 };
