@@ -396,7 +396,7 @@ __global__ __launch_bounds__(WPB * 64) void k_step3d(const KArgs a) {
 // 9 %, coalesced span loads 37 % in a timing build).  Here the rows a tick can need -- the 7 rows of the window plus the 3 a row move can
 // reach, TEN whole rows = 400 contiguous bytes of the env's record -- are read by 26 neighbouring lanes, 16 bytes each (piece P = it * 64 +
 // lane of the wave's 64 x 26 pieces belongs to env P / 26): coalesced runs, no reload after a move, the action is known before the load
-// and picks the side the extra rows lie on.  The pieces wait in registers; the wave's LDS (the staging tile: 13 312 bytes = 32 spans of
+// and picks the side the extra rows lie on; pieces none of whose cells the tick can touch (rows AND columns) are not fetched.  The pieces wait in registers; the wave's LDS (the staging tile: 13 312 bytes = 32 spans of
 // 416 bytes exactly) takes them HALF a wave at a time -- iterations 0 .. 12 are envs 0 .. 31, 13 .. 25 envs 32 .. 63 --, and the lanes of
 // that half do their whole tick on it: the six cells of the transition, K3D::step by selects (k_step3d's formulation), the state stores,
 // the 49 window cells round the NEW position (rows and columns outside the map are the frame by their coordinates: no pads, no
@@ -447,21 +447,26 @@ __global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(3, 3))
     // ... of which THIS tick can touch rows r - 6 - (3 if the action moves down) .. r + (3 if it moves up), inside the map: pieces outside
     // that range are not fetched (three quarters of the envs need 7 of the 10 rows)
     const int qlo = min(max(s.r - 6 - ((act == 3) ? 3 : 0), 0), 19), qhi = min(max(s.r + ((act == 2) ? 3 : 0), 0), 19);
-    const int need_lo = qlo * 40 - ab, need_hi = qhi * 40 + 40 - ab;  // byte range inside the (aligned) span
+    // ... and columns c - 6 - (3 if it moves left) .. c + (3 if it moves right): a piece (8 cells, possibly the end of one row and the start
+    // of the next) none of whose cells lies in that rectangle is not fetched either (a row is 2.5 pieces, the rectangle's part of it 1-2)
+    const int clo = min(max(s.c - 6 - ((act == 0) ? 3 : 0), 0), 19), chi = min(max(s.c + ((act == 1) ? 3 : 0), 0), 19);
     uint4 pc[NPC];
     {
         // what the lanes that fetch this env's pieces need to know, in one word: span start (10 bits), the needed byte range inside
         // it (10 + 10 bits), and whether the env reads at all (a freshly reset env is empty)
-        const int word = ab | (need_lo << 10) | (need_hi << 20) | ((nr || !active) ? (1 << 30) : 0);
+        const int word = (ab >> 4) | (clo << 5) | (chi << 10) | (qlo << 15) | (qhi << 20) | ((nr || !active) ? (1 << 30) : 0);
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int it = 0; it < NPC; ++it) {
             const int P = it * 64 + lane, e = P / NPC, part = P - NPC * e;
             const int we = __builtin_amdgcn_ds_bpermute(e << 2, word);
-            const int abe = we & 1023, nle = (we >> 10) & 1023, nhe = (we >> 20) & 1023, sk = we >> 30;
+            const int abe = (we & 31) << 4, cl = (we >> 5) & 31, ch = (we >> 10) & 31, ql = (we >> 15) & 31, qh = (we >> 20) & 31, sk = we >> 30;
             const int off = abe + part * 16;
+            // the piece's 8 cells f .. f + 7 lie in row q1 from column f - 20 q1 on and, if they cross a row end, in row q1 + 1 from column 0
+            const int f = off >> 1, q1 = f / 20, c1 = f - 20 * q1, e1 = min(c1 + 7, 19), e2 = c1 + 7 - 20;   // e2 >= 0: the last column of the part in row q1 + 1
+            const bool hit = (q1 >= ql && q1 <= qh && c1 <= ch && e1 >= cl) || (e2 >= 0 && q1 + 1 >= ql && q1 + 1 <= qh && cl <= e2);
             pc[it] = make_uint4(0u, 0u, 0u, 0u);
-            if (!sk && off + 16 <= GE * 2 && part * 16 + 16 > nle && part * 16 < nhe) {                         // nontemporal: streamed once per tick (k_step3d's measurement)
+            if (!sk && off + 16 <= GE * 2 && hit) {                         // nontemporal: streamed once per tick (k_step3d's measurement)
                 const u32x4 t = __builtin_nontemporal_load((const u32x4*)((const char*)a.grid + (size_t)(env0 + e) * (GE * 2) + off));
                 pc[it] = make_uint4(t.x, t.y, t.z, t.w);
             }
