@@ -586,14 +586,14 @@ void launch_step2d(const snac_env_desc* d, const KArgs& a, bool half, hipStream_
     }
 }
 
-void launch_step3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
+void launch_step3d(const snac_env_desc* d, const KArgs& a, bool span, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
     const int tiles = (a.n + 63) / 64;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
     if (a.variant) {
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step3d<true, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<true, double, 4, true>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step3d<false, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3d<false, double, 4, true>), grid, block, 0, s, a); }
-    } else if (tune(TN_STEP3D_SPAN) != 0 && a.n >= tune(TN_STEP3D_SPAN_MIN)) {   // the canonical rows of large batches: cooperative span loads (k_step3ds)
+    } else if (span) {                                              // the canonical rows of large batches: cooperative span loads (k_step3ds)
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step3ds<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3ds<true, double, 4>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step3ds<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step3ds<false, double, 4>), grid, block, 0, s, a); }
     } else {

@@ -114,7 +114,7 @@ void launch_roll1dt(const snac_env_desc* d, const KArgs& a, hipStream_t s);     
 void launch_roll3d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                     // k_roll3d.hip
 void launch_roll3db(const snac_env_desc* d, const KArgs& a, hipStream_t s);                    // k_roll3db.hip
 void launch_step2d(const snac_env_desc* d, const KArgs& a, bool half, hipStream_t s);          // k_step.hip
-void launch_step3d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                     // k_step.hip
+void launch_step3d(const snac_env_desc* d, const KArgs& a, bool span, hipStream_t s);          // k_step.hip (span: k_step3ds)
 void launch_trans2d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                    // k_trans.hip
 void launch_trans3d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                    // k_trans.hip (k_edges3d for gathered rows)
 }  // namespace snac_detail

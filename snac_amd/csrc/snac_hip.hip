@@ -210,7 +210,12 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
             if (op == OP_ROLLOUT && roll3db_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout3db"; launch_roll3db(d, a, s); break; }
             if (op == OP_ROLLOUT && E == 8 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && !pipeline_off()) { g_kernel = "k_rollout3d"; launch_roll3d(d, a, s); break; }
-            if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var3_ok(a))) { g_kernel = "k_step3d"; launch_step3d(d, a, s); break; }
+            if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var3_ok(a))) {
+                const bool span = !a.variant && tune(TN_STEP3D_SPAN) != 0 && a.n >= tune(TN_STEP3D_SPAN_MIN);   // large batches of canonical rows
+                g_kernel = span ? "k_step3ds" : "k_step3d";
+                launch_step3d(d, a, span, s);
+                break;
+            }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { g_kernel = "k_transition3d"; launch_trans3d(d, a, s); break; }
             launch_tile3d(op, dyn, E, d->obs_dtype, a, s);
             break;
