@@ -480,6 +480,125 @@ void launch_trans2d_e(const KArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((k_transition2d<DYN, OT, 4, 16>), grid, block, 0, s, a);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_edges2d (round 5): 2D tree edges with gathered rows, the records through LDS.  k_transition2d reads an edge's source record with eight
+// 4-byte loads per LANE (the agent's row word + the seven window rows, every lane in another record) and then once more for the copy to the
+// destination row -- and what a step pays for is the number of scattered lane requests (k_step3ds, profiles/r05_step_experiments.txt).
+// Here a wave takes 64 edges; every source record (80 bytes = five 16-byte pieces) is fetched ONCE by five neighbouring lanes (piece g of the
+// wave's 320 belongs to edge g / 5), lies in LDS ([edge][20] row words) for the transition and the window, and leaves for its destination
+// row the same way; the rows go out through emit_tile.  Semantics are k_transition2d's (K2D::step on the agent's row word).  m % 4 = 0 and a
+// 16-byte aligned obs; the canonical layout.
+template <bool DYN, typename OT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_edges2d(const KArgs a) {
+    using K = K2D<DYN, 64>;
+    constexpr int E = 64, GE = K::GE;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * (TILE_STG_BYTES / 4)];
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const int edge0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * WPB + wv) * E);
+    if (edge0 >= a.n) return;
+    const int nedge = min(E, a.n - edge0);
+    const bool active = lane < nedge;
+    const int edge = edge0 + (active ? lane : 0);
+    uint32_t* const rec = lds_all + wv * (TILE_STG_BYTES / 4);
+    const int srow = (int)row_of(a.src_index, a.pool, edge), drow = (int)row_of(a.dst_index, a.pool, edge);
+    // ---- the source records: five 16-byte pieces per edge, fetched by neighbouring lanes (plain loads: children share their parents)
+    uint4 rv[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int g = i * 64 + lane, e = g / 5, part = g - 5 * e;
+        const int se = __builtin_amdgcn_ds_bpermute(e << 2, srow);
+        rv[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (g < nedge * 5) rv[i] = ((const uint4*)a.grid)[(size_t)se * 5 + part];
+    }
+    Lane s;
+    s.unpack(a.hdr[srow]);
+    int episode = a.episode[srow];
+    const uint64_t gid = (uint64_t)(a.env_id_base + edge);
+    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+    if (a.actions) act = (int)a.actions[edge];
+    if (a.step_size) k = (int)a.step_size[edge];
+    k = min(max(k, 1), 3);
+    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+    if (nr) {
+        const int old_pidx = s.pidx, old_tb = s.tb;
+        episode += 1;
+        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    }
+    const uint32_t* const prow = (const uint32_t*)a.plans + (size_t)s.pidx * GE;
+    const int q0 = min(max(s.r - 3, 0), GE - 1), bit = min(max(s.c - 3, 0), 19);
+    const uint32_t pword = prow[q0];                                 // the one dependent load: the plan row under the agent (L2)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) ((uint4*)rec)[i * 64 + lane] = rv[i];
+    uint32_t* const mine = rec + lane * GE;
+    if (nr) {                                                        // a freshly reset board is empty
+#pragma unroll
+        for (int q = 0; q < GE; ++q) mine[q] = 0u;
+    }
+    // ---- K2D::step (DMP_Env_2D_dynamic_usedata_plan.py:85-147) on the agent's row word
+    const uint32_t row0 = mine[q0];
+    const bool was = ((row0 >> bit) & 1u) != 0u, planned = ((pword >> bit) & 1u) != 0u;
+    const bool drop = active && act == 4;
+    const uint32_t newrow = row0 | (1u << bit);                      // += 1 then clamp to 1 (:115, :134-135)
+    s.cs = min(s.cs + 1, CNT_MAX);
+    if (drop) { s.cb = min(s.cb + 1, CNT_MAX); mine[q0] = newrow; }
+    if (act == 0) s.c = max(s.c - k, 3);                             // clip_position :74-83
+    if (act == 1) s.c = min(s.c + k, 22);
+    if (act == 2) s.r = min(s.r + k, 22);                            // "up" is row + k (:100-103)
+    if (act == 3) s.r = max(s.r - k, 3);
+    const bool term = drop && s.cb >= s.tb + a.brick_gt;             // :117-126, tested before the time limit
+    const bool done = active && (term || s.cs >= a.ts_done);
+    const int reward = (drop && !term && !was && planned) ? 5 : 0;   // un-clamped cell vs plan (:129-133)
+    s.ep_ret = clamp16(s.ep_ret + reward);
+    s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    if (active) {
+        if (a.reward) a.reward[edge] = (float)reward;
+        if (a.done) a.done[edge] = done ? 1 : 0;
+        a.hdr[drow] = s.pack();
+        a.episode[drow] = episode;
+    }
+    if (a.stats_on && __builtin_expect(__any(done), 0)) {            // (snac_step with gathered rows does not exist; kept for completeness)
+        if (done) {
+            int inter = 0, uni = 0;
+            for (int q = 0; q < GE; ++q) { const uint32_t g = mine[q], p = prow[q]; inter += __popc(g & p); uni += __popc(g | p); }
+            const double v = (double)inter / (double)uni;
+            stat_add(a.stat_episodes + drow, 1);
+            stat_add(a.stat_return + drow, s.ep_ret);
+            stat_add(a.stat_iou_fx + drow, __double2ll_rn(v * FX40));
+        }
+    }
+    // ---- the (updated) records leave for their destination rows, five neighbouring lanes per record
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int g = i * 64 + lane, e = g / 5, part = g - 5 * e;
+        const int de = __builtin_amdgcn_ds_bpermute(e << 2, drow);
+        if (g < nedge * 5) ((uint4*)a.grid)[(size_t)de * 5 + part] = ((const uint4*)rec)[g];
+    }
+    if (!a.obs) return;
+    // ---- the 7x7 window round the new position as two-bit codes (00 empty / 01 brick / 11 frame), 14 bits per row
+    uint32_t wr[7];
+    {
+        const int sh = s.c - 3;                                      // first window column, bordered: 0..19
+        constexpr uint32_t FRAME26 = 0x3800007u;                     // frame columns 0-2 and 23-25 of an interior row
+        const uint32_t frm = spread16((FRAME26 >> sh) & 0x7Fu) * 3u;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int q = s.r - 6 + i;                               // board row of window row i
+            const bool in = (unsigned)q < (unsigned)GE;
+            const uint32_t g = mine[in ? q : 0];
+            wr[i] = in ? (spread16(((g << 3) >> sh) & 0x7Fu) | frm) : 0x3FFFu;
+        }
+    }
+    const double c0 = (double)s.cb, c1 = (double)s.cs;
+    const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
+    emit_tile<OT>((char*)rec, (char*)a.obs + (size_t)edge0 * K::D * sizeof(OT), lane, nedge,
+                  [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; }, v0, v1);
+}
+
 }  // namespace
 
 namespace snac_detail {
@@ -509,6 +628,15 @@ void launch_trans3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
 
 void launch_trans2d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
+    // gathered / scattered rows (tree edges): the records through LDS, every memory instruction wide (k_edges2d); SNAC_EDGES2D=0 keeps
+    // them on k_transition2d (A/B timing, tests of both paths), SNAC_EDGES2D_MIN=n moves the wave size from which it takes them
+    if ((a.src_index || a.dst_index) && tune(TN_EDGES2D) != 0 && a.n >= tune(TN_EDGES2D_MIN) && a.obs && (a.n & 3) == 0 && ((uintptr_t)a.obs & 15) == 0) {
+        g_kernel = "k_edges2d";
+        const dim3 grid((unsigned)(((a.n + 63) / 64 + 3) / 4)), block(256);
+        if (dyn) { if (f32) hipLaunchKernelGGL((k_edges2d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_edges2d<true, double, 4>), grid, block, 0, s, a); }
+        else { if (f32) hipLaunchKernelGGL((k_edges2d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_edges2d<false, double, 4>), grid, block, 0, s, a); }
+        return;
+    }
     if (dyn) f32 ? launch_trans2d_e<true, float>(a, s) : launch_trans2d_e<true, double>(a, s);
     else f32 ? launch_trans2d_e<false, float>(a, s) : launch_trans2d_e<false, double>(a, s);
 }

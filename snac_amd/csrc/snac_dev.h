@@ -35,6 +35,8 @@
 
 #include "snac_common.h"
 
+#include "snac_tune.h"   // the ids of the dispatch table's entries (kept out of this header: adding a knob does not touch the kernels' source)
+
 namespace snac_detail {
 struct KArgs {
     int32_t n, num_plans, static_plan, T, auto_reset, obs_mode;
@@ -87,14 +89,6 @@ enum Op { OP_ROLLOUT, OP_AUX, OP_TRANSITION };
 
 // which kernel the calling thread's last launch went to (snac_last_kernel())
 extern thread_local const char* g_kernel;
-
-// ---- the dispatch table (snac_hip.hip: KNOBS): ids of its entries, tune(id) = the effective value (default or environment override)
-enum Tn { TN_PIPELINE, TN_TILE, TN_2D_TILE32_MIN, TN_3D_BLOCK, TN_3D_BLOCK_MIN, TN_3D_BLOCK_MIN_F64, TN_3D_BLOCK_MIN_F32, TN_2D_STAGE, TN_2D_STAGE_MIN, TN_2D_STAGE_MIN_F64,
-          TN_2D_STAGE_MIN_F32, TN_2D_TP, TN_2D_TP_MAX, TN_2D_TP_MAX_F64, TN_2D_TP_GAP_LO, TN_2D_TP_GAP_HI, TN_2D_TP_MAX_F32, TN_2D_TP_MAX_ODD, TN_2D_TP_VAR_MAX,
-          TN_2D_TP_VAR_PLAN, TN_2D_TP_VAR_SHORT, TN_2D_TP_EB8, TN_1D_TP, TN_1D_TP_MAX, TN_1D_TP_MAX_F64, TN_1D_TP_MAX_F32, TN_1D_TP_VAR_MAX, TN_1D_TP_EB16,
-          TN_STEP_STAGE, TN_STEP_VAR_MIN, TN_STEP_VAR_SHORT, TN_STEP_VAR_HALF_LO, TN_STEP_VAR_HALF_HI, TN_STEP_VAR_F64, TN_STEP_VAR_F32, TN_STEP_VAR_HALF,
-          TN_STEP_VAR3_MIN, TN_STEP3D_SPAN, TN_STEP3D_SPAN_MIN, TN_T2D_E, TN_EDGES3D, TN_COUNT };
-int tune(int id);
 
 // ---- host side, defined in snac_hip.hip
 int check_layout(const snac_env_desc* d);

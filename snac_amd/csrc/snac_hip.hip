@@ -110,6 +110,8 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_STEP3D_SPAN_MIN */ {"SNAC_STEP3D_SPAN_MIN", 81920, "k_step3ds from this many envs (98 304: 21.0 against k_step3d's 25.1 us per tick, 262 144: 41.7 / 53.3, 524 288: 78.6 / 95.4-101; 65 536: 15.9 / 14.1; r05_step_experiments.txt part 6)"},
     /* TN_T2D_E           */ {"SNAC_T2D_E", 0, "edges per wave of k_transition2d (16 / 32 / 64; 0: 32 from 65 536 edges, else 16)"},
     /* TN_EDGES3D         */ {"SNAC_EDGES3D", 1, "0: 3D tree edges with gathered rows stay on k_transition3d instead of k_edges3d"},
+    /* TN_EDGES2D         */ {"SNAC_EDGES2D", 1, "0: 2D tree edges with gathered rows stay on k_transition2d instead of k_edges2d (records through LDS)"},
+    /* TN_EDGES2D_MIN     */ {"SNAC_EDGES2D_MIN", 4, "k_edges2d from this many edges per call"},
 };
 
 int tune(int id) {

@@ -375,12 +375,14 @@ def test_default_policy_evaluation_matches_the_reference_loop(dim, dyn):
 @pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
 @pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
 def test_large_waves_of_2d_edges(dyn, f32):
-    """A wave of 65 536 + 36 edges on a pool of 2^18 rows (the 32-edge tiles of k_transition2d; round 3 also tried 64-edge tiles whose
-    rows leave through emit_tile -- parity-green with this test, 6 % slower: 0.105 against 0.099 ms per 655 360 edges, not kept):
-    shared random parents from the lower half, distinct children in the upper half, some edges in place; against the oracle, and a
-    second wave on the children."""
+    """A wave of 65 536 + 36 edges on a pool of 2^18 rows.  Round 5: gathered rows take k_edges2d -- every source record fetched once by
+    five neighbouring lanes (16 bytes each), through LDS, out to its destination row the same way, rows through emit_tile: 0.075 against
+    k_transition2d's 0.105 ms per 524 288 random-parent edges (round 3's 64-edge tiles with emit_tile but per-lane 4-byte loads were 6 %
+    SLOWER than k_transition2d: what counts is the number of scattered lane requests) -- when m % 4 == 0 and the observations are 16-byte
+    aligned.  Shared random parents from the lower half, distinct children in the upper half, some edges in place; against the oracle,
+    and a second wave on the children; and m % 4 != 0 (k_transition2d) gives the same rows for the same edges."""
     import torch
-    from snac_amd import BatchedDMPEnv
+    from snac_amd import BatchedDMPEnv, _lib
 
     pool, m = 1 << 18, 65536 + 36
     table = helpers.plan_table(2, dyn, "dense_train" if dyn else "p0")
@@ -397,6 +399,7 @@ def test_large_waves_of_2d_edges(dyn, f32):
         acts = rng.integers(0, 5, m).astype(np.int8)
         ks = rng.integers(1, 4, m).astype(np.int8) if wave == 0 else None
         o, r, d = env.transition(acts, ks, src, dst, t=wave)
+        assert _lib.lib().snac_last_kernel() == b"k_edges2d"
         oo, ro, do = orc.transition(acts, ks, src, dst, t=wave)
         assert o.cpu().numpy().tobytes() == (oo.astype(np.float32) if f32 else oo).tobytes(), wave
         assert r.cpu().numpy().tobytes() == ro.tobytes() and np.array_equal(d.cpu().numpy().astype(np.uint8), do), wave
@@ -404,6 +407,19 @@ def test_large_waves_of_2d_edges(dyn, f32):
     idx = np.arange(0, pool, 1031)
     cb = env.count_brick.cpu().numpy()
     assert [int(cb[i]) for i in idx] == [int(orc.b.contents.envs[int(i)].cb) for i in idx]
+    st = orc.state()
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(pool, -1), st["grid"].astype(np.float64))
+    # the other kernel on the same edges: m - 2 of them (m % 4 != 0), rows and records compared on the device
+    twin = env.fork(torch.arange(pool, device=env.device))
+    dst = (pool // 2 + rng.choice(pool // 2, m, replace=False)).astype(np.int32)
+    src = rng.integers(0, pool // 2, m).astype(np.int32)
+    acts = rng.integers(0, 5, m).astype(np.int8)
+    o1, r1, d1 = env.transition(acts, None, src, dst, t=7)
+    o2, r2, d2 = twin.transition(acts[: m - 2], None, src[: m - 2], dst[: m - 2], t=7)
+    assert _lib.lib().snac_last_kernel() == b"k_transition2d"
+    assert torch.equal(o1[: m - 2], o2) and torch.equal(r1[: m - 2], r2) and torch.equal(d1[: m - 2], d2)
+    keep = torch.from_numpy(dst[: m - 2].astype(np.int64)).to(env.device)
+    assert torch.equal(env._grid[keep], twin._grid[keep]) and torch.equal(env._hdr[keep], twin._hdr[keep]) and torch.equal(env._episode[keep], twin._episode[keep])
 
 
 @pytest.mark.gpu
