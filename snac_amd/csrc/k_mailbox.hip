@@ -66,6 +66,43 @@ __device__ __forceinline__ T sys_load(const T* p) { return __hip_atomic_load(p, 
 template <typename T>
 __device__ __forceinline__ void sys_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// The row of a ONE-env batch in one store instruction: lane l holds value l of the row (window cell, scalar slot, position / record tail
+// value) -- write_obs walks the tile machinery for eight envs and sends window, tails and record as separate stores over the bus (0.9 us of
+// a 5.5 us step; this: see profiles/r05_mailbox.txt).  Layout rules are write_obs's / write_scalars'; rows with the plan tail keep the
+// general path.  s, reward, done: lane 0's.
+template <class K, typename OT, bool VAR>
+__device__ __forceinline__ void emit_one(uint32_t* lds, OT* row, const Lane& s, const KArgs& a, int lane, int reward, int done) {
+    const int r = __builtin_amdgcn_readlane(s.r, 0), c = __builtin_amdgcn_readlane(s.c, 0), cb = __builtin_amdgcn_readlane(s.cb, 0);
+    const int cs = __builtin_amdgcn_readlane(s.cs, 0), tb = __builtin_amdgcn_readlane(s.tb, 0), pidx = __builtin_amdgcn_readlane(s.pidx, 0);
+    const int rw = __builtin_amdgcn_readlane(reward, 0), dn = __builtin_amdgcn_readlane(done, 0);
+    const bool norm = VAR ? (a.sc_norm != 0) : K::DYN;
+    const double v0 = norm ? (double)cb / (double)tb : (double)cb, v1 = norm ? (double)cs / (double)a.total_step : (double)cs;
+    const int LD = VAR ? a.ld : K::D;
+    double val;
+    if (lane < K::W) {
+        int v;
+        if constexpr (K::D == 7) v = K::hmap(lds)[r - 2 + lane];                               // 1D: the five cells round the position
+        else if constexpr (K::A == 8) { const int i = lane / 7, j = lane - 7 * i; v = K::hmap(lds)[(r - 3 + i) * 26 + (c - 3 + j)]; }
+        else { const int i = lane / 7, j = lane - 7 * i; const uint64_t w = K::cells(lds)[(r - 3 + i) * K::RS]; v = ((int)((uint32_t)(w >> (2 * (c - 3 + j))) << 30)) >> 30; }
+        if constexpr (VAR) v = v < 0 ? a.frame_val : v;
+        val = (double)v;
+    } else if (lane < K::D) {
+        val = lane == K::W ? v0 : v1;
+    } else {
+        int ti = lane - K::D, out = 0;
+        if constexpr (VAR) {
+            if (a.tail & SNAC_TAIL_POSITION) {
+                constexpr int PN = K::D == 7 ? 1 : 2;
+                if (ti >= 0 && ti < PN) out = ti == 0 ? r : c;
+                ti -= PN;
+            }
+            if ((a.tail & SNAC_TAIL_RECORD) && ti >= 0) out = record_value(min(ti, 7), rw, dn, r, K::D == 7 ? 0 : c, cb, cs, tb, pidx);
+        }
+        val = (double)out;
+    }
+    if (lane < LD) row[lane] = (OT)val;
+}
+
 // One wave, env e of the batch on lane e (N <= K::E <= 64; the facades: N = 1).  VAR: the batch's layout is a variant (the facades carry
 // the record tail), OT = its observation type.
 template <class K, typename OT, bool VAR>
@@ -96,7 +133,7 @@ __global__ __launch_bounds__(64) void k_mailbox(const KArgs a, snac_mailbox* mb,
             const long long w0 = wall_clock64();
             __threadfence_system();
             if (lane == 0) {
-                sys_store(&mb->dbg[3], dbg_wt + (uint32_t)(wall_clock64() - w0));
+                if ((served & 63u) == 0u) sys_store(&mb->dbg[3], dbg_wt + (uint32_t)(wall_clock64() - w0));
                 sys_store(&mb->steps_served, served);
                 __hip_atomic_store(&mb->wt_seq, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -132,7 +169,8 @@ __global__ __launch_bounds__(64) void k_mailbox(const KArgs a, snac_mailbox* mb,
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
         }
         const long long c1 = wall_clock64();
-        emit_obs<K, OT, VAR, VAR && K::A != 8>(lds, (OT*)mb->row, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
+        if (nenv == 1 && !(VAR && (a.tail & SNAC_TAIL_PLAN))) emit_one<K, OT, VAR>(lds, (OT*)mb->row, s, a, lane, reward, done ? 1 : 0);
+        else emit_obs<K, OT, VAR, VAR && K::A != 8>(lds, (OT*)mb->row, nenv, s, a, lane, StepOut{reward, done ? 1 : 0});
         // (a single env whose row carries the record tail -- the drop-in classes -- has reward and done in the row: two stores over the bus less)
         if (active && (op == MB_STEP_N || !(VAR && (a.tail & SNAC_TAIL_RECORD)))) { mb->reward[lane] = (float)reward; mb->done[lane] = done ? 1 : 0; }
         const long long c2 = wall_clock64();
@@ -151,7 +189,9 @@ __global__ __launch_bounds__(64) void k_mailbox(const KArgs a, snac_mailbox* mb,
         K::store_grid(lds, a, 0, nenv, lane);
         if (active) { a.hdr[lane] = s.pack(); a.episode[lane] = episode; }
         served += 1u;
-        if (lane == 0) { sys_store(&mb->dbg[0], (uint32_t)(c1 - c0)); sys_store(&mb->dbg[1], (uint32_t)(c2 - c1)); sys_store(&mb->dbg[2], (uint32_t)(c3 - c2)); }
+        if (lane == 0 && (served & 63u) == 0u) {                     // the wave's own stamps, now and then (each is a store over the bus)
+            sys_store(&mb->dbg[0], (uint32_t)(c1 - c0)); sys_store(&mb->dbg[1], (uint32_t)(c2 - c1)); sys_store(&mb->dbg[2], (uint32_t)(c3 - c2));
+        }
         seen = req;
         wt_pending = true;                                           // fenced and reported behind the next poll (top of the loop)
         last = wall_clock64();
