@@ -62,6 +62,8 @@ CROSSOVERS = [
      {"SNAC_STEP_VAR_MIN": "1", "SNAC_STEP_VAR_HALF": "0"}, {"SNAC_STEP_VAR_MIN": "100000000"}, "min", [32768, 40960, 45056, 49152, 65536]),
     ("SNAC_STEP_VAR3_MIN", "k_step3d<VAR> | k_transition, 3D PPO rows per tick", dict(kind=3, T=1, f32=0, layout="ppo", mode="step"),
      {"SNAC_STEP_VAR3_MIN": "1"}, {"SNAC_STEP_VAR3_MIN": "100000000"}, "min", [8192, 16384, 24576, 32768, 65536]),
+    ("SNAC_STEP3D_SPAN_MIN", "k_step3ds (cooperative span loads) | k_step3d, 3D canonical rows per tick", dict(kind=3, T=1, f32=0, layout=None, mode="step"),
+     {"SNAC_STEP3D_SPAN_MIN": "4"}, {"SNAC_STEP3D_SPAN": "0"}, "min", [32768, 65536, 81920, 98304, 131072, 262144]),
 ]
 
 
