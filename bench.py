@@ -16,6 +16,7 @@ GPU) that starts N rank processes -- the one-command form of the reference drive
 WORLD_SIZE set (torch.distributed.run) it must equal N, anything else is a non-zero exit.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -414,6 +415,8 @@ def main():
     def timed_region():
         """EXACTLY K passes between a barrier + synchronize on either side; returns (wall seconds, MAX over ranks; per-pass kernel ms of this rank)."""
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        gc.collect()                                                # (no collector pause of the host thread inside the timed region)
+        gc.disable()
         sync()
         t0 = time.perf_counter()
         pending = []
@@ -439,6 +442,7 @@ def main():
             stats.copy_(pending[-1][1])
         sync()
         dt_ = time.perf_counter() - t0
+        gc.enable()
         dt_ = float(allreduce_(torch.tensor([dt_], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
         return dt_, [a.elapsed_time(b) for a, b in ev], len(pending)
 
@@ -615,14 +619,25 @@ def main():
             for _ in range(max(3, reps // 4)):
                 fn()
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(GROUPS)]
-            for a_, b_ in evs:
-                a_.record()
-                for _ in range(reps):
-                    fn()
-                b_.record()
-            torch.cuda.synchronize()
-            per = sorted(a_.elapsed_time(b_) / reps for a_, b_ in evs)
+            # the interpreter's cyclic garbage collector off while the launches are enqueued: a full collection in this process takes tens
+            # of milliseconds, during which the device runs dry -- the "stall" of round 4's driver run and of this round's first runs (always
+            # the same group of the same extra: the collector triggers on an allocation count); a stepping loop of 6000 launches on its own
+            # shows no such gap
+            gc.collect()
+            gc.disable()
+            try:
+                for a_, b_ in evs:
+                    a_.record()
+                    for _ in range(reps):
+                        fn()
+                    b_.record()
+                torch.cuda.synchronize()
+            finally:
+                gc.enable()
+            in_order = [a_.elapsed_time(b_) / reps for a_, b_ in evs]
+            per = sorted(in_order)
             spread.append({"min": per[0], "median": per[GROUPS // 2], "max": per[-1], "groups": GROUPS, "launches_per_group": reps,
+                           "in_order": [round(x, 6) for x in in_order],
                            "outlier": bool(per[-1] > 1.5 * per[GROUPS // 2])})
             return per[GROUPS // 2]
 
