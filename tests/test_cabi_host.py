@@ -174,3 +174,25 @@ def test_dispatch_table_is_one_table_with_documented_entries():
     for k, v in want.items():
         if k not in os.environ:
             assert t[k][0] == v, (k, t[k])
+
+
+def test_round5_entry_points_validate_their_arguments_before_any_hip_call():
+    from snac_amd import _lib
+
+    L = _lib.lib()
+    mb = C.c_void_p()
+    big = _lib.EnvDesc(2, 1, 65, 4, 0, 0, 1, 0, 0, 0)              # a mailbox steps one wavefront: 64 envs at most
+    assert L.snac_mailbox_create(C.byref(big), 0, C.byref(mb)) != 0 and b"1 .. 64" in L.snac_last_error() and not mb.value
+    assert L.snac_mailbox_create(None, 0, C.byref(mb)) != 0
+    assert L.snac_mailbox_step(None, None, None, 0, 1) != 0 and b"null mailbox" in L.snac_last_error()
+    assert L.snac_mailbox_touch(None) != 0
+    assert L.snac_mailbox_settle(None) == 0 and L.snac_mailbox_quit(None) == 0 and L.snac_mailbox_destroy(None) == 0   # nothing to wait for / end
+    assert not L.snac_mailbox_row(None) and not L.snac_mailbox_reward(None) and not L.snac_mailbox_done(None)
+    d = _lib.EnvDesc(2, 1, 16, 4, 0, 0, 1, 0, 0, 0)
+    st = _lib.State(1, 1, 1, 1, 1, 1, 1, 1)                        # (never dereferenced: every call below fails its checks first)
+    assert L.snac_plans_from_grids(C.byref(d), C.byref(st), 2, 3, None, 0, None, None, None, None) != 0 and b"out of range" in L.snac_last_error()
+    assert L.snac_plans_from_grids(C.byref(d), C.byref(st), 2, 0, None, 0, None, None, None, None) != 0 and b"exactly one" in L.snac_last_error()
+    mem = (C.c_double * (2 * 676))()
+    assert L.snac_plans_from_grids(C.byref(d), C.byref(st), 2, 0, None, 0, None, mem, None, None) != 0 and b"total_brick" in L.snac_last_error()
+    buf = C.create_string_buffer(8)
+    assert L.snac_tuning(buf, 8) != 0 and L.snac_tuning(None, 0) != 0
