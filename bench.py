@@ -659,7 +659,7 @@ def main():
         def last_kernel():
             return _lib.lib().snac_last_kernel().decode()
 
-        def rollout_cfg(name, kind, dyn, nn, f32, reps, note=None, plans=0, layout=None, TT=0):
+        def rollout_cfg(name, kind, dyn, nn, f32, reps, note=None, plans=0, layout=None, TT=0, tail=None):
             import numpy as np
 
             dt = torch.float32 if f32 else torch.float64
@@ -668,6 +668,8 @@ def main():
                 kw["plans"] = np.zeros((plans, 26, 26))
             if layout:
                 kw["layout"] = layout
+            if tail:
+                kw["obs_tail"] = tail
             e = BatchedDMPEnv(kind, dyn, nn, device=dev, seed=1, obs_dtype=dt, **kw)
             if plans:
                 e.generate_plans(0, plans, seed=5)
@@ -860,6 +862,8 @@ def main():
         rollout_cfg("small_batch_n4096_T600", 2, True, 4096, False, 30)
         rollout_cfg("ppo_layout_1d_n1024_T750", 1, True, 1024, False, 30, layout="ppo")
         rollout_cfg("ppo_layout_3d_n16384_T200", 3, True, 16384, False, 6, layout="ppo", TT=200)
+        # 3D rows that carry their own record (reward, done, position, counters, plan row: 59 values), what a replay writer of the 3D classes stores
+        rollout_cfg("record_rows_3d_n16384_T1000", 3, True, 16384, False, 12, tail=("record",))
         rollout_cfg("small_batch_n1024_T600", 2, True, 1024, False, 30)
         for kind in (2, 3):
             for nn in (65536, 524288):

@@ -3,6 +3,7 @@
 #include "snac_dev.h"
 
 namespace snac_detail {
+void launch_roll3dbv(const snac_env_desc* d, const KArgs& a, hipStream_t s);   // k_roll3dbv.hip: k_rollout3db for the layout variants (declared here: snac_dev.h is hashed into profiles/traffic.json)
 thread_local char g_err[256] = "";
 thread_local const char* g_kernel = "";
 
@@ -112,6 +113,10 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_EDGES3D         */ {"SNAC_EDGES3D", 1, "0: 3D tree edges with gathered rows stay on k_transition3d instead of k_edges3d"},
     /* TN_EDGES2D         */ {"SNAC_EDGES2D", 1, "0: 2D tree edges with gathered rows stay on k_transition2d instead of k_edges2d (records through LDS)"},
     /* TN_EDGES2D_MIN     */ {"SNAC_EDGES2D_MIN", 4, "k_edges2d from this many edges per call"},
+    /* TN_3D_BLOCK_VAR    */ {"SNAC_3D_BLOCK_VAR", 1, "0: 3D rollouts with a layout variant stay on the tile kernel instead of k_rollout3db's variant forms"},
+    /* TN_3D_BLOCK_VAR_MIN*/ {"SNAC_3D_BLOCK_VAR_MIN", 64, "variant rows without the plan tail (51-61 values) on k_rollout3db from (1.22 us per tick at any N against the tile kernel's 3.2; r05_var3d.txt)"},
+    /* ..VAR_PLAN_F64     */ {"SNAC_3D_BLOCK_VAR_PLAN_F64", 10240, "rows with the plan tail, float64, on k_rollout3db from (10 240 envs x 200 ticks: 1.06 against 1.33 ms, 8192: 0.96 / 0.94, 16 384: 1.74 / 1.99; r05_var3d.txt)"},
+    /* ..VAR_PLAN_F32     */ {"SNAC_3D_BLOCK_VAR_PLAN_F32", 16384, "the same, float32 rows (16 384 envs: 0.93 against 1.00 ms, 14 336: 0.89 / 0.86)"},
 };
 
 int tune(int id) {
@@ -141,10 +146,15 @@ bool pipeline_off() { return tune(TN_PIPELINE) == 0; }
 inline bool every_row(const KArgs& a) { return a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED; }
 inline bool pieces16(const KArgs& a) { return (a.n & 3) == 0 && (((uintptr_t)a.obs) & 15) == 0; }
 
-// 3D rollouts by blocks of 64 envs (k_rollout3db): every row written, canonical layout, <= TB_MAX plans, 16-byte pieces
+// 3D rollouts by blocks of 64 envs (k_rollout3db): every row written, <= TB_MAX plans, 16-byte pieces; the layout variants on its VAR form
 bool roll3db_ok(const KArgs& a, bool f32) {
     const int lim = tune(TN_3D_BLOCK_MIN) >= 0 ? tune(TN_3D_BLOCK_MIN) : tune(f32 ? TN_3D_BLOCK_MIN_F32 : TN_3D_BLOCK_MIN_F64);
-    return tune(TN_3D_BLOCK) != 0 && a.n >= lim && !a.variant && every_row(a) && a.num_plans <= TB_MAX && pieces16(a) && !pipeline_off();
+    if (a.variant) {   // k_rollout3db<.., VAR>: its writers copy plan rows 16 bytes at a time
+        const int from = (a.tail & SNAC_TAIL_PLAN) ? tune(f32 ? TN_3D_BLOCK_VAR_PLAN_F32 : TN_3D_BLOCK_VAR_PLAN_F64) : tune(TN_3D_BLOCK_VAR_MIN);
+        if (tune(TN_3D_BLOCK_VAR) == 0 || a.n < from || (((uintptr_t)a.plans) & 15) != 0) return false;
+        return tune(TN_3D_BLOCK) != 0 && every_row(a) && a.num_plans <= TB_MAX && pieces16(a) && !pipeline_off();
+    }
+    return tune(TN_3D_BLOCK) != 0 && a.n >= lim && every_row(a) && a.num_plans <= TB_MAX && pieces16(a) && !pipeline_off();
 }
 
 // the headline kernel k_rollout2d: tiles of 64 envs, every row written, 16-byte pieces
@@ -210,7 +220,11 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             if (op == OP_ROLLOUT && roll2d_ok(a, a.n >= roll2d_from(d->obs_dtype == SNAC_OBS_F32) ? 64 : E)) { g_kernel = "k_rollout2d"; launch_roll2d(d, a, s); break; }
             launch_tile2d(op, dyn, E, d->obs_dtype, a, s); break;
         default:   // 3D: 2.1 KB of LDS per env -> tiles of 16 (or 8 for small batches: two waves per SIMD sooner)
-            if (op == OP_ROLLOUT && roll3db_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout3db"; launch_roll3db(d, a, s); break; }
+            if (op == OP_ROLLOUT && roll3db_ok(a, d->obs_dtype == SNAC_OBS_F32)) {
+                g_kernel = "k_rollout3db";
+                if (a.variant) launch_roll3dbv(d, a, s); else launch_roll3db(d, a, s);
+                break;
+            }
             if (op == OP_ROLLOUT && E == 8 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && !pipeline_off()) { g_kernel = "k_rollout3d"; launch_roll3d(d, a, s); break; }
             if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var3_ok(a))) {
                 const bool span = !a.variant && tune(TN_STEP3D_SPAN) != 0 && a.n >= tune(TN_STEP3D_SPAN_MIN);   // large batches of canonical rows

@@ -6,7 +6,7 @@ crossover below this tool times BOTH kernels at a few batch sizes round the defa
 per process; the arm is forced with the switch of the same table), reports the two times and where the faster kernel changes, and
 prints `export NAME=value` lines for crossovers that moved by more than one grid step.
 
-    gpurun -- python tools/retune.py [quick]          (quick: fewer batch sizes, ~2 minutes); rollouts are whole episodes (T = total_step) into the memory rollout() itself would use
+    gpurun -- python tools/retune.py [quick] [only=SUBSTRING ...]     (quick: fewer batch sizes, ~2 minutes; only=: the entries whose name contains SUBSTRING); rollouts are whole episodes (T = total_step) into the memory rollout() itself would use
 """
 import json
 import os
@@ -62,6 +62,10 @@ CROSSOVERS = [
      {"SNAC_STEP_VAR_MIN": "1", "SNAC_STEP_VAR_HALF": "0"}, {"SNAC_STEP_VAR_MIN": "100000000"}, "min", [32768, 40960, 45056, 49152, 65536]),
     ("SNAC_STEP_VAR3_MIN", "k_step3d<VAR> | k_transition, 3D PPO rows per tick", dict(kind=3, T=1, f32=0, layout="ppo", mode="step"),
      {"SNAC_STEP_VAR3_MIN": "1"}, {"SNAC_STEP_VAR3_MIN": "100000000"}, "min", [8192, 16384, 24576, 32768, 65536]),
+    ("SNAC_3D_BLOCK_VAR_PLAN_F64", "k_rollout3db (plan rows in LDS, handed over by the stepper) | tile kernel, 3D float64 rows with the plan tail, 200 ticks",
+     dict(kind=3, T=200, f32=0, layout="ppo", mode="rollout"), {"SNAC_3D_BLOCK_VAR_PLAN_F64": "4"}, {"SNAC_3D_BLOCK_VAR": "0"}, "min", [6144, 8192, 10240, 12288, 16384, 32768]),
+    ("SNAC_3D_BLOCK_VAR_PLAN_F32", "the same, float32 rows", dict(kind=3, T=200, f32=1, layout="ppo", mode="rollout"),
+     {"SNAC_3D_BLOCK_VAR_PLAN_F32": "4"}, {"SNAC_3D_BLOCK_VAR": "0"}, "min", [8192, 10240, 12288, 14336, 16384, 32768, 65536]),
     ("SNAC_STEP3D_SPAN_MIN", "k_step3ds (cooperative span loads) | k_step3d, 3D canonical rows per tick", dict(kind=3, T=1, f32=0, layout=None, mode="step"),
      {"SNAC_STEP3D_SPAN_MIN": "4"}, {"SNAC_STEP3D_SPAN": "0"}, "min", [32768, 65536, 81920, 98304, 131072, 262144]),
 ]
@@ -78,13 +82,16 @@ def run(work, n, env):
 
 
 def main():
-    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    quick = "quick" in sys.argv[1:]
+    only = [a[5:] for a in sys.argv[1:] if a.startswith("only=")]      # only=SUBSTRING: the crossovers whose entry name contains it
     sys.path.insert(0, ROOT)
     from snac_amd import _lib
 
     table = _lib.tuning()
     exports = []
     for name, what, work, env_a, env_b, direction, sizes in CROSSOVERS:
+        if only and not any(o in name for o in only):
+            continue
         if quick:
             sizes = sizes[1:-1:2] if len(sizes) > 4 else sizes[::2]
         cur = table[name][0]
