@@ -50,8 +50,8 @@ def trial(rng, idx):
     if rng.random() < 0.25:                                       # an observation-layout variant: flags of the kernels
         tails = [t for t in ("position", "plan", "record") if rng.random() < 0.5]
         if n > 5000 and "plan" in tails:
-            if dim == 2 and rng.random() < 0.5:
-                pass                                               # 451-value rows at N >= 65 536 take k_rollout2d's row groups: a few ticks of them
+            if dim in (2, 3) and rng.random() < 0.5:
+                pass                                               # 451-value rows at N >= 65 536 take k_rollout2d's row groups, 3D ones from 10 240 envs k_rollout3db's plan rows: a few ticks of them
             else:
                 tails.remove("plan")                              # 400 more values per row: keep the oracle's share small
         lay = dict(obs_tail=tuple(tails), frame_value=int(rng.choice([-1, 2])) if dim != 3 else -1, obs_scalars=str(rng.choice(["raw", "norm"])))
