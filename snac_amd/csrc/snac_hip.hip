@@ -3,6 +3,7 @@
 #include "snac_dev.h"
 
 namespace snac_detail {
+void launch_roll2db(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);   // k_roll2db.hip: k_rollout2db (declared here for the same reason as the next one)
 void launch_roll3dbv(const snac_env_desc* d, const KArgs& a, hipStream_t s);   // k_roll3dbv.hip: k_rollout3db for the layout variants (declared here: snac_dev.h is hashed into profiles/traffic.json)
 thread_local char g_err[256] = "";
 thread_local const char* g_kernel = "";
@@ -117,6 +118,13 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_3D_BLOCK_VAR_MIN*/ {"SNAC_3D_BLOCK_VAR_MIN", 64, "variant rows without the plan tail (51-61 values) on k_rollout3db from (1.22 us per tick at any N against the tile kernel's 3.2; r05_var3d.txt)"},
     /* ..VAR_PLAN_F64     */ {"SNAC_3D_BLOCK_VAR_PLAN_F64", 10240, "rows with the plan tail, float64, on k_rollout3db from (10 240 envs x 200 ticks: 1.06 against 1.33 ms, 8192: 0.96 / 0.94, 16 384: 1.74 / 1.99; r05_var3d.txt)"},
     /* ..VAR_PLAN_F32     */ {"SNAC_3D_BLOCK_VAR_PLAN_F32", 16384, "the same, float32 rows (16 384 envs: 0.93 against 1.00 ms, 14 336: 0.89 / 0.86)"},
+    /* TN_2D_BLOCK        */ {"SNAC_2D_BLOCK", 1, "0: no 2D rollout takes the block kernel k_rollout2db (stepper waves + eight writer waves per 64 / 128 envs)"},
+    /* TN_2D_BLOCK_MIN_F64*/ {"SNAC_2D_BLOCK_MIN_F64", 11264, "k_rollout2db, float64 canonical rows, from this many envs (12 288: 0.443 against k_rollout2dt's 0.531 ms per 600 ticks, 10 240: 0.447 / 0.433; r05_2d_block.txt) ..."},
+    /* TN_2D_BLOCK_MAX_F64*/ {"SNAC_2D_BLOCK_MAX_F64", 32768, "... up to this many (32 768: 1.194 against the tile kernel's 1.228 ms, 40 960: 1.71 against k_rollout2d's 1.54)"},
+    /* TN_2D_BLOCK_MIN_F32*/ {"SNAC_2D_BLOCK_MIN_F32", 15360, "k_rollout2db, float32 canonical rows, from (16 384: 0.434 against k_rollout2dt's 0.462 ms, 12 288: 0.432 / 0.340) ..."},
+    /* TN_2D_BLOCK_MAX_F32*/ {"SNAC_2D_BLOCK_MAX_F32", 32768, "... up to (32 768: 0.607 against k_rollout2d's 0.820 ms, 36 864: 1.08 / 0.82)"},
+    /* TN_2D_BLOCK_TWO_F64*/ {"SNAC_2D_BLOCK_TWO_F64", 16384, "k_rollout2db with blocks of 128 envs (two stepper waves) from this many envs, float64 rows (16 384: 0.570 against 0.598 ms on 64-env blocks; 20 480: 0.746 / 0.948)"},
+    /* TN_2D_BLOCK_TWO_F32*/ {"SNAC_2D_BLOCK_TWO_F32", 16385, "the same, float32 rows (16 384: 0.502 against 0.434; 20 480: 0.504 / 0.849)"},
 };
 
 int tune(int id) {
@@ -155,6 +163,12 @@ bool roll3db_ok(const KArgs& a, bool f32) {
         return tune(TN_3D_BLOCK) != 0 && every_row(a) && a.num_plans <= TB_MAX && pieces16(a) && !pipeline_off();
     }
     return tune(TN_3D_BLOCK) != 0 && a.n >= lim && every_row(a) && a.num_plans <= TB_MAX && pieces16(a) && !pipeline_off();
+}
+
+// 2D rollouts by blocks of 64 envs (k_rollout2db): the middle batches, every row written, canonical layout, 16-byte pieces
+bool roll2db_ok(const KArgs& a, bool f32) {
+    if (tune(TN_2D_BLOCK) == 0 || a.variant || !every_row(a) || !pieces16(a) || pipeline_off()) return false;
+    return a.n >= tune(f32 ? TN_2D_BLOCK_MIN_F32 : TN_2D_BLOCK_MIN_F64) && a.n <= tune(f32 ? TN_2D_BLOCK_MAX_F32 : TN_2D_BLOCK_MAX_F64);
 }
 
 // the headline kernel k_rollout2d: tiles of 64 envs, every row written, 16-byte pieces
@@ -216,6 +230,11 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
         case SNAC_ENV_2D:
             if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var_ok(a, d->obs_dtype == SNAC_OBS_F32))) { g_kernel = "k_step2d"; launch_step2d(d, a, a.variant && step_var_half(a), s); break; }
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { g_kernel = "k_transition2d"; launch_trans2d(d, a, s); break; }
+            if (op == OP_ROLLOUT && roll2db_ok(a, d->obs_dtype == SNAC_OBS_F32)) {
+                g_kernel = "k_rollout2db";
+                launch_roll2db(d, a, a.n >= tune(d->obs_dtype == SNAC_OBS_F32 ? TN_2D_BLOCK_TWO_F32 : TN_2D_BLOCK_TWO_F64) ? 2 : 1, s);
+                break;
+            }
             if (op == OP_ROLLOUT && roll2dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout2dt"; launch_roll2dt(d, a, s); break; }
             if (op == OP_ROLLOUT && roll2d_ok(a, a.n >= roll2d_from(d->obs_dtype == SNAC_OBS_F32) ? 64 : E)) { g_kernel = "k_rollout2d"; launch_roll2d(d, a, s); break; }
             launch_tile2d(op, dyn, E, d->obs_dtype, a, s); break;

@@ -224,8 +224,10 @@ BIG = [
     # kind, N, T, float32 rows, kernel of the whole batch: every output below holds more than 2^31 values
     (2, 131072, 330, True, "k_rollout2d"),                           # 2.2e9 values, 8.8 GB
     (2, 8192, 5400, True, "k_rollout2dt"),                           # 2.26e9 values: 85 chunks of 64 ticks, rows [T][N] beyond 2^31 values
-    (2, 24576, 1800, True, "k_rollout2dt"),
-    (2, 24576, 1800, False, "k_rollout"),                            # the tile kernel, 18 GB
+    (2, 14336, 3100, True, "k_rollout2dt"),
+    (2, 24576, 1800, True, "k_rollout2db"),                          # blocks of 128 envs (round 5)
+    (2, 24576, 1800, False, "k_rollout2db"),                         # 18 GB
+    (2, 24578, 1800, False, "k_rollout"),                            # N % 4 != 0: the tile kernel, 18 GB
     (3, 65536, 660, True, "k_rollout3db"),                           # 2.21e9 values
     (3, 4088, 10900, True, "k_rollout3d"),                           # 2.27e9 values
 ]

@@ -57,11 +57,11 @@ def _end_state(env, orc):
 
 
 @pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
-@pytest.mark.parametrize("n", [1, 3, 13, 1001, 1024, 1026, 2046, 4100, 8191, 15872])
+@pytest.mark.parametrize("n", [1, 3, 13, 1001, 1024, 1026, 2046, 4100, 8191, 11260])
 def test_batch_shapes_and_tick_counts(dyn, n):
     """n = 1 / 3 / 13 / 1001: blocks of 4 envs, the last one ragged, odd N (rows leave element by element); 1024: the last batch in
     blocks of 4; 1026 / 2046: blocks of 8, a last block of 2 / 6 envs and idle stepper waves (which still draw ticks to expand); 4100: a
-    last block of 4; 8191: the largest odd batch of this kernel; 15 872: the last one below the tile kernel's full chip.  Launches of 1, 2, 37 and 80 steps; the time limit of 60 ends an episode
+    last block of 4; 8191: the largest odd batch of this kernel; 11 260: the last one below k_rollout2db's range.  Launches of 1, 2, 37 and 80 steps; the time limit of 60 ends an episode
     in every launch of 80."""
     env, orc = _pair(dyn, n, seed=5, total_step=60)
     t0 = 0
@@ -115,24 +115,25 @@ def test_a_whole_episode_of_float32_rows():
 
 
 BORDERS = [
-    # n, float32 rows, kernel of the canonical output, kernel of an output that is not 16-byte aligned
+    # n, float32 rows, kernel of the canonical output, kernel of an output that is not 16-byte aligned.  From 11 264 envs (float32: 15 360) to
+    # 32 768 the canonical rows are k_rollout2db's (round 5: blocks of 64 envs, of 128 from 16 384 / 16 385): tests/test_gpu_rollout2d_block.py
     (8191, False, "k_rollout2dt", "k_rollout2dt"),                  # odd N: element by element, still this kernel up to 8192
     (8193, False, "k_rollout", "k_rollout"),
     (8200, True, "k_rollout2dt", "k_rollout"),                      # whole pieces / an unaligned output of more than 8192 envs
-    (15872, False, "k_rollout2dt", "k_rollout"),
-    (15880, False, "k_rollout", "k_rollout"),                       # 249 of 256 waves: the tile kernel's full chip
-    (16384, False, "k_rollout", "k_rollout"),
-    (16392, False, "k_rollout2dt", "k_rollout"),
-    (19456, False, "k_rollout2dt", "k_rollout"),
-    (19464, False, "k_rollout", "k_rollout"),
-    (16384, True, "k_rollout2dt", "k_rollout"),
-    (30716, True, "k_rollout2dt", "k_rollout"),
-    (30720, True, "k_rollout", "k_rollout"),
+    (11260, False, "k_rollout2dt", "k_rollout"),
+    (11264, False, "k_rollout2db", "k_rollout"),
+    (11266, False, "k_rollout2dt", "k_rollout"),                    # N % 4 != 0: not the block kernel's
+    (15356, True, "k_rollout2dt", "k_rollout"),
+    (15360, True, "k_rollout2db", "k_rollout"),
+    (32768, False, "k_rollout2db", "k_rollout"),
+    (32772, False, "k_rollout2d", "k_rollout"),
+    (32768, True, "k_rollout2db", "k_rollout"),
+    (32772, True, "k_rollout2d", "k_rollout"),
 ]
 
 
-def _in_range(n, f32):
-    return n < 30720 if f32 else (n <= 15872 or 16384 < n <= 19456)
+def _tiled_kernel(n, f32, kern):
+    return "k_rollout2dt" if kern == "k_rollout" else kern             # (8193 envs: tile-major runs are whole pieces whatever N)
 
 
 @pytest.mark.parametrize("n,f32,kern,kern_unaligned", BORDERS, ids=lambda v: str(v))
@@ -153,7 +154,7 @@ def test_both_sides_of_every_border(n, f32, kern, kern_unaligned):
     assert og.cpu().numpy().tobytes() == want and rg.cpu().numpy().tobytes() == rc.tobytes()
     assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
     ot, rt, dtt = twin.rollout(T, obs="tiled")
-    assert _kernel() == ("k_rollout2dt" if _in_range(n, f32) else "k_rollout")   # tile-major runs are whole pieces whatever N
+    assert _kernel() == _tiled_kernel(n, f32, kern)
     assert twin.untile(ot).cpu().numpy().tobytes() == want and torch.equal(rt, rg) and torch.equal(dtt, dg)
     raw = torch.empty(T * n * 51 + 1, dtype=dt, device=env.device)
     ou, ru, du = third.rollout(T, out=raw[1:].view(T, n, 51))

@@ -62,6 +62,14 @@ CROSSOVERS = [
      {"SNAC_STEP_VAR_MIN": "1", "SNAC_STEP_VAR_HALF": "0"}, {"SNAC_STEP_VAR_MIN": "100000000"}, "min", [32768, 40960, 45056, 49152, 65536]),
     ("SNAC_STEP_VAR3_MIN", "k_step3d<VAR> | k_transition, 3D PPO rows per tick", dict(kind=3, T=1, f32=0, layout="ppo", mode="step"),
      {"SNAC_STEP_VAR3_MIN": "1"}, {"SNAC_STEP_VAR3_MIN": "100000000"}, "min", [8192, 16384, 24576, 32768, 65536]),
+    ("SNAC_2D_BLOCK_MIN_F64", "k_rollout2db (a stepper wave + eight writer waves per 64 envs) | k_rollout2dt / tile kernel, 2D float64 rows", dict(kind=2, T=0, f32=0, layout=None, mode="rollout"),
+     {"SNAC_2D_BLOCK_MIN_F64": "4", "SNAC_2D_BLOCK_MAX_F64": "100000000"}, {"SNAC_2D_BLOCK": "0"}, "min", [4096, 6144, 8192, 10240, 12288, 16384, 20480, 24576]),
+    ("SNAC_2D_BLOCK_MAX_F64", "k_rollout2db | tile kernel / k_rollout2d, 2D float64 rows", dict(kind=2, T=0, f32=0, layout=None, mode="rollout"),
+     {"SNAC_2D_BLOCK_MIN_F64": "4", "SNAC_2D_BLOCK_MAX_F64": "100000000"}, {"SNAC_2D_BLOCK": "0"}, "max", [28672, 32768, 40960, 49152, 57344, 65536]),
+    ("SNAC_2D_BLOCK_MIN_F32", "k_rollout2db | k_rollout2dt, 2D float32 rows", dict(kind=2, T=0, f32=1, layout=None, mode="rollout"),
+     {"SNAC_2D_BLOCK_MIN_F32": "4", "SNAC_2D_BLOCK_MAX_F32": "100000000"}, {"SNAC_2D_BLOCK": "0"}, "min", [4096, 8192, 12288, 16384, 24576]),
+    ("SNAC_2D_BLOCK_MAX_F32", "k_rollout2db | k_rollout2d, 2D float32 rows", dict(kind=2, T=0, f32=1, layout=None, mode="rollout"),
+     {"SNAC_2D_BLOCK_MIN_F32": "4", "SNAC_2D_BLOCK_MAX_F32": "100000000"}, {"SNAC_2D_BLOCK": "0"}, "max", [28672, 32768, 40960, 49152, 65536]),
     ("SNAC_3D_BLOCK_VAR_PLAN_F64", "k_rollout3db (plan rows in LDS, handed over by the stepper) | tile kernel, 3D float64 rows with the plan tail, 200 ticks",
      dict(kind=3, T=200, f32=0, layout="ppo", mode="rollout"), {"SNAC_3D_BLOCK_VAR_PLAN_F64": "4"}, {"SNAC_3D_BLOCK_VAR": "0"}, "min", [6144, 8192, 10240, 12288, 16384, 32768]),
     ("SNAC_3D_BLOCK_VAR_PLAN_F32", "the same, float32 rows", dict(kind=3, T=200, f32=1, layout="ppo", mode="rollout"),
