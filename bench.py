@@ -860,6 +860,8 @@ def main():
         rollout_cfg("ppo_layout_n4096_T600", 2, True, 4096, False, 10, layout="ppo")
         rollout_cfg("ppo_layout_n1024_T600", 2, True, 1024, False, 20, layout="ppo")
         rollout_cfg("small_batch_n4096_T600", 2, True, 4096, False, 30)
+        # the middle batches (at most one lane-per-env wave per SIMD): the block kernel k_rollout2db, blocks of 128 envs with two stepper waves
+        rollout_cfg("mid_batch_n20480_T600", 2, True, 20480, False, 20)
         rollout_cfg("ppo_layout_1d_n1024_T750", 1, True, 1024, False, 30, layout="ppo")
         rollout_cfg("ppo_layout_3d_n16384_T200", 3, True, 16384, False, 6, layout="ppo", TT=200)
         # 3D rows that carry their own record (reward, done, position, counters, plan row: 59 values), what a replay writer of the 3D classes stores

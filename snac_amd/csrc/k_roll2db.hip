@@ -98,6 +98,12 @@ __global__ __launch_bounds__((NS + 8) * 64) void k_rollout2db(const KArgs a) {
         };
         int act = 0, k = 1, act_n = 0, k_n = 1;
         if constexpr (EXPL) { load_inputs(0, act, k); load_inputs(1, act_n, k_n); }
+        else inputs_of(0, act, k);
+        // The tick's chain of dependent steps is what a launch of <= 256 blocks costs (600 x the tick), so what the NEXT tick needs first is
+        // asked for while this tick's window rows are on their way: the agent's row word and plan word at the new position (an env that
+        // starts over reads them again, below) and the counter-RNG word.
+        uint64_t w_pf = cells[s.r * RS + lane];
+        uint32_t pl_pf = pl[(s.r - 3) * 65 + lane];
         for (int t = 0; t < a.T; ++t) {
             const int par = t & 1;
             const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
@@ -131,15 +137,16 @@ __global__ __launch_bounds__((NS + 8) * 64) void k_rollout2db(const KArgs a) {
                         dtb = (double)tbv; rtb = 1.0 / dtb;
                     }
                 }
+                w_pf = cells[s.r * RS + lane];                       // (the board was cleared, the plan row may be another)
+                pl_pf = pl[(s.r - 3) * 65 + lane];
             }
             // ---- K2D::step (DMP_Env_2D_dynamic_usedata_plan.py:85-147)
-            if constexpr (!EXPL) inputs_of(t, act, k);
             k = min(max(k, 1), 3);
             uint64_t* const cw = cells + s.r * RS + lane;
-            const uint64_t w = *cw;
+            const uint64_t w = w_pf;
             const int off = 2 * s.c;
             const bool was = ((w >> off) & 1ull) != 0ull;
-            const bool planned = ((pl[(s.r - 3) * 65 + lane] >> (s.c - 3)) & 1u) != 0u;
+            const bool planned = ((pl_pf >> (s.c - 3)) & 1u) != 0u;
             const bool first = s.cs == 0;
             const bool drop = act == 4;
             s.cs = min(s.cs + 1, CNT_MAX);
@@ -175,9 +182,15 @@ __global__ __launch_bounds__((NS + 8) * 64) void k_rollout2db(const KArgs a) {
             {
                 const uint64_t* const wp = cells + (s.r - 3) * RS + lane;
                 const int sh = 2 * (s.c - 3);
+                uint64_t wq[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) wq[i] = wp[i * RS];
+                w_pf = cells[s.r * RS + lane];                       // the next tick's first reads and its RNG word, in the shadow of the seven above
+                pl_pf = pl[(s.r - 3) * 65 + lane];
+                if constexpr (!EXPL) inputs_of(t + 1, act, k);
                 uint32_t wr[7];
 #pragma unroll
-                for (int i = 0; i < 7; ++i) wr[i] = (uint32_t)(wp[i * RS] >> sh) & 0x3FFFu;
+                for (int i = 0; i < 7; ++i) wr[i] = (uint32_t)(wq[i] >> sh) & 0x3FFFu;
                 spw[par][pub + lane] = make_uint4(wr[0] | (wr[1] << 14), wr[2] | (wr[3] << 14), wr[4] | (wr[5] << 14), wr[6]);
                 double v0 = (double)s.cb, v1 = (double)s.cs;
                 if (DYN) {                                           // cb / tb, cs / T: correctly rounded (Roll3D, tests/native/recip_check.c)
