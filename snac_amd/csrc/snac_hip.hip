@@ -3,7 +3,8 @@
 #include "snac_dev.h"
 
 namespace snac_detail {
-void launch_roll2db(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);   // k_roll2db.hip: k_rollout2db (declared here for the same reason as the next one)
+void launch_roll2db(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);   // k_roll2db.hip
+void launch_roll2dbv(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);  // k_roll2dbv.hip: the same kernel for the layout variants: k_rollout2db (declared here for the same reason as the next one)
 void launch_roll3dbv(const snac_env_desc* d, const KArgs& a, hipStream_t s);   // k_roll3dbv.hip: k_rollout3db for the layout variants (declared here: snac_dev.h is hashed into profiles/traffic.json)
 thread_local char g_err[256] = "";
 thread_local const char* g_kernel = "";
@@ -125,6 +126,9 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_2D_BLOCK_MAX_F32*/ {"SNAC_2D_BLOCK_MAX_F32", 32768, "... up to (32 768: 0.607 against k_rollout2d's 0.820 ms, 36 864: 1.08 / 0.82)"},
     /* TN_2D_BLOCK_TWO_F64*/ {"SNAC_2D_BLOCK_TWO_F64", 16384, "k_rollout2db with blocks of 128 envs (two stepper waves) from this many envs, float64 rows (16 384: 0.570 against 0.598 ms on 64-env blocks; 20 480: 0.746 / 0.948)"},
     /* TN_2D_BLOCK_TWO_F32*/ {"SNAC_2D_BLOCK_TWO_F32", 16385, "the same, float32 rows (16 384: 0.502 against 0.434; 20 480: 0.504 / 0.849)"},
+    /* TN_2D_BLOCK_VAR_MIN*/ {"SNAC_2D_BLOCK_VAR_MIN", 6148, "2D rollouts with a layout variant without the plan tail (51-61 values) on k_rollout2db from this many envs (up to 6144: k_rollout2dt; 59-value rows at 6144 envs 0.56 against 0.63 ms, 4096: 0.55 / 0.42; r05_2d_block.txt) ..."},
+    /* TN_2D_BLOCK_VAR_MAX*/ {"SNAC_2D_BLOCK_VAR_MAX", 32768, "... up to this many (32 768: 1.36 against the tile kernel's 5.92 ms; above: k_rollout2d, 49 152: 2.47 / 2.54, 65 536: 2.70 / 2.56)"},
+    /* TN_2D_BLOCK_VAR_TWO*/ {"SNAC_2D_BLOCK_VAR_TWO", 16385, "the variant rows on blocks of 128 envs from this many envs (16 384 envs, L-Net rows: 0.92 ms on 128 blocks of 128 against the tile kernel's 0.82)"},
 };
 
 int tune(int id) {
@@ -167,7 +171,8 @@ bool roll3db_ok(const KArgs& a, bool f32) {
 
 // 2D rollouts by blocks of 64 envs (k_rollout2db): the middle batches, every row written, canonical layout, 16-byte pieces
 bool roll2db_ok(const KArgs& a, bool f32) {
-    if (tune(TN_2D_BLOCK) == 0 || a.variant || !every_row(a) || !pieces16(a) || pipeline_off()) return false;
+    if (tune(TN_2D_BLOCK) == 0 || !every_row(a) || !pieces16(a) || pipeline_off()) return false;
+    if (a.variant) return !(a.tail & SNAC_TAIL_PLAN) && a.n >= tune(TN_2D_BLOCK_VAR_MIN) && a.n <= tune(TN_2D_BLOCK_VAR_MAX);   // k_roll2dbv.hip
     return a.n >= tune(f32 ? TN_2D_BLOCK_MIN_F32 : TN_2D_BLOCK_MIN_F64) && a.n <= tune(f32 ? TN_2D_BLOCK_MAX_F32 : TN_2D_BLOCK_MAX_F64);
 }
 
@@ -232,7 +237,8 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { g_kernel = "k_transition2d"; launch_trans2d(d, a, s); break; }
             if (op == OP_ROLLOUT && roll2db_ok(a, d->obs_dtype == SNAC_OBS_F32)) {
                 g_kernel = "k_rollout2db";
-                launch_roll2db(d, a, a.n >= tune(d->obs_dtype == SNAC_OBS_F32 ? TN_2D_BLOCK_TWO_F32 : TN_2D_BLOCK_TWO_F64) ? 2 : 1, s);
+                const int steppers = a.n >= tune(a.variant ? TN_2D_BLOCK_VAR_TWO : (d->obs_dtype == SNAC_OBS_F32 ? TN_2D_BLOCK_TWO_F32 : TN_2D_BLOCK_TWO_F64)) ? 2 : 1;
+                if (a.variant) launch_roll2dbv(d, a, steppers, s); else launch_roll2db(d, a, steppers, s);
                 break;
             }
             if (op == OP_ROLLOUT && roll2dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout2dt"; launch_roll2dt(d, a, s); break; }

@@ -4,7 +4,9 @@ that publishes each tick's window codes, scalar slots, reward and done, and eigh
 2D rollouts of 11 264 .. 32 768 envs (float32 rows: 15 360 .. 32 768; N % 4 = 0, 16-byte aligned output) that write every row: full
 blocks and ragged last blocks (a last stepper without envs, a last writer with 4 rows), float64 and float32 rows, dataset and static plans,
 [T][N][D] and tile-major outputs, launches of 1 / 2 / 37 steps, explicit actions / step sizes, the `>` rule bits, time limits of 1 .. 3,
-the record outputs -- and, bit for bit, what the tile kernel writes for the same batch (an unaligned output selects it)."""
+the record outputs -- and, bit for bit, what the tile kernel writes for the same batch (an unaligned output selects it).  The layout variants
+without the plan tail (rows of 51 .. 61 values: the L-Net rows with frame cells 2 and normalised scalar slots, raw slots, position and
+record tails) take the same kernel from 6148 to 32 768 envs (blocks of 128 envs from 16 388)."""
 import numpy as np
 import pytest
 
@@ -208,3 +210,78 @@ def test_replay_rings_filled_by_the_block_kernel():
     for i in range(7):
         slot = (a.head - 7 + i) % 48
         assert a.obs_at(slot).cpu().numpy().tobytes() == oc[i].tobytes(), i
+
+
+# ---- the layout variants without the plan tail (k_roll2dbv.hip)
+def _vpair(dyn, n, seed, kw, total_step=None, f32=False, base=0):
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(2, dyn, "dense_train" if dyn else "p1")
+    env = BatchedDMPEnv(2, dyn, n, plans=table.reshape(len(table), 26, 26), seed=seed, env_id_base=base, total_step=total_step,
+                        obs_dtype=torch.float32 if f32 else torch.float64, **kw)
+    orc = helpers.oracle().OracleBatch(2, dyn, n, table, seed=seed, env_id_base=base)
+    if total_step:
+        orc.set_total_step(total_step)
+    orc.configure(obs_norm={None: dyn, "raw": False, "norm": True}[env.obs_scalars], frame=env.frame_value, tail=env.obs_tail)
+    assert orc.obs_dim == env.obs_dim
+    o = orc.reset()
+    assert env.reset().cpu().numpy().tobytes() == (o.astype(np.float32) if f32 else o).tobytes()
+    return env, orc
+
+
+VARIANTS = [dict(layout="lnet2d"), dict(obs_tail=("record",)), dict(obs_tail=("position", "record"), obs_scalars="raw", frame_value=2), dict(obs_tail=("position",)),
+            dict(obs_scalars="raw"), dict(obs_scalars="norm")]
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
+@pytest.mark.parametrize("n", [6148 + 36, N2 + 128 + 36])
+@pytest.mark.parametrize("kw", VARIANTS, ids=["lnet2d", "record", "pos_record_raw_f2", "position", "raw", "norm"])
+def test_variant_rows_without_the_plan_tail(kw, n, dyn, f32):
+    """Rows of 51 / 53 / 59 / 61 values on blocks of 64 envs (6184 envs: a last block of 40) and of 128 envs (16 548: a last block of 36);
+    launches of 1, 2 and 37 steps with a time limit of 30."""
+    if kw == dict(obs_scalars="norm" if dyn else "raw"):
+        pytest.skip("the canonical layout of this class")
+    env, orc = _vpair(dyn, n, 5, kw, total_step=30, f32=f32, base=11)
+    t0 = 0
+    for T in (1, 2, 37):
+        _compare(env, orc, T, t0, f32)
+        t0 += T
+    _end_state(env, orc)
+    _compare(env, orc, 3, t0, f32)
+
+
+@pytest.mark.parametrize("n,kernel", [(6144, "k_rollout2dt"), (6148, "k_rollout2db"), (16384, "k_rollout2db"), (32768, "k_rollout2db"), (32772, "k_rollout2d")])
+def test_variant_rows_either_side_of_the_thresholds(n, kernel):
+    import torch
+
+    env, orc = _vpair(True, n, 6, dict(obs_tail=("record",)), total_step=7)
+    og, rg, dg = env.rollout(12)
+    assert _kernel() == kernel
+    oc, rc, dc = orc.rollout(12, t0=0, nthreads=16)
+    assert og.cpu().numpy().tobytes() == oc.tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes()
+    assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+    _end_state(env, orc)
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+def test_variant_rows_tile_major_explicit_inputs_and_the_tile_kernel(f32):
+    import torch
+
+    n, T = N2 + 100, 33
+    dt = torch.float32 if f32 else torch.float64
+    a, orc = _vpair(True, n, 4, dict(obs_tail=("position", "record"), obs_scalars="raw", frame_value=2), total_step=20, f32=f32)
+    b = a.fork(torch.arange(n, device=a.device))
+    rng = np.random.default_rng(5)
+    acts, ks = rng.integers(0, 5, size=(T, n)).astype(np.int8), rng.integers(1, 4, size=(T, n)).astype(np.int8)
+    ta, tk = torch.from_numpy(acts).cuda(), torch.from_numpy(ks).cuda()
+    ot, rt, dtt = a.rollout(T, obs="tiled", actions=ta, step_size=tk)
+    assert _kernel() == "k_rollout2db"
+    raw = torch.empty(T * n * 61 + 1, dtype=dt, device=a.device)
+    ob, rwb, db = b.rollout(T, out=raw[1:].view(T, n, 61), actions=ta, step_size=tk)
+    assert ob.data_ptr() % 16 != 0 and _kernel() == "k_rollout"
+    assert torch.equal(a.untile(ot), ob) and torch.equal(rt, rwb) and torch.equal(dtt, db)
+    oc, rc, dc = orc.rollout(T, t0=0, actions=acts, step_size=ks, nthreads=16)
+    assert ob.cpu().numpy().tobytes() == (oc.astype(np.float32) if f32 else oc).tobytes()
+    assert torch.equal(a._hdr, b._hdr) and torch.equal(a._grid, b._grid) and torch.equal(a._stats, b._stats) and torch.equal(a._episode, b._episode)

@@ -306,7 +306,7 @@ def test_layout_variants(kw, f32):
     assert torch.equal(env.untile(ot), on)
 
 
-@pytest.mark.parametrize("n,kw,kern", [(6144, dict(obs_tail=("record",)), "k_rollout2dt"), (6148, dict(obs_tail=("record",)), "k_rollout"),
+@pytest.mark.parametrize("n,kw,kern", [(6144, dict(obs_tail=("record",)), "k_rollout2dt"), (6148, dict(obs_tail=("record",)), "k_rollout2db"),
                                        (49152, dict(layout="ppo"), "k_rollout2dt"), (49156, dict(layout="ppo"), "k_rollout2d"),
                                        (1002, dict(layout="ppo"), "k_rollout")], ids=str)
 def test_layout_variants_at_the_borders(n, kw, kern):

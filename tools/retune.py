@@ -22,7 +22,9 @@ import torch
 from snac_amd import BatchedDMPEnv, _lib
 kind, n, T, f32, layout, mode = %(kind)d, %(n)d, %(T)d, %(f32)d, %(layout)r, %(mode)r
 dt = torch.float32 if f32 else torch.float64
-e = BatchedDMPEnv(kind, True, n, seed=1, obs_dtype=dt, **({"layout": layout} if layout else {}))
+kw = {"layout": layout} if layout else {}
+if os.environ.get("SNAC_RETUNE_TAIL"): kw["obs_tail"] = tuple(os.environ["SNAC_RETUNE_TAIL"].split(","))   # (tools/var2d_time.py: rows with a tail)
+e = BatchedDMPEnv(kind, layout != "lnet2d", n, seed=1, obs_dtype=dt, **kw)
 e.reset()
 def timed(fn, reps):
     for _ in range(max(3, reps // 3)): fn()
