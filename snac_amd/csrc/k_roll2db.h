@@ -445,7 +445,10 @@ void launch_roll2db_w(const KArgs& a, hipStream_t s) {
 
 template <bool DYN, typename OT, bool VAR>
 void launch_roll2db_n(const KArgs& a, int ns, hipStream_t s) {
-    if (ns == 2) launch_roll2db_w<DYN, OT, 2, VAR>(a, s);
+    if constexpr (!VAR) {
+        if (ns == 4) { launch_roll2db_w<DYN, OT, 4, VAR>(a, s); return; }
+    }
+    if (ns >= 2) launch_roll2db_w<DYN, OT, 2, VAR>(a, s);
     else launch_roll2db_w<DYN, OT, 1, VAR>(a, s);
 }
 

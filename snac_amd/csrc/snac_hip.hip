@@ -129,6 +129,8 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_2D_BLOCK_VAR_MIN*/ {"SNAC_2D_BLOCK_VAR_MIN", 6148, "2D rollouts with a layout variant without the plan tail (51-61 values) on k_rollout2db from this many envs (up to 6144: k_rollout2dt; 59-value rows at 6144 envs 0.56 against 0.63 ms, 4096: 0.55 / 0.42; r05_2d_block.txt) ..."},
     /* TN_2D_BLOCK_VAR_MAX*/ {"SNAC_2D_BLOCK_VAR_MAX", 32768, "... up to this many (32 768: 1.36 against the tile kernel's 5.92 ms; above: k_rollout2d, 49 152: 2.47 / 2.54, 65 536: 2.70 / 2.56)"},
     /* TN_2D_BLOCK_VAR_TWO*/ {"SNAC_2D_BLOCK_VAR_TWO", 16385, "the variant rows on blocks of 128 envs from this many envs (16 384 envs, L-Net rows: 0.92 ms on 128 blocks of 128 against the tile kernel's 0.82)"},
+    /* TN_2D_BLOCK_FOUR_F64*/ {"SNAC_2D_BLOCK_FOUR_MAX_F64", 38912, "canonical float64 rows above SNAC_2D_BLOCK_MAX_F64 and up to this many envs: k_rollout2db with blocks of 256 envs (four stepper waves; 34 816 envs: 1.35 against k_rollout2d's 1.53 ms, 36 864: 1.46 / 1.53, 40 960: 1.55 / 1.54; 0: never)"},
+    /* TN_2D_BLOCK_FOUR_F32*/ {"SNAC_2D_BLOCK_FOUR_MAX_F32", 45056, "the same, float32 rows (36 864 envs: 0.75 against 0.82 ms, 40 960: 0.77 / 0.83, 49 152: 0.91 / 0.88)"},
 };
 
 int tune(int id) {
@@ -173,7 +175,8 @@ bool roll3db_ok(const KArgs& a, bool f32) {
 bool roll2db_ok(const KArgs& a, bool f32) {
     if (tune(TN_2D_BLOCK) == 0 || !every_row(a) || !pieces16(a) || pipeline_off()) return false;
     if (a.variant) return !(a.tail & SNAC_TAIL_PLAN) && a.n >= tune(TN_2D_BLOCK_VAR_MIN) && a.n <= tune(TN_2D_BLOCK_VAR_MAX);   // k_roll2dbv.hip
-    return a.n >= tune(f32 ? TN_2D_BLOCK_MIN_F32 : TN_2D_BLOCK_MIN_F64) && a.n <= tune(f32 ? TN_2D_BLOCK_MAX_F32 : TN_2D_BLOCK_MAX_F64);
+    return a.n >= tune(f32 ? TN_2D_BLOCK_MIN_F32 : TN_2D_BLOCK_MIN_F64) &&
+           a.n <= std::max(tune(f32 ? TN_2D_BLOCK_MAX_F32 : TN_2D_BLOCK_MAX_F64), tune(f32 ? TN_2D_BLOCK_FOUR_F32 : TN_2D_BLOCK_FOUR_F64));
 }
 
 // the headline kernel k_rollout2d: tiles of 64 envs, every row written, 16-byte pieces
@@ -237,7 +240,9 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             if (op == OP_TRANSITION && !a.variant && !pipeline_off()) { g_kernel = "k_transition2d"; launch_trans2d(d, a, s); break; }
             if (op == OP_ROLLOUT && roll2db_ok(a, d->obs_dtype == SNAC_OBS_F32)) {
                 g_kernel = "k_rollout2db";
-                const int steppers = a.n >= tune(a.variant ? TN_2D_BLOCK_VAR_TWO : (d->obs_dtype == SNAC_OBS_F32 ? TN_2D_BLOCK_TWO_F32 : TN_2D_BLOCK_TWO_F64)) ? 2 : 1;
+                const bool f32 = d->obs_dtype == SNAC_OBS_F32;
+                int steppers = a.n >= tune(a.variant ? TN_2D_BLOCK_VAR_TWO : (f32 ? TN_2D_BLOCK_TWO_F32 : TN_2D_BLOCK_TWO_F64)) ? 2 : 1;
+                if (!a.variant && a.n > tune(f32 ? TN_2D_BLOCK_MAX_F32 : TN_2D_BLOCK_MAX_F64)) steppers = 4;   // (up to SNAC_2D_BLOCK_FOUR_MAX_*: roll2db_ok)
                 if (a.variant) launch_roll2dbv(d, a, steppers, s); else launch_roll2db(d, a, steppers, s);
                 break;
             }

@@ -1,7 +1,7 @@
 """GPU: the block-cooperative 2D rollout kernel (k_rollout2db, round 5: per 64 envs a stepper wave -- lane = env, the boards its alone --
 that publishes each tick's window codes, scalar slots, reward and done, and eight writer waves that assemble and store the rows; blocks of
-64 envs with one stepper below 16 384 envs, of 128 envs with two steppers from there) against the CPU oracle.  It takes the canonical
-2D rollouts of 11 264 .. 32 768 envs (float32 rows: 15 360 .. 32 768; N % 4 = 0, 16-byte aligned output) that write every row: full
+64 envs with one stepper below 16 384 envs, of 128 envs with two steppers up to 32 768, of 256 envs with four above) against the CPU oracle.
+It takes the canonical 2D rollouts of 11 264 .. 38 912 envs (float32 rows: 15 360 .. 45 056; N % 4 = 0, 16-byte aligned output) that write every row: full
 blocks and ragged last blocks (a last stepper without envs, a last writer with 4 rows), float64 and float32 rows, dataset and static plans,
 [T][N][D] and tile-major outputs, launches of 1 / 2 / 37 steps, explicit actions / step sizes, the `>` rule bits, time limits of 1 .. 3,
 the record outputs -- and, bit for bit, what the tile kernel writes for the same batch (an unaligned output selects it).  The layout variants
@@ -67,11 +67,12 @@ def _end_state(env, orc):
 
 @pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
 @pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
-@pytest.mark.parametrize("n", [N1 + 3072, N1 + 3072 + 36, N2 + 128 + 36, N2 + 128 + 68, N2 + 4])
+@pytest.mark.parametrize("n", [N1 + 3072, N1 + 3072 + 36, N2 + 128 + 36, N2 + 128 + 68, N2 + 4, 32768 + 256 + 36, 32768 + 256 + 200])
 def test_blocks_dtypes_and_launch_lengths(dyn, n, f32):
     """15 360 envs: full blocks of 64; + 36: a last block of 36 envs (four full writer waves, one with 4 envs, three idle).  16 548 envs:
     blocks of 128 envs with a last block of 36 (its second stepper has no envs); + 32: a last block of 68 (the second stepper has 4);
-    16 388: a last block of 4 envs.  Launches of 1, 2 and 37 steps with a time limit of 30: every launch of 37 has envs that start over."""
+    16 388: a last block of 4 envs; 33 060 / 33 224 envs: blocks of 256 envs (four steppers) with a last block of 36 (three steppers without
+    envs) / of 200 (the fourth stepper has 8).  Launches of 1, 2 and 37 steps with a time limit of 30: every launch of 37 has envs that start over."""
     env, orc = _pair(dyn, n, seed=5, f32=f32, base=11, total_step=30)
     t0 = 0
     for T in (1, 2, 37):

@@ -116,7 +116,7 @@ def test_a_whole_episode_of_float32_rows():
 
 BORDERS = [
     # n, float32 rows, kernel of the canonical output, kernel of an output that is not 16-byte aligned.  From 11 264 envs (float32: 15 360) to
-    # 32 768 the canonical rows are k_rollout2db's (round 5: blocks of 64 envs, of 128 from 16 384 / 16 385): tests/test_gpu_rollout2d_block.py
+    # 38 912 (45 056) the canonical rows are k_rollout2db's (round 5: blocks of 64 envs, of 128 from 16 384 / 16 385, of 256 above 32 768): tests/test_gpu_rollout2d_block.py
     (8191, False, "k_rollout2dt", "k_rollout2dt"),                  # odd N: element by element, still this kernel up to 8192
     (8193, False, "k_rollout", "k_rollout"),
     (8200, True, "k_rollout2dt", "k_rollout"),                      # whole pieces / an unaligned output of more than 8192 envs
@@ -125,10 +125,11 @@ BORDERS = [
     (11266, False, "k_rollout2dt", "k_rollout"),                    # N % 4 != 0: not the block kernel's
     (15356, True, "k_rollout2dt", "k_rollout"),
     (15360, True, "k_rollout2db", "k_rollout"),
-    (32768, False, "k_rollout2db", "k_rollout"),
-    (32772, False, "k_rollout2d", "k_rollout"),
-    (32768, True, "k_rollout2db", "k_rollout"),
-    (32772, True, "k_rollout2d", "k_rollout"),
+    (32768, False, "k_rollout2db", "k_rollout"),                    # blocks of 128 envs
+    (32772, False, "k_rollout2db", "k_rollout"),                    # ... of 256 envs, up to 38 912 (float32: 45 056)
+    (38916, False, "k_rollout2d", "k_rollout"),
+    (45056, True, "k_rollout2db", "k_rollout"),
+    (45060, True, "k_rollout2d", "k_rollout"),
 ]
 
 

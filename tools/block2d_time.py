@@ -1,4 +1,4 @@
-"""2D rollouts of the middle batches: k_rollout2db with one / two stepper waves per block against what the table would otherwise pick
+"""2D rollouts of the middle batches: k_rollout2db with one / two / four stepper waves per block against what the table would otherwise pick
 (k_rollout2dt, the tile kernel, k_rollout2d), whole episodes (600 ticks) into trajectory memory; one subprocess per arm (tools/retune.py's worker).
 
     gpurun -- python tools/block2d_time.py [f32] [N ...]
@@ -8,9 +8,11 @@ import sys
 import retune
 
 ARMS = [("64-env blocks", {"SNAC_2D_BLOCK_MIN_F64": "4", "SNAC_2D_BLOCK_MAX_F64": "100000000", "SNAC_2D_BLOCK_TWO_F64": "100000000",
-                           "SNAC_2D_BLOCK_MIN_F32": "4", "SNAC_2D_BLOCK_MAX_F32": "100000000", "SNAC_2D_BLOCK_TWO_F32": "100000000"}),
+                           "SNAC_2D_BLOCK_MIN_F32": "4", "SNAC_2D_BLOCK_MAX_F32": "100000000", "SNAC_2D_BLOCK_TWO_F32": "100000000", "SNAC_2D_BLOCK_FOUR_MAX_F64": "0", "SNAC_2D_BLOCK_FOUR_MAX_F32": "0"}),
         ("128-env blocks", {"SNAC_2D_BLOCK_MIN_F64": "4", "SNAC_2D_BLOCK_MAX_F64": "100000000", "SNAC_2D_BLOCK_TWO_F64": "4",
-                            "SNAC_2D_BLOCK_MIN_F32": "4", "SNAC_2D_BLOCK_MAX_F32": "100000000", "SNAC_2D_BLOCK_TWO_F32": "4"}),
+                            "SNAC_2D_BLOCK_MIN_F32": "4", "SNAC_2D_BLOCK_MAX_F32": "100000000", "SNAC_2D_BLOCK_TWO_F32": "4", "SNAC_2D_BLOCK_FOUR_MAX_F64": "0", "SNAC_2D_BLOCK_FOUR_MAX_F32": "0"}),
+        ("256-env blocks", {"SNAC_2D_BLOCK_MIN_F64": "4", "SNAC_2D_BLOCK_MAX_F64": "3", "SNAC_2D_BLOCK_FOUR_MAX_F64": "100000000",
+                            "SNAC_2D_BLOCK_MIN_F32": "4", "SNAC_2D_BLOCK_MAX_F32": "3", "SNAC_2D_BLOCK_FOUR_MAX_F32": "100000000"}),
         ("without k_rollout2db", {"SNAC_2D_BLOCK": "0"})]
 
 
