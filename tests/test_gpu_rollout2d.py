@@ -67,10 +67,11 @@ def test_tiles_dtypes_and_launch_lengths(dyn, n, f32):
     _compare(env, orc, 3, t0, f32)                                # the records written back by the launches above carry on
 
 
-@pytest.mark.parametrize("n", [32768 + 36, 49152 + 4])
+@pytest.mark.parametrize("n", [45056 + 36, 49152 + 4])
 @pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
 def test_the_staged_kernel_from_32769_envs(dyn, n):
-    """Above 32 768 envs both row types take the staged kernel (float32 rows from 32 768 on; round 3: float64 only from 65 536) --
+    """Above 45 056 envs both row types take the staged kernel (round 4: from 32 769 / 32 768 envs; since round 5 the block kernel k_rollout2db
+    has the batches up to 38 912 / 45 056 envs, tests/test_gpu_rollout2d_block.py; round 3: float64 only from 65 536) --
     float32 and float64 rows of the same batch against the oracle and against each other, a ragged last tile, the tile-major output."""
     import torch
     from snac_amd import _lib
