@@ -1,4 +1,4 @@
-// k_roll2db.h -- k_rollout2db: 2D rollouts by blocks of 64 / 128 envs (round 5; the kernel: instantiated by k_roll2db.hip for the canonical
+// k_roll2db.h -- k_rollout2db: 2D rollouts by blocks of 64 / 128 / 256 envs (round 5; the kernel: instantiated by k_roll2db.hip for the canonical
 // rows and by k_roll2dbv.hip for the layout variants without the plan tail)
 #pragma once
 #include "snac_dev.h"
@@ -19,12 +19,12 @@ namespace {
 //       (the record outputs of snac_rollout_rec excepted);
 //   waves 1-8, the writers (8 envs each): behind the tick's barrier every lane assembles its 16-byte pieces of the wave's 8 rows -- value
 //       g of the slice is element g % 51 of env g / 51, and WHERE that is in the publication never changes: a dword and a bit offset per
-//       value, fixed per lane (one ds_read_b32 + v_bfe_i32 + a conversion per window cell; the 16 scalar slots of a wave as a short list)
-//       -- and stores them: 8 x 408 bytes as one run, 16 bytes per lane; the tick's reward / done runs by two of the writers.
+//       value, fixed per lane (one ds_read_b32 + v_bfe_i32 + a conversion per window cell; the pieces that hold a scalar slot in a store
+//       instruction of their own) -- and stores them: 8 x 408 bytes as one run, 16 bytes per lane; the tick's reward / done runs by two of the writers.
 // ONE barrier per tick: the stepper computes tick t + 1 into the other half while the writers write tick t; the barrier after that finds
 // the writers done with the half the stepper takes next.
-// Semantics are K2D::step's as k_rollout2d formulates them.  Conditions: every row written (SNAC_OBS_ALL / SNAC_OBS_TILED), canonical
-// layout, N % 4 = 0 and a 16-byte aligned output; the dispatch table's SNAC_2D_BLOCK_* entries say for which N.
+// Semantics are K2D::step's as k_rollout2d formulates them.  Conditions: every row written (SNAC_OBS_ALL / SNAC_OBS_TILED), the canonical
+// layout or a variant without the plan tail (VAR below), N % 4 = 0 and a 16-byte aligned output; the dispatch table's SNAC_2D_BLOCK_* entries say for which N.
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -35,7 +35,7 @@ constexpr int special_pieces(int rows, int VP) {
     return c;
 }
 
-// NS: stepper waves per block (1: 64 envs, 2: 128 envs -- two steppers of ONE block sit on different SIMDs, the steppers of two
+// NS: stepper waves per block (1: 64 envs, 2: 128 envs, 4: 256 envs for the batches just above 32 768 envs -- two steppers of ONE block sit on different SIMDs, the steppers of two
 // co-resident blocks need not: with 257 .. 511 blocks of 64 envs the CUs that hold two of them decide the launch, and those run their
 // two steppers' ~150 instructions a tick -- 64-bit shifts, the RNG's multiplies -- one after the other when they share a SIMD: 20 480 envs
 // 0.94 ms on 320 blocks of 64 envs, as slow as the tile kernel).  Eight writer waves either way: 8 NS envs each.
