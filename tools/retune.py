@@ -50,12 +50,13 @@ print(json.dumps({"ms": ms, "kernel": _lib.lib().snac_last_kernel().decode()}))
 # (name of the table entry that holds the crossover, what is compared, workload, env of arm A, env of arm B, direction, batch sizes)
 #   direction "max": kernel A is used UP TO the entry's value; "min": kernel A is used FROM the entry's value
 CROSSOVERS = [
+    # (the three entries below order the kernels BEHIND k_rollout2db: both arms run with SNAC_2D_BLOCK=0)
     ("SNAC_2D_TP_MAX_F64", "k_rollout2dt | tile kernel / k_rollout2d, 2D float64 rows", dict(kind=2, T=0, f32=0, layout=None, mode="rollout"),
-     {"SNAC_2D_TP_MAX": "10000000"}, {"SNAC_2D_TP": "0"}, "max", [12288, 14336, 16384, 18432, 20480, 24576, 28672]),
+     {"SNAC_2D_TP_MAX": "10000000", "SNAC_2D_BLOCK": "0"}, {"SNAC_2D_TP": "0", "SNAC_2D_BLOCK": "0"}, "max", [12288, 14336, 16384, 18432, 20480, 24576, 28672]),
     ("SNAC_2D_TP_MAX_F32", "k_rollout2dt | tile kernel / k_rollout2d, 2D float32 rows", dict(kind=2, T=0, f32=1, layout=None, mode="rollout"),
-     {"SNAC_2D_TP_MAX": "10000000"}, {"SNAC_2D_TP": "0"}, "max", [20480, 24576, 28672, 30720, 32768, 40960]),
+     {"SNAC_2D_TP_MAX": "10000000", "SNAC_2D_BLOCK": "0"}, {"SNAC_2D_TP": "0", "SNAC_2D_BLOCK": "0"}, "max", [20480, 24576, 28672, 30720, 32768, 40960]),
     ("SNAC_2D_STAGE_MIN_F64", "k_rollout2d | tile kernel, 2D float64 rows", dict(kind=2, T=0, f32=0, layout=None, mode="rollout"),
-     {"SNAC_2D_STAGE_MIN": "1", "SNAC_2D_TP": "0"}, {"SNAC_2D_STAGE": "0", "SNAC_2D_TP": "0"}, "min", [24576, 28672, 32768, 36864, 40960, 49152]),
+     {"SNAC_2D_STAGE_MIN": "1", "SNAC_2D_TP": "0", "SNAC_2D_BLOCK": "0"}, {"SNAC_2D_STAGE": "0", "SNAC_2D_TP": "0", "SNAC_2D_BLOCK": "0"}, "min", [24576, 28672, 32768, 36864, 40960, 49152]),
     ("SNAC_1D_TP_MAX_F64", "k_rollout1dt | tile kernel, 1D float64 rows", dict(kind=1, T=0, f32=0, layout=None, mode="rollout"),
      {"SNAC_1D_TP_MAX": "10000000"}, {"SNAC_1D_TP": "0"}, "max", [32768, 40960, 49152, 57344, 65536, 81920]),
     ("SNAC_3D_BLOCK_MIN_F64", "k_rollout3db | k_rollout3d, 3D float64 rows", dict(kind=3, T=0, f32=0, layout=None, mode="rollout"),
