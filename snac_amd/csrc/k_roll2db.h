@@ -51,12 +51,16 @@ __global__ __launch_bounds__((NS + 8) * 64) void k_rollout2db(const KArgs a) {
     constexpr int IMG_WORDS = 26 * RS * 2;
     __shared__ __attribute__((aligned(16))) uint32_t img_all[NS * IMG_WORDS]; // per stepper: the bordered two-bit image, 26 rows x 65 x 8 B (its alone)
     __shared__ uint32_t pl_all[NS * GE * 65];                                  // per stepper: the lanes' plan rows [20][65]
-    __shared__ __attribute__((aligned(16))) uint4 spw[2][BE];                  // window rows 0|1, 2|3, 4|5, 6 as 14-bit codes, two per dword
+    // TB ticks per barrier: the stepper publishes TB ticks into one half of the buffers below, then the barrier; the writers take them in turn
+    // (float32 rows, where a launch is mostly the tick's floor: 20 480 envs 0.509 -> 0.461 ms with TB = 4; float64 rows are bound by the HBM rate from
+    // 16 384 envs and lost 3-6 % to the burstier stores: TB = 1)
+    constexpr int TB = (sizeof(OT) == 4 && NS <= 2) ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) uint4 spw[2 * TB][BE];                  // window rows 0|1, 2|3, 4|5, 6 as 14-bit codes, two per dword
     // per parity: the two scalar slots of every env (8-byte slots 0 .. 2 BE - 1); VAR: then reward, done, row, column, count_brick,
     // count_step, total_brick, plan row of every env as int32 pairs (slots 2 BE + 4 env ..)
-    __shared__ __attribute__((aligned(16))) double ssc[2][VAR ? 6 * BE : 2 * BE];
-    __shared__ float srew[2][BE];
-    __shared__ __attribute__((aligned(16))) uint8_t sdone[2][BE];
+    __shared__ __attribute__((aligned(16))) double ssc[2 * TB][VAR ? 6 * BE : 2 * BE];
+    __shared__ float srew[2 * TB][BE];
+    __shared__ __attribute__((aligned(16))) uint8_t sdone[2 * TB][BE];
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int chunk = ((int)gridDim.x + 7) >> 3;                     // an XCD takes a contiguous eighth of the envs
     const int blk = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
@@ -114,7 +118,7 @@ __global__ __launch_bounds__((NS + 8) * 64) void k_rollout2db(const KArgs a) {
         uint64_t w_pf = cells[s.r * RS + lane];
         uint32_t pl_pf = pl[(s.r - 3) * 65 + lane];
         for (int t = 0; t < a.T; ++t) {
-            const int par = t & 1;
+            const int par = ((t / TB) & 1) * TB + t % TB;           // which of the 2 x TB tick buffers
             const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
             if (__builtin_expect(__any(nr), 0)) {                    // rare, out of line
                 bool fresh = false;                                  // a new plan row (K2D::reset: it brings its total_brick; the same row keeps the header's)
@@ -225,7 +229,7 @@ __global__ __launch_bounds__((NS + 8) * 64) void k_rollout2db(const KArgs a) {
                 act = act_n; k = k_n;
                 load_inputs(t + 2, act_n, k_n);
             }
-            lds_barrier();                                           // tick t is published; the writers are done with tick t - 1
+            if (t % TB == TB - 1 || t == a.T - 1) lds_barrier();     // this group of ticks is published; the writers are done with the group before
         }
         K::store_grid(img, a, env0, nenv, lane);
         if (active) {
@@ -294,8 +298,8 @@ __global__ __launch_bounds__((NS + 8) * 64) void k_rollout2db(const KArgs a) {
         const int npieces = rows * ROWBV / 16;
         const int fv = a.frame_val;
         for (int t = 0; t < a.T; ++t) {
-            const int par = t & 1;
-            lds_barrier();
+            const int par = ((t / TB) & 1) * TB + t % TB;           // which of the 2 x TB tick buffers
+            if (t % TB == 0) lds_barrier();
             char* const g = obs0 + (size_t)t * tstride;
             const char* const wb = (const char*)spw[par];
             const char* const sb = (const char*)ssc[par];
@@ -398,8 +402,8 @@ __global__ __launch_bounds__((NS + 8) * 64) void k_rollout2db(const KArgs a) {
     }
     const int npieces = rows * ROWB / 16;
     for (int t = 0; t < a.T; ++t) {
-        const int par = t & 1;
-        lds_barrier();
+        const int par = ((t / TB) & 1) * TB + t % TB;
+        if (t % TB == 0) lds_barrier();
         char* const g = obs0 + (size_t)t * tstride;
         const char* const wb = (const char*)spw[par];
         const char* const scs = (const char*)ssc[par];
