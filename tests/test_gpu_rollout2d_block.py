@@ -213,6 +213,30 @@ def test_replay_rings_filled_by_the_block_kernel():
         assert a.obs_at(slot).cpu().numpy().tobytes() == oc[i].tobytes(), i
 
 
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("P", [2000, 32767])
+def test_generated_plan_tables_of_any_size(P, f32):
+    """Tables from generate_plans() (2000 rows; 32 767: the rows then miss the scalar cache): a time limit of 25, so every env picks a new row
+    of the big table in every launch of 37 -- the stepper fetches it through the scalar cache; blocks of 128 envs, a ragged last block."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    n = N2 + 3072 + 36
+    env = BatchedDMPEnv(2, True, n, plans=np.zeros((P, 26, 26)), seed=8, total_step=25, obs_dtype=torch.float32 if f32 else torch.float64)
+    env.generate_plans(0, P, sparse=False, seed=77, id_base=5)
+    env._sync_plans_full()
+    orc = helpers.oracle().OracleBatch(2, True, n, env.plans_full.reshape(P, -1).astype(np.int32), seed=8)
+    orc.set_total_step(25)
+    o = orc.reset()
+    assert env.reset().cpu().numpy().tobytes() == (o.astype(np.float32) if f32 else o).tobytes()
+    t0 = 0
+    for T in (1, 37, 2):
+        _compare(env, orc, T, t0, f32)
+        t0 += T
+    _end_state(env, orc)
+    assert len(set(env.plan_idx.cpu().numpy().tolist())) > min(P, 400) // 2   # the batch really draws from all over the table
+
+
 # ---- the layout variants without the plan tail (k_roll2dbv.hip)
 def _vpair(dyn, n, seed, kw, total_step=None, f32=False, base=0):
     import torch
