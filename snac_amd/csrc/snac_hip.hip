@@ -3,6 +3,7 @@
 #include "snac_dev.h"
 
 namespace snac_detail {
+void launch_step3dq(const snac_env_desc* d, const KArgs& a, hipStream_t s);                   // k_step3dq.hip
 void launch_roll2db(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);   // k_roll2db.hip
 void launch_roll2dbv(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);  // k_roll2dbv.hip: the same kernel for the layout variants: k_rollout2db (declared here for the same reason as the next one)
 void launch_roll3dbv(const snac_env_desc* d, const KArgs& a, hipStream_t s);   // k_roll3dbv.hip: k_rollout3db for the layout variants (declared here: snac_dev.h is hashed into profiles/traffic.json)
@@ -131,6 +132,9 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_2D_BLOCK_VAR_TWO*/ {"SNAC_2D_BLOCK_VAR_TWO", 16385, "the variant rows on blocks of 128 envs from this many envs (16 384 envs, L-Net rows: 0.92 ms on 128 blocks of 128 against the tile kernel's 0.82)"},
     /* TN_2D_BLOCK_FOUR_F64*/ {"SNAC_2D_BLOCK_FOUR_MAX_F64", 38912, "canonical float64 rows above SNAC_2D_BLOCK_MAX_F64 and up to this many envs: k_rollout2db with blocks of 256 envs (four stepper waves; 34 816 envs: 1.35 against k_rollout2d's 1.53 ms, 36 864: 1.46 / 1.53, 40 960: 1.55 / 1.54; 0: never)"},
     /* TN_2D_BLOCK_FOUR_F32*/ {"SNAC_2D_BLOCK_FOUR_MAX_F32", 45056, "the same, float32 rows (36 864 envs: 0.75 against 0.82 ms, 40 960: 0.77 / 0.83, 49 152: 0.91 / 0.88)"},
+    /* TN_STEP3D_QUARTER  */ {"SNAC_STEP3D_QUARTER", 1, "0: the canonical 3D snac_step stays on k_step3d / k_step3ds instead of k_step3dq (16 envs per wave, four lanes per env)"},
+    /* TN_STEP3D_QUARTER_MIN*/ {"SNAC_STEP3D_QUARTER_MIN", 4, "k_step3dq from this many envs (1024: 6.9 against k_step3d's 8.0 us per tick, 32 768: 9.5 / 11.5, 65 536: 13.1 / 14.1; r05_step3dq.txt) ..."},
+    /* TN_STEP3D_QUARTER_MAX*/ {"SNAC_STEP3D_QUARTER_MAX", 1 << 30, "... up to this many (524 288: 67.5 against k_step3ds' 76.6 us, 131 072: 23.9 / 23.6)"},
 };
 
 int tune(int id) {
@@ -256,6 +260,8 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
                 break;
             }
             if (op == OP_ROLLOUT && E == 8 && !a.variant && (a.obs_mode == SNAC_OBS_ALL || a.obs_mode == SNAC_OBS_TILED) && a.num_plans <= TB_MAX && !pipeline_off()) { g_kernel = "k_rollout3d"; launch_roll3d(d, a, s); break; }
+            if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && !a.variant && tune(TN_STEP3D_QUARTER) != 0 &&
+                a.n >= tune(TN_STEP3D_QUARTER_MIN) && a.n <= tune(TN_STEP3D_QUARTER_MAX)) { g_kernel = "k_step3dq"; launch_step3dq(d, a, s); break; }
             if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var3_ok(a))) {
                 const bool span = !a.variant && tune(TN_STEP3D_SPAN) != 0 && a.n >= tune(TN_STEP3D_SPAN_MIN);   // large batches of canonical rows
                 g_kernel = span ? "k_step3ds" : "k_step3d";

@@ -1,4 +1,9 @@
-"""GPU: k_step3ds (round 5) -- the canonical 3D snac_step of large batches with cooperative span loads (26 neighbouring lanes read the ten
+"""GPU: k_step3ds and k_step3d behind k_step3dq.  Since the end of round 5 the canonical 3D snac_step on identity rows takes k_step3dq
+(tests/test_gpu_step3dq.py) at every batch size; the two kernels it replaced stay as what SNAC_STEP3D_QUARTER=0 falls back to, and their
+tests run in ONE child process with that switch (and the span kernel's threshold lowered to 4 envs).  Below: what this file said when
+k_step3ds was the default for large batches.
+
+k_step3ds (round 5) -- the canonical 3D snac_step of large batches with cooperative span loads (26 neighbouring lanes read the ten
 rows a tick can need; pieces outside the rows / columns the tick can touch are not fetched; half a wave at a time through the staging tile).
 By default it takes batches of 81 920 envs and more (SNAC_STEP3D_SPAN_MIN); here: at its own batch sizes against the CPU oracle and against
 k_step3d's rows, and -- in ONE child process with the threshold lowered to 4 envs -- under every step test of the suite (ragged tiles,
@@ -14,10 +19,14 @@ import helpers
 
 pytestmark = pytest.mark.gpu
 
+INNER = os.environ.get("SNAC_TEST_STEP3DS_INNER") == "1"
+inner = pytest.mark.skipif(not INNER, reason="runs in the child process of test_every_step_test_of_the_suite_on_span_loads (SNAC_STEP3D_QUARTER=0)")
 
+
+@inner
 @pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
 @pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
-def test_large_batches_step_on_span_loads_like_the_oracle(dyn, f32):
+def test_inner_large_batches_step_on_span_loads_like_the_oracle(dyn, f32):
     """N = 98 304 + 36 (a ragged last tile of 36 envs): 45 ticks with auto-reset -- counter RNG, then explicit actions biased towards
     row moves (the side the extra rows of a span lie on) and builds -- rows, rewards, done flags and the end state against the oracle."""
     import torch
@@ -49,29 +58,14 @@ def test_large_batches_step_on_span_loads_like_the_oracle(dyn, f32):
     assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
 
 
-def test_both_step_kernels_write_the_same_rows_either_side_of_the_threshold():
-    """81 916 envs step on k_step3d, 81 920 on k_step3ds: a batch of 81 920 and its first 81 916 envs (same seeds, same global ids) walk the
-    same 30 ticks; rows, rewards, done flags and records agree on the common envs."""
-    import torch
-    from snac_amd import BatchedDMPEnv, _lib
-
-    big, small = BatchedDMPEnv(3, True, 81920, seed=5), BatchedDMPEnv(3, True, 81916, seed=5)
-    assert torch.equal(big.reset()[:81916], small.reset())
-    for t in range(30):
-        ob, rb, db = big.step(auto_reset=True)
-        kb = _lib.lib().snac_last_kernel()
-        os_, rs, ds = small.step(auto_reset=True)
-        assert (kb, _lib.lib().snac_last_kernel()) == (b"k_step3ds", b"k_step3d")
-        assert torch.equal(ob[:81916], os_) and torch.equal(rb[:81916], rs) and torch.equal(db[:81916], ds), t
-    assert torch.equal(big._hdr[:81916], small._hdr) and torch.equal(big._grid[:81916], small._grid)
-
-
 def test_every_step_test_of_the_suite_on_span_loads():
-    """One child process, SNAC_STEP3D_SPAN_MIN=4: the step tests of tests/test_gpu_step_tile.py and tests/test_gpu_property.py (3D cases)
-    with every 3D snac_step on identity rows taking k_step3ds."""
-    env = dict(os.environ)
-    env["SNAC_STEP3D_SPAN_MIN"] = "4"
-    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_step_tile.py", "tests/test_gpu_property.py", "-x", "-q", "-m", "gpu", "-k", "3 or property or dim"],
+    """One child process, SNAC_STEP3D_QUARTER=0 and SNAC_STEP3D_SPAN_MIN=4: the step tests of tests/test_gpu_step_tile.py and
+    tests/test_gpu_property.py (3D cases) and the large batches above, with every 3D snac_step on identity rows taking k_step3ds."""
+    if INNER:
+        pytest.skip("the child itself")
+    env = dict(os.environ, SNAC_STEP3D_SPAN_MIN="4", SNAC_STEP3D_QUARTER="0", SNAC_TEST_STEP3DS_INNER="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_step_tile.py", "tests/test_gpu_property.py", os.path.abspath(__file__), "-x", "-q", "-m", "gpu",
+                          "-k", "3 or property or dim or inner", "-p", "no:cacheprovider"],
                          cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
     assert " passed" in out.stdout
