@@ -64,9 +64,12 @@ def _free_port():
     return p
 
 
-def launch_ranks(n):
+def launch_ranks(n, script=None, argv=None):
     """Start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), forward rank 0's JSON line and
-    return the worst exit status.  This process has not initialised the GPU and never does."""
+    return the worst exit status.  This process has not initialised the GPU and never does.  (script / argv: the rank program and
+    its arguments, for tests/test_bench_launcher.py, which starts eight stand-in ranks on the CPU.)"""
+    script = script or os.path.abspath(__file__)
+    argv = sys.argv[1:] if argv is None else list(argv)
     port = _free_port()
     procs = []
     for r in range(n):
@@ -74,7 +77,7 @@ def launch_ranks(n):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd(),
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env, cwd=os.getcwd(),
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
     # rank 0 prints one short JSON line (far below the pipe buffer), so polling without draining cannot block it
     rc = 0
@@ -215,6 +218,68 @@ def cpu_baseline(kind, dynamic, n, T, seed):
                "are the C oracle behind ctypes, so this is an UPPER bound for that loop shape -- the reference's own pure-Python "
                "classes do 1.1-1.2e5 env-steps/s in it (BASELINE.md section 2)" % ticks)
     return best
+
+
+# ------------------------------------------------------------------------------------------------
+# the stdout line: compact, strict JSON, a few KB (tests/test_gpu_bench.py holds it below 6000 bytes)
+def _sig(x, digits=6):
+    """Floats to `digits` significant digits (recursively); NaN / inf -> None so the line stays strict JSON."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return str(x)
+
+
+EXTRA_COLS = ["kernel_or_path", "us", "frac"]
+
+
+def _extra_row(e):
+    """One extra configuration as [kernel or path, microseconds per launch / tick / call, fraction of the 8 TB/s peak or null]."""
+    if "kernel_ms" in e:
+        us = e["kernel_ms"] * 1e3
+    elif "us_per_tick" in e:
+        us = e["us_per_tick"]
+    elif "us_per_step" in e:
+        us = e["us_per_step"]
+    else:
+        us = e.get("us_per_vector_step")
+    name = e.get("kernel") or ("mailbox" if str(e.get("path", "")).startswith("mailbox") else "launch")
+    return [name, us, e.get("frac")]
+
+
+def compact_line(out, extra_file):
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "backend", "rccl_ranks", "collective_check", "rccl_async_exchanges", "retimed", "ranks", "kernel_ms_per_rank",
+            "trajectory_check", "trajectory_full_pass_check", "parity_vs_oracle", "ranks_on_distinct_devices", "episodic")
+    line = {k: out[k] for k in keep if k in out}
+    r = out["roofline"]
+    line["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "alg_bytes_per_env_step",
+                                          "peak_measured_write")}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": "C oracle, %d OpenMP threads, same workload, %s" % (cb["cores"], cb["sample"].split("thread(s), ", 1)[-1].split(" of the same", 1)[0]),
+                                "cpu_model": cb.get("cpu_model"), "cores_available": cb.get("cores_available"),
+                                "single_thread": {"value": (cb.get("single_thread") or {}).get("value")},
+                                "python_loop_n1024": {"value": (cb.get("python_loop_n1024") or {}).get("value")}}
+    cfgs = (out.get("extra") or {}).get("configs")
+    if isinstance(cfgs, dict) and "error" not in cfgs:
+        line["extra_cols"] = EXTRA_COLS
+        line["extra"] = {k: _extra_row(v) for k, v in cfgs.items()}
+    elif isinstance(cfgs, dict):
+        line["extra"] = cfgs
+    if isinstance(out.get("tiled_layout"), dict) and "kernel_ms" in out["tiled_layout"]:
+        line["tiled_layout_kernel_ms"] = out["tiled_layout"]["kernel_ms"]
+    line["timed_regions_ms_per_step"] = [t["ms_per_step"] for t in out.get("timed_regions", [])]   # both, when the region was retimed
+    line["extra_file"] = os.path.basename(extra_file) if extra_file else None
+    return _sig(line)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -417,6 +482,12 @@ def main():
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         gc.collect()                                                # (no collector pause of the host thread inside the timed region)
         gc.disable()
+        try:
+            return _timed_region_body(ev)
+        finally:
+            gc.enable()
+
+    def _timed_region_body(ev):
         sync()
         t0 = time.perf_counter()
         pending = []
@@ -442,7 +513,6 @@ def main():
             stats.copy_(pending[-1][1])
         sync()
         dt_ = time.perf_counter() - t0
-        gc.enable()
         dt_ = float(allreduce_(torch.tensor([dt_], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
         return dt_, [a.elapsed_time(b) for a, b in ev], len(pending)
 
@@ -974,7 +1044,18 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.kind, dynamic, n, T, 1)
-        print(json.dumps(out))
+        # The driver parses the LAST stdout line and keeps only a tail of stdout: the line stays a few KB (round 5's 22 KB line was
+        # cut and could not be parsed).  Everything else -- extras with their timing spreads, placement, per-rank accounts, timed
+        # regions -- goes to the side file, whose path the line names.
+        extra_file = os.environ.get("SNAC_BENCH_EXTRA_FILE") or os.path.join(ROOT, "bench_extra.json")
+        try:
+            with open(extra_file, "w") as fh:
+                json.dump(out, fh, indent=1)
+                fh.write("\n")
+        except OSError as e:
+            sys.stderr.write("bench.py: could not write %s (%r)\n" % (extra_file, e))
+            extra_file = None
+        print(json.dumps(compact_line(out, extra_file), separators=(",", ":"), allow_nan=False))
         sys.stdout.flush()
     if use_dist:
         dist.barrier()

@@ -17,15 +17,68 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "dtype", "data", "config", "roofline"}
 
 
+LINE_LIMIT = 6000                                                 # bytes: the driver keeps a tail of stdout and parses its last line
+
+
+def _strict(text):
+    def bad(c):
+        raise ValueError("non-standard JSON constant %r" % c)
+    return json.loads(text, parse_constant=bad)
+
+
+def _parse(stdout, extra_path):
+    """The bench contract on stdout: ONE JSON object, on the LAST line, strict JSON, a few KB, carrying the roofline fraction (and the
+    CPU baseline when the run timed one).  Returns the full account of the side file the line names, after checking that the line's
+    figures are that account's."""
+    rows = [ln for ln in stdout.splitlines() if ln.strip()]
+    lines = [ln for ln in rows if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    assert rows[-1] is lines[0], "the JSON object must be the last stdout line"
+    assert len(lines[0].encode()) < LINE_LIMIT, len(lines[0])
+    line = _strict(lines[0])
+    assert KEYS <= set(line)
+    assert isinstance(line["roofline"]["frac"], float) and 0 < line["roofline"]["frac"] < 1.0
+    assert line["extra_file"] == os.path.basename(extra_path)
+    with open(extra_path) as fh:
+        full = _strict(fh.read())
+    for k in ("metric", "n_gpus", "steps", "warmup", "scaling", "dtype", "config", "episodic", "ranks", "backend", "retimed",
+              "parity_vs_oracle", "trajectory_check"):
+        assert line[k] == full[k] or k == "episodic", k
+    for k in ("value", "ms_per_step"):
+        assert abs(line[k] - full[k]) <= 1e-5 * abs(full[k]), k
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5
+    assert ("cpu_baseline" in line) == ("cpu_baseline" in full)
+    if "cpu_baseline" in line:
+        cb = line["cpu_baseline"]
+        assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and cb["single_thread"]["value"] > 0
+    full["_line"] = line
+    return full
+
+
+def _bench(cmd, env, check=True):
+    import tempfile
+
+    e = dict(env)
+    fd, path = tempfile.mkstemp(prefix="snac_bench_", suffix=".json")
+    os.close(fd)
+    os.unlink(path)
+    e["SNAC_BENCH_EXTRA_FILE"] = path
+    try:
+        out = subprocess.run(cmd, cwd=helpers.ROOT, env=e, capture_output=True, text=True, timeout=900)
+        if not check:
+            return out, None
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out, _parse(out.stdout, path)
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
 def _run(cmd, env=None):
     e = dict(os.environ)
     e["SNAC_BENCH_RETIME"] = "0"                                  # (a retimed region runs K more passes: the episodic sums compared below would differ)
     e.update(env or {})
-    out = subprocess.run(cmd, cwd=helpers.ROOT, env=e, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    return _bench(cmd, e)[1]
 
 
 def _port():
@@ -66,11 +119,7 @@ def test_gpus_flag_starts_the_ranks_itself():
     env["SNAC_BENCH_BACKEND"] = "gloo"
     env["SNAC_BENCH_RETIME"] = "0"
     cmd = [sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--T", "120", "--no-cpu"]
-    out = subprocess.run(cmd + ["--gpus", "2", "--envs", "4096"], cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    two = json.loads(lines[0])
+    out, two = _bench(cmd + ["--gpus", "2", "--envs", "4096"], env)
     one = _run(cmd + ["--envs", "8192"])
     assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["backend"] == "gloo"
     assert two["episodic"] == one["episodic"]
@@ -78,21 +127,14 @@ def test_gpus_flag_starts_the_ranks_itself():
     assert two["extra"]["configs"] is None and two["tiled_layout"] is None          # N > 1: the headline only
     # four ranks (the GPU box admits six processes on its card: this test process, its launcher -- which never touches the GPU --
     # and four ranks; BASELINE config 4's eight ranks on one card would trip that guard, the 8-way split itself runs on CPU in
-    # tests/test_dist_gloo.py): 4 x 2048 envs == 1 x 8192, inside a wall-time bound that a per-rank start-up of seconds would break
-    import time
-
-    t0 = time.perf_counter()
-    out = subprocess.run(cmd + ["--gpus", "4", "--envs", "2048"], cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=900)
-    wall = time.perf_counter() - t0
-    assert out.returncode == 0, out.stderr[-2000:]
-    four = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    # tests/test_dist_gloo.py, the launcher's own eight-process form in tests/test_bench_launcher.py): 4 x 2048 envs == 1 x 8192
+    out, four = _bench(cmd + ["--gpus", "4", "--envs", "2048"], env)
     assert four["n_gpus"] == 4 and four["ranks"] == 4 and len(four["kernel_ms_per_rank"]) == 4 and len(four["ranks_devices"]) == 4
     assert four["episodic"] == one["episodic"] and four["config"]["env_steps_per_pass"] == 4 * 2048 * 120
-    assert wall < 240, wall
     # RCCL needs one GPU per rank: two RCCL ranks on a one-GPU box must fail loudly, not report a 1-GPU number
     if __import__("torch").cuda.device_count() == 1:
         env["SNAC_BENCH_BACKEND"] = "nccl"
-        bad = subprocess.run(cmd + ["--gpus", "2", "--envs", "4096"], cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=900)
+        bad, _ = _bench(cmd + ["--gpus", "2", "--envs", "4096"], env, check=False)
         assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
 
 
@@ -148,9 +190,7 @@ def test_bench_takes_its_rccl_path_with_one_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(SNAC_BENCH_FORCE_DIST="1", SNAC_BENCH_BACKEND="nccl", SNAC_BENCH_RETIME="0")
     cmd = [sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--envs", "8192", "--T", "120", "--no-cpu"]
-    out = subprocess.run(cmd, cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    forced = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    out, forced = _bench(cmd, env)
     assert forced["backend"] == "nccl" and forced["rccl_ranks"] == 1 and forced["ranks"] == 1 and forced["n_gpus"] == 1
     assert forced["collective_check"] is True and forced["rccl_async_exchanges"] == 4
     assert forced["ranks_on_distinct_devices"] is True and forced["parity_vs_oracle"] is True and forced["trajectory_check"] is True
