@@ -391,14 +391,21 @@ int snac_export_grid(const snac_env_desc* desc, const snac_state* st, double* ou
  * The reference's scripts drive ONE env, one env.step(action) per loop turn (script/DQN/2d/DQN_2d_dynamic.py:214;
  * Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:85-147 is 9 us of Python per step).  Through snac_step_scalar such a step is one launch and
  * one stream wait (15 us).  A mailbox keeps ONE wavefront resident instead: it polls a doorbell in coherent page-locked host memory,
- * steps the envs of a small batch (N = 1: the drop-in classes; up to 64: an env per lane) with the kind's own step rules, writes the observation row (obs_dim values of obs_dtype, layout of desc,
+ * steps the envs of a small batch (N = 1: the drop-in classes; up to 256: an env per lane, 64 envs per wavefront, a launch per wavefront) with the kind's own step rules, writes the observation row (obs_dim values of obs_dtype, layout of desc,
  * tails included) into the mailbox over the bus, acknowledges, and writes the env's state through to st behind the acknowledgement
  * (snac_mailbox_settle waits for that: call it before any other entry point reads or changes st).  The wave leaves by itself after idle_us microseconds without a command
  * (0 = 1000) and on snac_mailbox_quit / _destroy; snac_mailbox_step arms (launches) one when none is resident.
  *   snac_mailbox_touch   the caller has changed st through another entry point (reset, plan row, import ...) and has waited for it:
  *                        the wave reloads the records before its next step
  *   snac_mailbox_step    semantics of snac_step_scalar(desc, st, t, action, step_size, auto_reset = 0, row, NULL, NULL) + a wait;
- *                        episodic sums are updated like snac_step's.  SNAC_ERR_HIP if no acknowledgement arrives within 2 s
+ *                        episodic sums are updated like snac_step's.  A wave whose launch is still QUEUED (behind kernels that fill the
+ *                        device) is waited for, up to SNAC_MAILBOX_TIMEOUT_S seconds (default 120); then the command is WITHDRAWN
+ *                        (replaced by a quit of the same sequence number: a wave that starts later leaves without stepping) and the
+ *                        call returns SNAC_ERR_HIP with st as the last acknowledged step left it -- or SNAC_OK if the step was served
+ *                        while it was being withdrawn.  The mailbox belongs to the device that was current at snac_mailbox_create:
+ *                        its waves are launched there whatever is current later.  While a thread keeps stepping, a wave stays
+ *                        resident: a device-wide synchronisation (hipDeviceSynchronize, hipFree) in ANOTHER thread returns only once the
+ *                        stepping pauses for idle_us -- synchronise streams or events there instead
  *   snac_mailbox_row     the row (host pointer, valid until destroy; also a device pointer: the launch path may write it too)
  *   snac_mailbox_stats   out[0] launches, out[1] steps served, out[2] a wave is resident, out[3] idle_us, out[4..7] the last step in ticks of
  *                        the GPU's 100 MHz clock: transition, row stores issued, fence before the acknowledgement, write-through behind it */
@@ -407,7 +414,8 @@ int snac_mailbox_create(const snac_env_desc* desc, uint32_t idle_us, snac_mailbo
 double* snac_mailbox_row(snac_mailbox* mb);
 int snac_mailbox_touch(snac_mailbox* mb);
 int snac_mailbox_step(snac_mailbox* mb, const snac_env_desc* desc, const snac_state* st, int32_t action, int32_t step_size);
-/* the same for a batch of up to 64 envs (desc->num_envs <= 64: one wavefront, env e on lane e) -- the reference's VectorizedEnvWrapper
+/* the same for a batch of up to 256 envs (wavefront w takes envs [64 w, 64 w + 64), env 64 w + e on lane e; every wavefront is a launch
+ * of its own on a stream of its own and polls the same doorbell) -- the reference's VectorizedEnvWrapper
  * (multiprocess.py:15-32, default --num_envs 3): actions / step_size int8[num_envs] in host memory; rows [num_envs][obs_dim] in
  * snac_mailbox_row, rewards float[num_envs] in snac_mailbox_reward, done flags uint8[num_envs] in snac_mailbox_done */
 int snac_mailbox_step_n(snac_mailbox* mb, const snac_env_desc* desc, const snac_state* st, const int8_t* actions, const int8_t* step_size);

@@ -372,7 +372,16 @@ class BatchedDMPEnv:
         out / reward_out / done_out: optional preallocated outputs (done_out uint8).  record: optional dict of
         preallocated [T, N] tensors {"actions": int8, "step_size": int8, "plan_idx": int16, "first": uint8} that receive
         the action taken, the step size used, the plan row in effect and the first-step-of-episode flag of every env-step.
-        Returns (obs, reward [T, N] float32, done [T, N] bool)."""
+        Returns (obs, reward [T, N] float32, done [T, N] bool).
+
+        Memory: without `out=`, an observation tensor of 1 GiB or more comes from snac_amd.trajmem.cached_empty -- blocks of the HIP
+        virtual-memory API OUTSIDE torch's caching allocator (invisible to torch.cuda.memory_*, not released by empty_cache()): the
+        first request of a size builds a block (0.1-5 s; while it measures, its pool may hold up to SNAC_TRAJ_POOL_CAP_BYTES, default
+        64 GiB and never more than half of what is free, beyond the block), later ones recycle it; up to SNAC_TRAJ_CACHE_BYTES
+        (40 GiB per device) of free blocks are retained until trajmem.cache_trim() -- which this class calls by itself when torch
+        runs out of memory while allocating an output.  SNAC_TRAJ_CACHE=0 switches the cache off (torch.empty: one physical run,
+        5.7 instead of 7.0 TB/s for the headline's rows).  A recycled block is ordered behind its previous user's work on the stream
+        it was ALLOCATED on; a tensor used on another stream must be waited for before it is dropped (torch's record_stream rule)."""
         if not self._was_reset:
             raise _lib.SnacError("rollout() before reset()")
         N, T = self.num_envs, int(T)
@@ -394,11 +403,11 @@ class BatchedDMPEnv:
         if reward_out is not None:
             reward = self._buf(reward_out, (T, N), torch.float32, "reward_out")
         else:
-            reward = torch.empty((T, N), dtype=torch.float32, device=self.device) if want_reward else None
+            reward = self._empty((T, N), torch.float32) if want_reward else None
         if done_out is not None:
             done = self._buf(done_out, (T, N), torch.uint8, "done_out")
         else:
-            done = torch.empty((T, N), dtype=torch.uint8, device=self.device) if want_done else None
+            done = self._empty((T, N), torch.uint8) if want_done else None
         rec = None
         if record is not None:
             kinds = {"actions": torch.int8, "step_size": torch.int8, "plan_idx": torch.int16, "first": torch.uint8}
@@ -433,13 +442,26 @@ class BatchedDMPEnv:
                 from . import trajmem
 
                 if trajmem._cache_limit() > 0:
-                    return trajmem.cached_empty(shape, self.obs_dtype, self.device)
+                    return trajmem.cached_empty(shape, self.obs_dtype, self.device, pool_cap=trajmem.default_pool_cap())
             except (RuntimeError, OSError) as e:                    # SnacError is a RuntimeError: no such block on this box / out of ranges
                 import warnings
 
                 self._traj_failed = True
                 warnings.warn("rollout(): no trajectory block (%s); its outputs come from torch.empty from now on" % (e,))
-        return torch.empty(shape, dtype=self.obs_dtype, device=self.device)
+        return self._empty(shape, self.obs_dtype)
+
+    def _empty(self, shape, dtype):
+        """torch.empty on this batch's device; when torch is out of memory the free list of measured trajectory blocks (memory torch's
+        allocator cannot see or reclaim) is given back and the allocation tried once more."""
+        try:
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        except torch.cuda.OutOfMemoryError:
+            from . import trajmem
+
+            if trajmem.cache_trim(self.device.index) == 0:
+                raise
+            torch.cuda.empty_cache()
+            return torch.empty(shape, dtype=dtype, device=self.device)
 
     def alloc_trajectory(self, T, candidates=2, reps=3, layout="ticks", memory="vmm"):
         """The [T, N, obs_dim] output tensor of rollout(T, out=...), allocated where this batch's rollout writes fastest.  On
@@ -516,6 +538,8 @@ class BatchedDMPEnv:
                 ri = torch.as_tensor(rows, device=self.device).to(torch.int32).contiguous()
             m = int(ri.numel()) if ri is not None else src.num_envs
             mem, sstate, sn = None, C.byref(src._state), src.num_envs
+            src._settle()                                            # src's resident stepper writes its records through BEHIND the acknowledgement
+            # (src's launches must be on the current stream of this device, or waited for: the read below is ordered on that stream only)
         else:
             sz = self.sizes
             mem = torch.as_tensor(environment_memory, device=self.device).to(torch.float64).reshape(-1, sz.env_height, sz.env_width).contiguous()
@@ -534,7 +558,7 @@ class BatchedDMPEnv:
 
     # ---- the resident single-env stepper (snac_mailbox_*: what the drop-in classes step through) ------------------------------
     def mailbox_open(self, idle_us=0):
-        """N <= 64 (one wavefront, an env per lane; the drop-in classes: N = 1).  Creates the mailbox of this batch (coherent page-locked
+        """N <= 256 (up to four wavefronts, an env per lane; the drop-in classes: N = 1).  Creates the mailbox of this batch (coherent page-locked
         host memory + a stream of its own) and returns its rows: a host tensor [N, obs_dim] of obs_dtype that mailbox_step() /
         mailbox_step_n() fill -- and that reset_scalar() / step_scalar() accept as `out` (it is page-locked: the launch path writes it
         over the bus too).  A wavefront becomes resident at the first mailbox_step()
@@ -544,7 +568,8 @@ class BatchedDMPEnv:
         if self._mb is not None:
             return self._mb_row
         mb = C.c_void_p()
-        _lib.check(self._lib.snac_mailbox_create(C.byref(self._desc), int(idle_us), C.byref(mb)))
+        with torch.cuda.device(self.device):                         # the mailbox records the CURRENT device: its waves and streams live there,
+            _lib.check(self._lib.snac_mailbox_create(C.byref(self._desc), int(idle_us), C.byref(mb)))   # whatever is current when a step arms one
         ptr = self._lib.snac_mailbox_row(mb)
         n = self.obs_dim * self.num_envs
         if self.obs_dtype == torch.float64:
@@ -576,7 +601,7 @@ class BatchedDMPEnv:
         self.t += 1
 
     def mailbox_step_n(self, actions, step_size):
-        """One vector step of the batch (N <= 64) through its resident wave: actions / step_size contiguous int8 numpy arrays [N]
+        """One vector step of the batch (N <= 256) through its resident waves: actions / step_size contiguous int8 numpy arrays [N]
         (host memory).  When this returns the rows of mailbox_open() hold the observations and mailbox_outputs() the rewards and
         done flags; no auto-reset (the reference's wrapper has none)."""
         if self._mb_dirty:

@@ -49,13 +49,22 @@ struct TrajBlock {
 std::mutex g_traj_mu;
 std::unordered_map<void*, TrajBlock> g_traj;
 std::atomic<unsigned long long> g_reserved_dead{0};     // address space of ranges that are no longer mapped (never handed out again)
-constexpr int TRAJ_CHUNK_LOG2 = 25;
+// tests/native/traj_host_test.cpp compiles this file with gcc against a fake HIP layer and shrinks the whole geometry by 2^13 (4 KB
+// chunks, "1 GiB" = 128 KB) so that every path -- pools, spacers, windows, rebuilds, every failure -- runs on real memory in milliseconds
+#ifndef SNAC_TRAJ_TEST_SHIFT
+#define SNAC_TRAJ_TEST_SHIFT 0
+#endif
+#ifndef SNAC_TRAJ_AUX_BLOCKS
+#define SNAC_TRAJ_AUX_BLOCKS 4096
+#endif
+constexpr size_t gib(size_t n) { return (n << 30) >> SNAC_TRAJ_TEST_SHIFT; }
+constexpr int TRAJ_CHUNK_LOG2 = 25 - SNAC_TRAJ_TEST_SHIFT;
 constexpr size_t TRAJ_CHUNK = (size_t)1 << TRAJ_CHUNK_LOG2;   // one physical handle per 32 MB: 480 handles for the headline's 16 GB
-constexpr size_t TRAJ_SLICE = (size_t)32 << 30;   // distance between the starts of consecutive runs
+constexpr size_t TRAJ_SLICE = gib(32);   // distance between the starts of consecutive runs
 constexpr int TRAJ_RUNS = 3;
-constexpr size_t TRAJ_SPLIT_MIN = (size_t)1 << 30;     // smaller blocks are not worth the probe: one run
-constexpr size_t TRAJ_POOL_DEFAULT = (size_t)160 << 30;  // what the pool (groups + spacers) may hold beyond the block itself
-constexpr size_t TRAJ_MARGIN = (size_t)4 << 30;        // device memory the pool never touches
+constexpr size_t TRAJ_SPLIT_MIN = gib(1);     // smaller blocks are not worth the probe: one run
+constexpr size_t TRAJ_POOL_DEFAULT = gib(160);  // what the pool (groups + spacers) may hold beyond the block itself
+constexpr size_t TRAJ_MARGIN = gib(4);        // device memory the pool never touches
 
 // Unmap chunk by chunk (each call undoes exactly one hipMemMap), release the physical handles -- and KEEP the address range
 // reserved: a range that was handed out again right after an unmap has been seen to serve stale translations (round 2: a fresh
@@ -97,8 +106,8 @@ int traj_verify(char* va, size_t total, size_t chunk, hipStream_t stream) {
     std::vector<uint64_t> firsts(nchunks, 0);
     unsigned long long hbad = 0;
     (void)hipMemsetAsync(bad, 0, sizeof(*bad), stream);
-    hipLaunchKernelGGL(k_traj_fill, dim3(4096), dim3(256), 0, stream, (uint64_t*)va, words, salt);
-    hipLaunchKernelGGL(k_traj_check, dim3(4096), dim3(256), 0, stream, (const uint64_t*)va, words, salt, bad);
+    hipLaunchKernelGGL(k_traj_fill, dim3(SNAC_TRAJ_AUX_BLOCKS), dim3(256), 0, stream, (uint64_t*)va, words, salt);
+    hipLaunchKernelGGL(k_traj_check, dim3(SNAC_TRAJ_AUX_BLOCKS), dim3(256), 0, stream, (const uint64_t*)va, words, salt, bad);
     e = hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, stream);
     for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) e = hipMemcpyAsync(&firsts[c], va + c * chunk, 8, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -193,7 +202,7 @@ struct TrajPool {
             if (hipMemMap(va + i * chunk, chunk, 0, fresh[i], 0) != hipSuccess) { (void)hipGetLastError(); ok = false; } else mapped += chunk;
         }
         if (ok && hipMemSetAccess(va, mapped, &acc, 1) != hipSuccess) { (void)hipGetLastError(); ok = false; }
-        if (!ok) { traj_release(va, mapped, chunk, fresh); return 0; }
+        if (!ok) { traj_release(va, mapped, chunk, fresh); g_reserved_dead += got * gbytes - mapped; return 0; }   // (the whole range stays reserved: round 6, tests/native/traj_host_test.cpp)
         ranges.emplace_back(va, mapped);
         for (size_t g = 0; g < got; ++g) gva.push_back(va + g * gbytes);
         h.insert(h.end(), fresh.begin(), fresh.end());
@@ -300,7 +309,7 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
             if (jump) {
                 size_t sp = std::min(jump, room > TRAJ_GROW * pool.gbytes ? room - TRAJ_GROW * pool.gbytes : (size_t)0);
                 sp &= ~(chunk - 1);
-                while (sp >= ((size_t)2 << 30) && !pool.space(sp)) sp = (sp / 2) & ~(chunk - 1);
+                while (sp >= gib(2) && !pool.space(sp)) sp = (sp / 2) & ~(chunk - 1);
                 room = limit_bytes - (pool.groups() * pool.gbytes + pool.spacer_bytes);
             }
             const size_t got = pool.grow(std::min(TRAJ_GROW, room / pool.gbytes), gran);
@@ -384,7 +393,7 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
             // one is made: nothing of the short class -> the next one jumps (16, 32, 64 GiB of spacer); a pool without ANY group of the
             // other class jumps at once
             const size_t have = std::min(near_clean, far_clean + n_aside), before = pool.groups();
-            if (have <= 1 && !jump) jump = (size_t)16 << 30;
+            if (have <= 1 && !jump) jump = gib(16);
             if (!extend()) break;
             t.resize(pool.groups(), 0.f); aside.resize(pool.groups(), 0);
             size_t nc = near_clean, fc = far_clean;
@@ -395,7 +404,7 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
             }
             const size_t now = std::min(nc, fc + n_aside);
             stagnant = now >= have + std::min((size_t)3, W - have) ? 0 : stagnant + 1;
-            jump = stagnant ? std::min((size_t)16 << 30 << std::min(stagnant - 1, 2), (size_t)64 << 30) : 0;
+            jump = stagnant ? std::min(gib(16) << std::min(stagnant - 1, 2), gib(64)) : 0;
         }
     }
     // ---- step 2: the block's windows, each a (near, far) pair timed as the pair it will be
@@ -471,7 +480,7 @@ int traj_alloc_probed(size_t bytes, int device, const hipMemAllocationProp& prop
     size_t m2 = 0;
     for (size_t j = 0; j < k; ++j) {
         e = hipMemMap(va + j * chunk, chunk, 0, hs[j], 0);
-        if (e != hipSuccess) { done_events(); traj_release(va, m2, chunk, hs); return fail_hip(e, "hipMemMap"); }
+        if (e != hipSuccess) { done_events(); traj_release(va, m2, chunk, hs); g_reserved_dead += total - m2; return fail_hip(e, "hipMemMap"); }
         m2 += chunk;
     }
     e = hipMemSetAccess(va, total, &pool.acc, 1);
@@ -637,7 +646,7 @@ int snac_traj_alloc_ex(size_t bytes, int device, size_t pool_cap_bytes, void* st
     size_t gran = 0;
     e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
     if (e != hipSuccess) return fail_hip(e, "hipMemGetAllocationGranularity");
-    if (gran < ((size_t)2 << 20)) gran = (size_t)2 << 20;          // whole 2 MB pages whatever the minimum is
+    if (gran < (((size_t)2 << 20) >> SNAC_TRAJ_TEST_SHIFT)) gran = ((size_t)2 << 20) >> SNAC_TRAJ_TEST_SHIFT;   // whole 2 MB pages whatever the minimum is
     const size_t cap = pool_cap_bytes ? pool_cap_bytes : TRAJ_POOL_DEFAULT;
     const char* off = std::getenv("SNAC_TRAJ_PROBE");
     const bool measured = bytes >= TRAJ_SPLIT_MIN && !(off && off[0] == '0');

@@ -37,9 +37,21 @@ def _make_step_size_draw():
     straight from the global RandomState's bit generator (0.26 us).  The generator object is the one np.random.seed() re-seeds in
     place.  Checked at import against randint itself on a scratch generator; any difference (another numpy) falls back to randint."""
     try:
-        raw = np.random.mtrand._rand._bit_generator.random_raw
+        mt = np.random.mtrand
+        state = [mt._rand, mt._rand._bit_generator, mt._rand._bit_generator.random_raw]
+        if type(state[1]).__name__ != "MT19937":
+            raise RuntimeError("the global generator is not an MT19937")
 
         def draw():
+            # the global generator can be swapped after import (np.random.set_bit_generator, a rebound mtrand._rand): two identity tests
+            # per draw (0.05 us) keep the fast path on whatever generator np.random.randint itself would use -- or leave it (ADVICE round 5)
+            rs = mt._rand
+            if rs is not state[0] or rs._bit_generator is not state[1]:
+                bg = rs._bit_generator
+                if type(bg).__name__ != "MT19937":
+                    return int(np.random.randint(1, 4))
+                state[0], state[1], state[2] = rs, bg, bg.random_raw
+            raw = state[2]
             while True:
                 v = raw() & 3
                 if v != 3:

@@ -149,7 +149,7 @@ def _view(owner, index, numel, shape, dtype):
 def traj_empty(shape, dtype, device, pool_cap=0):
     """torch.empty(shape, dtype=dtype, device=device) on snac_traj_alloc memory (contiguous; it holds the pattern of the library's
     own check, not zeros).  pool_cap: bytes of device memory the slice measurement may hold beyond the block while it runs
-    (0 = 64 GiB, never more than half of what is free; snac_traj_alloc_ex).  Raises SnacError when the block cannot be allocated
+    (0 = 160 GiB, never more than half of what is free nor the last 4 GiB; snac_traj_alloc_ex).  Raises SnacError when the block cannot be allocated
     or fails its check, and RuntimeError when this PyTorch build cannot view a foreign device pointer.  The block is unmapped when
     the last tensor viewing it dies -- snac_traj_free then waits for the whole device to go idle first, so that garbage collection
     is where the wait happens.  (cached_empty() is the recycling form: what rollout() uses for its own outputs.)"""
@@ -193,6 +193,14 @@ def _cache_limit():
     if os.environ.get("SNAC_TRAJ_CACHE", "1") == "0":
         return 0
     return int(float(os.environ.get("SNAC_TRAJ_CACHE_BYTES", str(40 << 30))))
+
+
+def default_pool_cap():
+    """What the slice measurement of a block that rollout() allocates by itself may hold beyond the block while it runs:
+    SNAC_TRAJ_POOL_CAP_BYTES, default 64 GiB (the library never takes more than half of what is free, nor the last 4 GiB)."""
+    import os
+
+    return int(float(os.environ.get("SNAC_TRAJ_POOL_CAP_BYTES", str(64 << 30))))
 
 
 class _Lease:

@@ -49,13 +49,14 @@ class VectorizedEnvWrapper:
         self._o = self.batched.new_host_obs() if n <= self.HOST_OBS_MAX else self.batched._new_obs()
         self._a_np, self._k_np, self._r_np, self._d_np = self._a.numpy(), self._k.numpy(), self._r.numpy(), self._d.numpy()
         self._out = (self._o, self._r, self._d)                  # ONE tuple object: step()'s fast path recognises the call before by identity
-        # Up to 64 envs -- the reference driver's default is --num_envs 3 (multiprocess.py:96) -- step through the batch's MAILBOX: a
-        # resident wavefront (an env per lane) polls a doorbell in host memory, so a vector step is a store and a spin instead of a
-        # launch and a stream wait (snac_mailbox_step_n; 24 -> 9 us per vector step at 3 envs).  SNAC_MAILBOX=0 keeps the launch path.
+        # Up to 256 envs -- the reference driver's default is --num_envs 3 (multiprocess.py:96) -- step through the batch's MAILBOX: up to
+        # four resident wavefronts (an env per lane, 64 envs per wave) poll a doorbell in host memory, so a vector step is a store and a
+        # spin instead of a launch and a stream wait (snac_mailbox_step_n; 24 -> 9 us per vector step at 3 envs).  SNAC_MAILBOX=0 keeps
+        # the launch path, SNAC_MAILBOX_MAX_ENVS moves the limit (round 5: 64, one wave).
         import os
 
         self._mrows = None
-        if n <= 64 and os.environ.get("SNAC_MAILBOX", "1") != "0":
+        if n <= min(256, int(os.environ.get("SNAC_MAILBOX_MAX_ENVS", "256"))) and os.environ.get("SNAC_MAILBOX", "1") != "0":
             try:
                 self._mrows = self.batched.mailbox_open().numpy()
                 self._mr, self._md = self.batched.mailbox_outputs()

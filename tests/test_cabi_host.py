@@ -183,8 +183,8 @@ def test_round5_entry_points_validate_their_arguments_before_any_hip_call():
 
     L = _lib.lib()
     mb = C.c_void_p()
-    big = _lib.EnvDesc(2, 1, 65, 4, 0, 0, 1, 0, 0, 0)              # a mailbox steps one wavefront: 64 envs at most
-    assert L.snac_mailbox_create(C.byref(big), 0, C.byref(mb)) != 0 and b"1 .. 64" in L.snac_last_error() and not mb.value
+    big = _lib.EnvDesc(2, 1, 257, 4, 0, 0, 1, 0, 0, 0)             # a mailbox steps four wavefronts: 256 envs at most
+    assert L.snac_mailbox_create(C.byref(big), 0, C.byref(mb)) != 0 and b"1 .. 256" in L.snac_last_error() and not mb.value
     assert L.snac_mailbox_create(None, 0, C.byref(mb)) != 0
     assert L.snac_mailbox_step(None, None, None, 0, 1) != 0 and b"null mailbox" in L.snac_last_error()
     assert L.snac_mailbox_touch(None) != 0

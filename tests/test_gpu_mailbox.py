@@ -138,9 +138,11 @@ def test_the_drop_in_class_steps_through_the_mailbox():
     assert o[0].shape == (1, 51)
 
 
-@pytest.mark.parametrize("dim,dyn,n", [(1, True, 3), (2, True, 64), (2, False, 9), (3, True, 24), (3, False, 64)])
-def test_batches_of_up_to_64_envs_step_through_one_wave(dim, dyn, n):
-    """snac_mailbox_step_n: env e on lane e of the resident wave.  300 vector steps with random actions / step sizes and a masked reset
+@pytest.mark.parametrize("dim,dyn,n", [(1, True, 3), (2, True, 64), (2, False, 9), (3, True, 24), (3, False, 64),
+                                       (2, True, 65), (1, False, 128), (3, True, 130), (2, True, 256), (3, False, 256)])
+def test_batches_of_up_to_256_envs_step_through_resident_waves(dim, dyn, n):
+    """snac_mailbox_step_n: env 64 w + e on lane e of resident wave w (up to four waves, each a launch of its own polling the same
+    doorbell; round 5: one wave, 64 envs).  300 vector steps with random actions / step sizes and a masked reset
     every 50 steps (the launch path, under the resident wave): rows, rewards and done flags equal those of snac_step on a twin batch
     and of the oracle; the records in HBM and the episodic sums agree afterwards."""
     import torch

@@ -46,3 +46,32 @@ def test_known_answers_of_the_reference_stream():
     assert [_draw_step_size() for _ in range(20)] == [1, 2, 1, 2, 2, 3, 1, 3, 1, 1, 1, 3, 2, 3, 3, 1, 2, 2, 2, 2]
     np.random.seed(1)
     assert [_draw_step_size() for _ in range(20)] == [2, 1, 1, 2, 2, 1, 1, 2, 1, 2, 1, 3, 2, 3, 1, 3, 2, 3, 1, 1]
+
+
+def test_fast_draw_follows_a_global_generator_swapped_after_import():
+    """the fast path bound the bit generator at import.  A script that swaps the global generator afterwards
+    (np.random.set_bit_generator, numpy >= 1.25, or a rebound mtrand._rand) must keep getting np.random.randint(1, 4)'s stream."""
+    from snac_amd.envs import _draw_step_size
+
+    mt = np.random.mtrand
+    old = mt._rand
+    try:
+        if hasattr(np.random, "set_bit_generator"):
+            np.random.set_bit_generator(np.random.MT19937(77))
+            a = [_draw_step_size() for _ in range(200)]
+            np.random.set_bit_generator(np.random.MT19937(77))
+            b = [int(np.random.randint(1, 4)) for _ in range(200)]
+            assert a == b
+            np.random.set_bit_generator(np.random.PCG64(5))          # not an MT19937: the fast path steps aside, value for value
+            a = [_draw_step_size() for _ in range(50)]
+            np.random.set_bit_generator(np.random.PCG64(5))
+            b = [int(np.random.randint(1, 4)) for _ in range(50)]
+            assert a == b
+            np.random.set_bit_generator(np.random.MT19937(3))
+        np.random.seed(4)
+        a = [_draw_step_size() for _ in range(100)]
+        np.random.seed(4)
+        assert a == [int(np.random.randint(1, 4)) for _ in range(100)]
+    finally:
+        if hasattr(np.random, "set_bit_generator"):
+            np.random.set_bit_generator(old._bit_generator)

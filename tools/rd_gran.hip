@@ -109,13 +109,16 @@ int main() {
     run("colb", k_rd<COLB>, 960);
     const size_t n = (size_t)1 << 23;                                // 8 M lanes
     auto st = [&](const char* name, auto kern, int S) {
+        if ((n - 1) * (size_t)S + 16 > total) { printf("%s: skipped (slab too small)\n", name); return; }
         const float ms = best_of([&] { hipLaunchKernelGGL(kern, dim3((unsigned)(n / 256)), dim3(256), 0, 0, (const char*)slab, n, sink); });
         printf("%-9s 16 B per lane at stride %3d: %7.3f ms per %zu lanes (%.0f MB useful)\n", name, S, ms, n, n * 16 / 1e6);
     };
     st("stride16", k_stride<16>, 16); st("stride32", k_stride<32>, 32); st("stride64", k_stride<64>, 64); st("stride128", k_stride<128>, 128); st("stride256", k_stride<256>, 256);
     auto wr = [&](const char* name, auto kern, int S, int B) {
-        const float ms = best_of([&] { hipLaunchKernelGGL(kern, dim3((unsigned)(n / 256)), dim3(256), 0, 0, slab, n); });
-        printf("%-9s %2d B per lane written at stride %3d: %7.3f ms per %zu lanes (%.0f MB useful)\n", name, B, S, ms, n, n * (double)B / 1e6);
+        const size_t m = ((total / (size_t)S < n ? total / (size_t)S : n) / 256 - 1) * 256;   // every lane's bytes inside the slab
+        if ((m - 1) * (size_t)S + 64 > total) { printf("%s: skipped (slab too small)\n", name); return; }
+        const float ms = best_of([&] { hipLaunchKernelGGL(kern, dim3((unsigned)(m / 256)), dim3(256), 0, 0, slab, m); });
+        printf("%-9s %2d B per lane written at stride %3d: %7.3f ms per %zu lanes (%.0f MB useful)\n", name, B, S, ms, m, m * (double)B / 1e6);
     };
     wr("wr2_800", k_wr<800, 2>, 800, 2); wr("wr2_128", k_wr<128, 2>, 128, 2); wr("wr16_16", k_wr<16, 16>, 16, 16); wr("wr16_64", k_wr<64, 16>, 64, 16); wr("wr16_128", k_wr<128, 16>, 128, 16);
     return 0;
