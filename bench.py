@@ -761,7 +761,7 @@ def main():
             if note:
                 res[name]["note"] = note
 
-        def edges_cfg(name, kind, parents, reps):
+        def edges_cfg(name, kind, parents, reps, nodes=False):
             """snac_transition as one search wave (Env/2D/DMP_ENV_2D_dynamic_MCTS.py:117-175): `parents`
             random rows of a 2^20-row node pool, one child each with a random action, written to fresh rows with the child's
             observation.  Bytes per edge: the source record in, the destination record out, row + reward + done + indices."""
@@ -779,8 +779,18 @@ def main():
             rw = torch.empty(m, dtype=torch.float32, device=dev)
             dn = torch.empty(m, dtype=torch.uint8, device=dev)
             vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+            recs = None
+            if nodes:                                               # the same pool as ONE 128-byte record per node (snac_amd.NodePool2D, k_edges2dp)
+                from snac_amd import NodePool2D
+
+                recs = NodePool2D(e, pool)
+                recs.load()
 
             def call():
+                if recs is not None:
+                    _lib.check(e._lib.snac_transition_nodes2d(C.byref(e._desc), C.byref(e._state), vp(recs.records), pool, m, vp(src), vp(dst), 0, vp(acts),
+                                                              None, vp(ob), vp(rw), vp(dn), e._stream()))
+                    return
                 _lib.check(e._lib.snac_transition(C.byref(e._desc), C.byref(e._state), m, vp(src), vp(dst), 0, vp(acts), None, vp(ob),
                                                   vp(rw), vp(dn), e._stream()))
 
@@ -944,6 +954,7 @@ def main():
         step_cfg("step_3d_ppo_layout_n65536", 3, 65536, 100, layout="ppo")
         for kind in (2, 3):
             edges_cfg("transition_%dd_524288_edges" % kind, kind, 524288, 20)
+        edges_cfg("transition_2d_nodes_524288_edges", 2, 524288, 20, nodes=True)
         gather_cfg("replay_gather_65536", 65536, 64, 65536, 20)
         facade_cfg("facade_2d_dynamic_one_env")
         vector_cfg("vector_wrapper_3_envs", 3)

@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define SNAC_ABI_VERSION 10
+#define SNAC_ABI_VERSION 11
 
 typedef enum snac_status {
     SNAC_OK = 0,
@@ -444,6 +444,29 @@ int snac_mailbox_stats(const snac_mailbox* mb, uint32_t out[8]);
 int snac_transition(const snac_env_desc* desc, const snac_state* st, int32_t m, const int32_t* src_index,
                     const int32_t* dst_index, uint32_t t, const int8_t* actions, const int8_t* step_size, void* obs,
                     float* reward, uint8_t* done, void* stream);
+
+/* ---- 2D node pools with ONE record per node (round 6).  A tree edge reads its parent at a random row; in the arrays of snac_state
+ * that is three lines of memory (header, episode counter, board: the memory side reads whole 128-byte lines) for 100 bytes.  A
+ * snac_node2d holds the three in one line: an edge reads one line and writes one.  The pool is caller-owned, 128-byte aligned.
+ *   snac_nodes2d_pack        node record node_rows[i] (NULL: i)  <-  batch row rows[i] (NULL: i) of st, i in [0, m)
+ *   snac_nodes2d_unpack      the inverse: batch row rows[i] of st  <-  node record node_rows[i]
+ *   snac_transition_nodes2d  snac_transition on the pool: record dst_index[i] <- step(record src_index[i], actions[i], step size i);
+ *                            st supplies the plan table (plans, plan_tb) only; same rules, outputs and index conventions; the
+ *                            canonical observation layout (variants: snac_transition); 2D kinds only */
+typedef struct snac_node2d {    /* 128 bytes, 128-byte aligned */
+    snac_env_hdr hdr;
+    int32_t episode;
+    int32_t zero0[3];
+    uint32_t board[20];         /* the grid record of the 2D kinds: row word q, bit j = interior cell (q, j) */
+    uint32_t zero1[4];
+} snac_node2d;
+int snac_nodes2d_pack(const snac_env_desc* desc, const snac_state* st, const int32_t* rows, int32_t m, snac_node2d* nodes, int32_t pool_rows,
+                      const int32_t* node_rows, void* stream);
+int snac_nodes2d_unpack(const snac_env_desc* desc, const snac_node2d* nodes, int32_t pool_rows, const int32_t* node_rows, int32_t m, snac_state* st,
+                        const int32_t* rows, void* stream);
+int snac_transition_nodes2d(const snac_env_desc* desc, const snac_state* st, snac_node2d* nodes, int32_t pool_rows, int32_t m,
+                            const int32_t* src_index, const int32_t* dst_index, uint32_t t, const int8_t* actions, const int8_t* step_size,
+                            void* obs, float* reward, uint8_t* done, void* stream);
 
 /* (position, environment_memory, count_brick, count_step) tuples of the reference (the `state` of the MCTS variants,
  * Env/2D/DMP_ENV_2D_dynamic_MCTS.py:88-91) -> pool rows dst_index[i] (NULL: row i); the inverse of snac_export_grid plus

@@ -6,7 +6,7 @@ implementation.  See DESIGN.md / INTEGRATION.md.
 from ._lib import SnacError, build  # noqa: F401
 from . import plans  # noqa: F401
 
-__all__ = ["BatchedDMPEnv", "VectorizedEnvWrapper", "ReplayRing", "SnacError", "build", "plans"]
+__all__ = ["BatchedDMPEnv", "VectorizedEnvWrapper", "ReplayRing", "NodePool2D", "SnacError", "build", "plans"]
 
 
 def __getattr__(name):  # torch is imported lazily so that `import snac_amd` stays cheap
@@ -18,6 +18,10 @@ def __getattr__(name):  # torch is imported lazily so that `import snac_amd` sta
         from .replay import ReplayRing
 
         return ReplayRing
+    if name == "NodePool2D":
+        from .nodes import NodePool2D
+
+        return NodePool2D
     if name == "VectorizedEnvWrapper":
         from .vector import VectorizedEnvWrapper
 

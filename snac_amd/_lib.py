@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SNAC_OK = 0
-ABI_VERSION = 10
+ABI_VERSION = 11
 ENV_1D, ENV_2D, ENV_3D = 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 OBS_NONE, OBS_ALL, OBS_LAST, OBS_TILED = 0, 1, 2, 3
@@ -24,7 +24,8 @@ EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_obs_dim", 
            "snac_rollout_rec", "snac_replay_gather", "snac_make_plans", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
            "snac_import_state", "snac_obs_equal", "snac_plans_from_grids", "snac_mailbox_create", "snac_mailbox_row", "snac_mailbox_touch", "snac_mailbox_step", "snac_mailbox_step_n", "snac_mailbox_reward", "snac_mailbox_done",
            "snac_mailbox_quit", "snac_mailbox_settle", "snac_mailbox_destroy", "snac_mailbox_stats", "snac_stream_sync", "snac_rollout_tiled", "snac_replay_gather_tiled", "snac_traj_alloc",
-           "snac_traj_alloc_ex", "snac_traj_free", "snac_traj_layout", "snac_traj_describe", "snac_traj_reserved_bytes", "snac_last_kernel", "snac_tuning")
+           "snac_traj_alloc_ex", "snac_traj_free", "snac_traj_layout", "snac_traj_describe", "snac_traj_reserved_bytes", "snac_last_kernel", "snac_tuning",
+           "snac_nodes2d_pack", "snac_nodes2d_unpack", "snac_transition_nodes2d")
 
 
 class Sizes(C.Structure):
@@ -125,6 +126,9 @@ def lib():
         L.snac_iou.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
         L.snac_export_grid.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, vp]
         L.snac_transition.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
+        L.snac_nodes2d_pack.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, C.c_int32, vp, C.c_int32, vp, vp]
+        L.snac_nodes2d_unpack.argtypes = [C.POINTER(EnvDesc), vp, C.c_int32, vp, C.c_int32, C.POINTER(State), vp, vp]
+        L.snac_transition_nodes2d.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), vp, C.c_int32, C.c_int32, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
         L.snac_import_state.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.snac_plans_from_grids.argtypes = [C.POINTER(EnvDesc), C.POINTER(State), C.c_int32, C.c_int32, C.POINTER(State), C.c_int32, vp, vp, vp, vp]
         L.snac_mailbox_create.argtypes = [C.POINTER(EnvDesc), C.c_uint32, C.POINTER(vp)]

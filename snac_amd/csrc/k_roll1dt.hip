@@ -292,8 +292,9 @@ void launch_roll1dt_w(const KArgs& a, hipStream_t s) {
         }
         return;
     }
-    const int emin = snac_detail::tune(snac_detail::TN_1D_TP_EB16);
-    if (a.n >= emin) launch_roll1dt_e<DYN, OT, 16>(a, s);      // 16 envs per block: runs of 896 / 448 bytes per tick (3072 envs: 0.048 against 0.041 ms; 3584: level)
+    const int emin = snac_detail::tune(snac_detail::TN_1D_TP_EB16), e8lo = snac_detail::tune(snac_detail::TN_1D_TP_EB8_MIN), e8hi = snac_detail::tune(snac_detail::TN_1D_TP_EB8_MAX);
+    if (a.n >= e8lo && a.n <= e8hi) launch_roll1dt_e<DYN, OT, 8>(a, s);   // 8 envs per block: two blocks share a CU where 16-env blocks number one per CU
+    else if (a.n >= emin) launch_roll1dt_e<DYN, OT, 16>(a, s); // 16 envs per block: runs of 896 / 448 bytes per tick (3072 envs: 0.048 against 0.041 ms; 3584: level)
     else launch_roll1dt_e<DYN, OT, 4>(a, s);                        // small batches: more blocks than CUs first
 }
 

@@ -161,21 +161,14 @@ __global__ __launch_bounds__((NS + 8) * 64) void k_rollout2db(const KArgs a) {
             const bool was = ((w >> off) & 1ull) != 0ull;
             const bool planned = ((pl_pf >> (s.c - 3)) & 1u) != 0u;
             const bool first = s.cs == 0;
-            const bool drop = act == 4;
-            s.cs = min(s.cs + 1, CNT_MAX);
-            if (drop) {
-                s.cb = min(s.cb + 1, CNT_MAX);
-                if (active) *cw = w | (1ull << off);                 // += 1 then clamp to 1 (:115, :134-135)
-                gcnt += was ? 0 : 1;
+            const Rule2D u = rules2d(s, act, k, was, planned, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+            if (u.drop) {
+                if (active) *cw = w | (1ull << off);
+                gcnt += was ? 0 : 1;                                 // the running counts of the boolean IoU
                 inter += (!was && planned) ? 1 : 0;
             }
-            if (act == 0) s.c = max(s.c - k, 3);                     // clip_position :74-83
-            if (act == 1) s.c = min(s.c + k, 22);
-            if (act == 2) s.r = min(s.r + k, 22);                    // "up" is row + k (:100-103)
-            if (act == 3) s.r = max(s.r - k, 3);
-            const bool term = drop && s.cb >= s.tb + a.brick_gt;     // :117-126, tested before the time limit
-            const bool done = active && (term || s.cs >= a.ts_done);
-            const int reward = (drop && !term && !was && planned) ? 5 : 0;   // un-clamped cell vs plan (:129-133)
+            const bool done = active && u.done;
+            const int reward = u.reward;
             s.ep_ret = clamp16(s.ep_ret + reward);
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
             if (active) {

@@ -210,36 +210,15 @@ struct Roll3D {
         const int tr = s.r + dr - 3, tc = s.c + dc - 3;              // the build target in plan coordinates
         const bool inside = (unsigned)tr < 20u && (unsigned)tc < 20u;
         const int16_t* plp = (const int16_t*)a.plans + ((size_t)s.pidx * K::GE + (inside ? tr * 20 + tc : 0));
-        const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
-        const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
-        const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
         const bool first = s.cs == 0;
-        s.cs = min(s.cs + 1, CNT_MAX);
-        const bool can_move = valid && act < 4 && nd == 0;           // check[act] == 0
-        const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;   // move_step: consecutive free cells, <= k
-        s.r += can_move ? dr * m : 0;
-        s.c += can_move ? dc * m : 0;
-        const bool built = is_build && nd != -1;                     // check[act] == 0 for act in 4..7
-        const int newh = min(nd + 1, CNT_MAX);
+        // the rules: snac_dev.h (every lane steps -- idle lanes read some env's map and store nothing: `active` is applied at the stores)
+        const Rule3D u = rules3d<DYN>(s, act, k, n0, n1, n2, n3, c2, c3, true, a.ts_done, a.brick_gt);
+        const bool built = u.built;
+        const int newh = u.newh;
         if (active && built) h[dl] = (int16_t)newh;
-        s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
-        const bool limit = s.cb >= s.tb + a.brick_gt;
-        bool done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);      // moves, blocked moves, blocked builds
-        int reward0;                                                 // the part of the reward that does not need the plan
-        bool sel;                                                    // reward = reward_check(built cell)
-        if (DYN) {
-            // neighbours re-evaluated AFTER the build: the built cell now blocks its direction
-            const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
-            const bool fin = is_build && (boxed_post || limit);
-            reward0 = (is_build && boxed_post) ? -100 : 0;
-            sel = is_build && !fin && built;
-            done = fin ? true : (sel ? false : done);
-        } else {
-            const bool fin = is_build && (limit || boxed_pre);
-            reward0 = 0;
-            sel = is_build && !fin && built;
-            done = fin ? true : (sel ? false : done);
-        }
+        const bool done = u.done;
+        const int reward0 = u.reward0;                               // the part of the reward that does not need the plan
+        const bool sel = u.sel;                                      // reward = reward_check(built cell)
         s.ep_ret = clamp16(s.ep_ret + reward0);
         s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
         {   // the two scalar observation slots -> LDS (write_scalars of the generic kernel)

@@ -219,33 +219,13 @@ __global__ __launch_bounds__(576) void k_rollout3db(const KArgs a) {
                 n0 = o == -1 ? pb_h : n0; n1 = o == 1 ? pb_h : n1; n2 = o == 26 ? pb_h : n2; n3 = o == -26 ? pb_h : n3;
                 c2 = o == 2 * dl ? pb_h : c2; c3 = o == 3 * dl ? pb_h : c3;
             }
-            const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
-            const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
-            const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
             const bool first = s.cs == 0;
-            s.cs = min(s.cs + 1, CNT_MAX);
-            const bool can_move = valid && act < 4 && nd == 0;
-            const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;
-            s.r += can_move ? dr * m : 0;
-            s.c += can_move ? dc * m : 0;
-            const bool built = active && is_build && nd != -1;
-            const int newh = min(nd + 1, CNT_MAX);
-            s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
+            const Rule3D u = rules3d<DYN>(s, act, k, n0, n1, n2, n3, c2, c3, active, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+            const bool built = u.built;
+            const int newh = u.newh;
             s.cross += (built && newh <= pl) ? 1 : 0;                    // the tick's only vector-memory wait: pl, loaded a tick ago
-            const bool limit = s.cb >= s.tb + a.brick_gt;
-            bool done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);
-            int reward = 0;
-            const int rcheck = newh > pl ? -1 : (newh == pl ? 10 : 1);
-            if (DYN) {
-                const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
-                const bool fin = is_build && (boxed_post || limit);
-                reward = is_build ? (boxed_post ? -100 : ((!limit && built) ? rcheck : 0)) : 0;
-                done = fin ? true : ((is_build && built) ? false : done);
-            } else {
-                const bool fin = is_build && (limit || boxed_pre);
-                reward = (is_build && !fin && built) ? rcheck : 0;
-                done = fin ? true : ((is_build && built) ? false : done);
-            }
+            bool done = u.done;
+            const int reward = u.sel ? reward_check3d(newh, pl) : u.reward0;
             done = done && active;
             s.ep_ret = clamp16(s.ep_ret + reward);
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;

@@ -89,17 +89,12 @@ __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
     // ---- K2D::step (DMP_Env_2D_dynamic_usedata_plan.py:85-147) on the agent's row word
     const uint32_t row0 = mine[q0];
     const bool was = ((row0 >> bit) & 1u) != 0u, planned = ((pword >> bit) & 1u) != 0u;
-    const bool drop = active && act == 4;
-    const uint32_t newrow = row0 | (1u << bit);                      // += 1 then clamp to 1 (:115, :134-135)
-    s.cs = min(s.cs + 1, CNT_MAX);
-    if (drop) { s.cb = min(s.cb + 1, CNT_MAX); mine[q0] = newrow; }
-    if (act == 0) s.c = max(s.c - k, 3);                             // clip_position :74-83
-    if (act == 1) s.c = min(s.c + k, 22);
-    if (act == 2) s.r = min(s.r + k, 22);                            // "up" is row + k (:100-103)
-    if (act == 3) s.r = max(s.r - k, 3);
-    const bool term = drop && s.cb >= s.tb + a.brick_gt;             // :117-126, tested before the time limit
-    const bool done = active && (term || s.cs >= a.ts_done);
-    const int reward = (drop && !term && !was && planned) ? 5 : 0;   // un-clamped cell vs plan (:129-133)
+    const uint32_t newrow = row0 | (1u << bit);
+    const Rule2D u = rules2d(s, act, k, was, planned, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+    const bool drop = active && u.drop;
+    if (drop) mine[q0] = newrow;
+    const bool done = active && u.done;
+    const int reward = u.reward;
     s.ep_ret = clamp16(s.ep_ret + reward);
     s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
     if (active) {
@@ -154,8 +149,8 @@ __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
         emit_rows_var<OT>((char*)rec, cmp, (char*)a.obs + (size_t)env0 * (size_t)a.ld * sizeof(OT), lane, nenv, a.ld, a.tail, a.frame_val, wr, v0, v1,
                           recv, [&](int e, int row) { return pl[row * 65 + e]; });
     } else {
-        emit_tile<OT>((char*)rec, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv,
-                      [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; }, v0, v1);
+        emit_tile<OT, ROWS_NT_STEP>((char*)rec, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv,
+                                    [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; }, v0, v1);
     }
 }
 
@@ -248,33 +243,13 @@ __global__ __launch_bounds__(WPB * 64) void k_step3d(const KArgs a) {
     const int n0 = cen[-1], n1 = cen[1], n2 = cen[RC], n3 = cen[-RC];    // check_sur: left, right, "up" (row + 1), "down"
     const int dl = dr * RC + dc;
     const int c2 = cen[2 * dl], c3 = cen[3 * dl];
-    const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
-    const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
-    const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
-    s.cs = min(s.cs + 1, CNT_MAX);
-    const bool can_move = valid && act < 4 && nd == 0;
-    const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;
     const int old_r = s.r, old_c = s.c;
-    s.r += can_move ? dr * m : 0;
-    s.c += can_move ? dc * m : 0;
-    const bool built = active && is_build && nd != -1;
-    const int newh = min(nd + 1, CNT_MAX);
-    s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
+    const Rule3D u = rules3d<DYN>(s, act, k, n0, n1, n2, n3, c2, c3, active, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+    const bool built = u.built;
+    const int newh = u.newh;
     s.cross += (built && newh <= pl) ? 1 : 0;
-    const bool limit = s.cb >= s.tb + a.brick_gt;
-    bool done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);
-    int reward = 0;
-    const int rcheck = newh > pl ? -1 : (newh == pl ? 10 : 1);
-    if (DYN) {
-        const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
-        const bool fin = is_build && (boxed_post || limit);
-        reward = is_build ? (boxed_post ? -100 : ((!limit && built) ? rcheck : 0)) : 0;
-        done = fin ? true : ((is_build && built) ? false : done);
-    } else {
-        const bool fin = is_build && (limit || boxed_pre);
-        reward = (is_build && !fin && built) ? rcheck : 0;
-        done = fin ? true : ((is_build && built) ? false : done);
-    }
+    bool done = u.done;
+    const int reward = u.sel ? reward_check3d(newh, pl) : u.reward0;
     done = done && active;
     s.ep_ret = clamp16(s.ep_ret + reward);
     s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
@@ -319,7 +294,7 @@ __global__ __launch_bounds__(WPB * 64) void k_step3d(const KArgs a) {
     const bool norm = VAR ? (a.sc_norm != 0) : DYN;
     const double v0 = norm ? c0 / (double)s.tb : c0, v1 = norm ? c1 / (double)a.total_step : c1;
     if constexpr (!VAR) {
-        emit_tile<OT>(scr, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv, [&](int el) { return cellv[el]; }, v0, v1);
+        emit_tile<OT, ROWS_NT_STEP>(scr, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv, [&](int el) { return cellv[el]; }, v0, v1);
     } else {
         typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte global store at a 4-byte aligned address
         const int LD = a.ld;
@@ -494,31 +469,12 @@ __global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(3, 3))
             // ---- K3D::step by selects (the formulation of k_step3d / k_transition3d / Roll3D::tick)
             const int n0 = cell_at(qa, ca - 1), n1 = cell_at(qa, ca + 1), n2 = cell_at(qa + 1, ca), n3 = cell_at(qa - 1, ca);   // check_sur: left, right, "up" (row + 1), "down"
             const int c2 = cell_at(qa + 2 * dr, ca + 2 * dc), c3 = cell_at(qa + 3 * dr, ca + 3 * dc);
-            const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
-            const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
-            const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
-            s.cs = min(s.cs + 1, CNT_MAX);
-            const bool can_move = valid && act < 4 && nd == 0;
-            const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;
-            s.r += can_move ? dr * m : 0;
-            s.c += can_move ? dc * m : 0;
-            built = active && is_build && nd != -1;
-            newh = min(nd + 1, CNT_MAX);
-            s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
+            const Rule3D u = rules3d<DYN>(s, act, k, n0, n1, n2, n3, c2, c3, active, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+            built = u.built;
+            newh = u.newh;
             s.cross += (built && newh <= pl) ? 1 : 0;
-            const bool limit = s.cb >= s.tb + a.brick_gt;
-            done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);
-            const int rcheck = newh > pl ? -1 : (newh == pl ? 10 : 1);
-            if (DYN) {
-                const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
-                const bool fin = is_build && (boxed_post || limit);
-                reward = is_build ? (boxed_post ? -100 : ((!limit && built) ? rcheck : 0)) : 0;
-                done = fin ? true : ((is_build && built) ? false : done);
-            } else {
-                const bool fin = is_build && (limit || boxed_pre);
-                reward = (is_build && !fin && built) ? rcheck : 0;
-                done = fin ? true : ((is_build && built) ? false : done);
-            }
+            done = u.done;
+            reward = u.sel ? reward_check3d(newh, pl) : u.reward0;
             done = done && active;
             s.ep_ret = clamp16(s.ep_ret + reward);
             s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
@@ -562,7 +518,7 @@ __global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(3, 3))
     if (!a.obs) return;
     const double c0 = (double)s.cb, c1 = (double)s.cs;
     const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
-    emit_tile<OT>(scr, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv, [&](int el) { return cellv[el]; }, v0, v1);
+    emit_tile<OT, ROWS_NT_STEP>(scr, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv, [&](int el) { return cellv[el]; }, v0, v1);
 }
 
 }  // namespace

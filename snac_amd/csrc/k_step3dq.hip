@@ -97,32 +97,12 @@ __global__ __launch_bounds__(WPB * 64) void k_step3dq(const KArgs a) {
     // ---- K3D::step by selects (the formulation of k_step3d / k_step3ds / Roll3D::tick), the same in the env's four lanes
     const int n0 = cell_at(qa, ca - 1), n1 = cell_at(qa, ca + 1), n2 = cell_at(qa + 1, ca), n3 = cell_at(qa - 1, ca);   // check_sur: left, right, "up" (row + 1), "down"
     const int c2 = cell_at(qa + 2 * dr, ca + 2 * dc), c3 = cell_at(qa + 3 * dr, ca + 3 * dc);
-    const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
-    const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
-    const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
-    s.cs = min(s.cs + 1, CNT_MAX);
-    const bool can_move = valid && act < 4 && nd == 0;
-    const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;
-    s.r += can_move ? dr * m : 0;
-    s.c += can_move ? dc * m : 0;
-    const bool built = active && is_build && nd != -1;
-    const int newh = min(nd + 1, CNT_MAX);
-    s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
+    const Rule3D u = rules3d<DYN>(s, act, k, n0, n1, n2, n3, c2, c3, active, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+    const bool built = u.built;
+    const int newh = u.newh;
     s.cross += (built && newh <= pl) ? 1 : 0;
-    const bool limit = s.cb >= s.tb + a.brick_gt;
-    bool done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);
-    int reward = 0;
-    const int rcheck = newh > pl ? -1 : (newh == pl ? 10 : 1);
-    if (DYN) {
-        const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
-        const bool fin = is_build && (boxed_post || limit);
-        reward = is_build ? (boxed_post ? -100 : ((!limit && built) ? rcheck : 0)) : 0;
-        done = fin ? true : ((is_build && built) ? false : done);
-    } else {
-        const bool fin = is_build && (limit || boxed_pre);
-        reward = (is_build && !fin && built) ? rcheck : 0;
-        done = fin ? true : ((is_build && built) ? false : done);
-    }
+    bool done = u.done;
+    const int reward = u.sel ? reward_check3d(newh, pl) : u.reward0;
     done = done && active;
     s.ep_ret = clamp16(s.ep_ret + reward);
     s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
@@ -184,7 +164,7 @@ __global__ __launch_bounds__(WPB * 64) void k_step3dq(const KArgs a) {
         for (int i = 0; i < NF; ++i) fv[i] = *(const uint4*)(scr + min(i * 1024 + lane * 16, WAVE_LDS - 16));
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-            if (i * 1024 + lane * 16 < validb) *(uint4*)(g + i * 1024 + lane * 16) = fv[i];
+            if (i * 1024 + lane * 16 < validb) store16<ROWS_NT_STEP>(g + i * 1024 + lane * 16, fv[i]);
     }
 }
 

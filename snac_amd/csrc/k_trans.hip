@@ -61,32 +61,12 @@ __global__ __launch_bounds__(WPB * 64) void k_transition3d(const KArgs a) {
     const int tcell = inside ? tr * 20 + tc : 0;
     const int pl = ((const int16_t*)a.plans)[(size_t)s.pidx * K::GE + tcell];
     // K3D::step by selects (the same formulation as Roll3D::tick, without its deferral)
-    const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
-    const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
-    const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
-    s.cs = min(s.cs + 1, CNT_MAX);
-    const bool can_move = valid && act < 4 && nd == 0;
-    const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;
-    s.r += can_move ? dr * m : 0;
-    s.c += can_move ? dc * m : 0;
-    const bool built = active && is_build && nd != -1;
-    const int newh = min(nd + 1, CNT_MAX);
-    s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
+    const Rule3D u = rules3d<DYN>(s, act, k, n0, n1, n2, n3, c2, c3, active, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+    const bool built = u.built;
+    const int newh = u.newh;
     s.cross += (built && newh <= pl) ? 1 : 0;
-    const bool limit = s.cb >= s.tb + a.brick_gt;
-    bool done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);
-    int reward = 0;
-    const int rcheck = newh > pl ? -1 : (newh == pl ? 10 : 1);
-    if (DYN) {
-        const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
-        const bool fin = is_build && (boxed_post || limit);
-        reward = is_build ? (boxed_post ? -100 : ((!limit && built) ? rcheck : 0)) : 0;
-        done = fin ? true : ((is_build && built) ? false : done);
-    } else {
-        const bool fin = is_build && (limit || boxed_pre);
-        reward = (is_build && !fin && built) ? rcheck : 0;
-        done = fin ? true : ((is_build && built) ? false : done);
-    }
+    bool done = u.done;
+    const int reward = u.sel ? reward_check3d(newh, pl) : u.reward0;
     s.ep_ret = clamp16(s.ep_ret + reward);
     s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
     if (active) {
@@ -249,32 +229,12 @@ __global__ __launch_bounds__(WPB * 64) void k_edges3d(const KArgs a) {
     const int n0 = cell(s.r, s.c - 1), n1 = cell(s.r, s.c + 1), n2 = cell(s.r + 1, s.c), n3 = cell(s.r - 1, s.c);
     const int c2 = cell(s.r + 2 * dr, s.c + 2 * dc), c3 = cell(s.r + 3 * dr, s.c + 3 * dc);
     // K3D::step by selects (the formulation of k_transition3d / Roll3D::tick)
-    const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
-    const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
-    const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
-    s.cs = min(s.cs + 1, CNT_MAX);
-    const bool can_move = valid && act < 4 && nd == 0;
-    const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;
-    s.r += can_move ? dr * m : 0;
-    s.c += can_move ? dc * m : 0;
-    const bool built = active && is_build && nd != -1;
-    const int newh = min(nd + 1, CNT_MAX);
-    s.cb = built ? min(s.cb + 1, CNT_MAX) : s.cb;
+    const Rule3D u = rules3d<DYN>(s, act, k, n0, n1, n2, n3, c2, c3, active, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+    const bool built = u.built;
+    const int newh = u.newh;
     s.cross += (built && newh <= pl) ? 1 : 0;
-    const bool limit = s.cb >= s.tb + a.brick_gt;
-    bool done = (s.cs >= a.ts_done) || (!DYN && boxed_pre);
-    int reward = 0;
-    const int rcheck = newh > pl ? -1 : (newh == pl ? 10 : 1);
-    if (DYN) {
-        const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
-        const bool fin = is_build && (boxed_post || limit);
-        reward = is_build ? (boxed_post ? -100 : ((!limit && built) ? rcheck : 0)) : 0;
-        done = fin ? true : ((is_build && built) ? false : done);
-    } else {
-        const bool fin = is_build && (limit || boxed_pre);
-        reward = (is_build && !fin && built) ? rcheck : 0;
-        done = fin ? true : ((is_build && built) ? false : done);
-    }
+    bool done = u.done;
+    const int reward = u.sel ? reward_check3d(newh, pl) : u.reward0;
     done = done && active;
     s.ep_ret = clamp16(s.ep_ret + reward);
     s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
@@ -313,7 +273,7 @@ __global__ __launch_bounds__(WPB * 64) void k_edges3d(const KArgs a) {
     }
     const double c0 = (double)s.cb, c1 = (double)s.cs;
     const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
-    emit_tile<OT>(rec, (char*)a.obs + (size_t)edge0 * K::D * sizeof(OT), lane, nedge, [&](int el) { return cellv[el]; }, v0, v1);
+    emit_tile<OT, ROWS_NT_EDGES>(rec, (char*)a.obs + (size_t)edge0 * K::D * sizeof(OT), lane, nedge, [&](int el) { return cellv[el]; }, v0, v1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -365,18 +325,12 @@ __global__ __launch_bounds__(WPB * 64) void k_transition2d(const KArgs a) {
     const int q0 = min(max(s.r - 3, 0), K::GE - 1), bit = min(max(s.c - 3, 0), 19);
     const uint32_t row0 = nr ? 0u : src[q0];
     const bool was = ((row0 >> bit) & 1u) != 0u, planned = ((prow[q0] >> bit) & 1u) != 0u;
-    const bool drop = active && act == 4;
-    const uint32_t newrow = row0 | (1u << bit);                      // += 1 then clamp to 1 (:115, :134-135)
+    const uint32_t newrow = row0 | (1u << bit);
+    const Rule2D u = rules2d(s, act, k, was, planned, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+    const bool drop = active && u.drop;
     const int patch = drop ? q0 : -1;                                // the board row this step changed
-    s.cs = min(s.cs + 1, CNT_MAX);
-    if (drop) s.cb = min(s.cb + 1, CNT_MAX);
-    if (act == 0) s.c = max(s.c - k, 3);                             // clip_position :74-83
-    if (act == 1) s.c = min(s.c + k, 22);
-    if (act == 2) s.r = min(s.r + k, 22);                            // "up" is row + k (:100-103)
-    if (act == 3) s.r = max(s.r - k, 3);
-    const bool term = drop && s.cb >= s.tb + a.brick_gt;             // :117-126, tested before the time limit
-    const bool done = term || s.cs >= a.ts_done;
-    const int reward = (drop && !term && !was && planned) ? 5 : 0;   // un-clamped cell vs plan (:129-133)
+    const bool done = u.done;
+    const int reward = u.reward;
     s.ep_ret = clamp16(s.ep_ret + reward);
     s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
     if (active) {
@@ -542,17 +496,12 @@ __global__ __launch_bounds__(WPB * 64) void k_edges2d(const KArgs a) {
     // ---- K2D::step (DMP_Env_2D_dynamic_usedata_plan.py:85-147) on the agent's row word
     const uint32_t row0 = mine[q0];
     const bool was = ((row0 >> bit) & 1u) != 0u, planned = ((pword >> bit) & 1u) != 0u;
-    const bool drop = active && act == 4;
-    const uint32_t newrow = row0 | (1u << bit);                      // += 1 then clamp to 1 (:115, :134-135)
-    s.cs = min(s.cs + 1, CNT_MAX);
-    if (drop) { s.cb = min(s.cb + 1, CNT_MAX); mine[q0] = newrow; }
-    if (act == 0) s.c = max(s.c - k, 3);                             // clip_position :74-83
-    if (act == 1) s.c = min(s.c + k, 22);
-    if (act == 2) s.r = min(s.r + k, 22);                            // "up" is row + k (:100-103)
-    if (act == 3) s.r = max(s.r - k, 3);
-    const bool term = drop && s.cb >= s.tb + a.brick_gt;             // :117-126, tested before the time limit
-    const bool done = active && (term || s.cs >= a.ts_done);
-    const int reward = (drop && !term && !was && planned) ? 5 : 0;   // un-clamped cell vs plan (:129-133)
+    const uint32_t newrow = row0 | (1u << bit);
+    const Rule2D u = rules2d(s, act, k, was, planned, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+    const bool drop = active && u.drop;
+    if (drop) mine[q0] = newrow;
+    const bool done = active && u.done;
+    const int reward = u.reward;
     s.ep_ret = clamp16(s.ep_ret + reward);
     s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
     if (active) {
@@ -595,8 +544,8 @@ __global__ __launch_bounds__(WPB * 64) void k_edges2d(const KArgs a) {
     }
     const double c0 = (double)s.cb, c1 = (double)s.cs;
     const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
-    emit_tile<OT>((char*)rec, (char*)a.obs + (size_t)edge0 * K::D * sizeof(OT), lane, nedge,
-                  [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; }, v0, v1);
+    emit_tile<OT, ROWS_NT_EDGES>((char*)rec, (char*)a.obs + (size_t)edge0 * K::D * sizeof(OT), lane, nedge,
+                                 [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; }, v0, v1);
 }
 
 }  // namespace

@@ -189,6 +189,74 @@ struct Lane {
     __device__ void clear() { r = c = flags = cb = cs = tb = pidx = ep_ret = cross = 0; }
 };
 
+// ------------------------------------------------------------------------------------------------
+// The RULES of the 2D step (Env/2D/DMP_Env_2D_dynamic_usedata_plan.py:85-147, static: DMP_Env_2D_static.py:95-154), ONCE, for every
+// kernel that steps a 2D env lane-per-env (K2D::step of the tile kernels and the mailbox, k_rollout2d, k_rollout2db, k_step2d,
+// k_transition2d, k_edges2d, k_edges2dp): the kernels differ in where a board lives (two-bit cells in LDS, row words in LDS or
+// registers, node records) and hand in the two facts the rules need about the cell under the agent -- `was`: it holds a brick,
+// `planned`: the plan wants one; what a step does to the counters, the position, the reward and `done` is decided here and nowhere
+// else (round 5 had seven copies).  When `drop` comes back the caller sets the cell's bit (+= 1, then clamped to 1: :115, :134-135).
+// k_rollout2dt is time-parallel (counters by ballots, positions by scans of composed clamps): the same rules in another formulation.
+struct Rule2D { bool drop, term, done; int reward; };
+__device__ __forceinline__ Rule2D rules2d(Lane& s, int act, int k, bool was, bool planned, int ts_done, int brick_gt) {
+    Rule2D o;
+    o.drop = act == 4;
+    s.cs = min(s.cs + 1, CNT_MAX);
+    if (o.drop) s.cb = min(s.cb + 1, CNT_MAX);
+    if (act == 0) s.c = max(s.c - k, 3);                             // clip_position :74-83
+    if (act == 1) s.c = min(s.c + k, 22);
+    if (act == 2) s.r = min(s.r + k, 22);                            // "up" is row + k (:100-103)
+    if (act == 3) s.r = max(s.r - k, 3);
+    o.term = o.drop && s.cb >= s.tb + brick_gt;                      // :117-126, tested before the time limit (brick_gt: SNAC_RULE_BRICK_GT)
+    o.done = o.term || s.cs >= ts_done;
+    o.reward = (o.drop && !o.term && !was && planned) ? 5 : 0;       // the un-clamped cell against the plan (:129-133): 5 iff it was empty and is planned
+    return o;
+}
+
+// The RULES of the 3D step (Env/3D/DMP_simulator_3d_dynamic_triangle_usedata.py:142-231, static: DMP_simulator_3d_static_circle.py:153-230),
+// ONCE, for K3D::step (tile kernels, mailbox), k_rollout3d, k_rollout3db, k_step3d / 3ds / 3dq, k_transition3d and k_edges3d: a kernel
+// hands in the six cells the rules look at -- n0 .. n3: the four neighbours as check_sur sees them (left, right, "up" = row + 1, "down";
+// -1 frame, > 0 built), c2 / c3: the cells two and three ahead in the action's direction -- and gets back what the step does:
+//   built        a brick goes on the neighbour in direction act & 3 (the caller writes newh there and adds to s.cross / count arrays)
+//   sel          the reward is reward_check3d(newh, plan cell) (:233-240); otherwise it is reward0 (-100 boxed in, else 0)
+//   done         SURVEY 8a-Q7 .. Q9: static tests the neighbours BEFORE the build, dynamic AFTER it; a successful non-terminal build
+//                does not test the time limit
+// s.cs, s.r, s.c, s.cb are updated here.  The plan is not needed (k_rollout3d defers the plan-dependent part by a tick).
+struct Rule3D { bool built, sel, done; int newh, reward0; };
+__device__ __forceinline__ int reward_check3d(int newh, int pl) { return newh > pl ? -1 : (newh == pl ? 10 : 1); }
+template <bool DYN>
+__device__ __forceinline__ Rule3D rules3d(Lane& s, int act, int k, int n0, int n1, int n2, int n3, int c2, int c3, bool active, int ts_done, int brick_gt) {
+    Rule3D o;
+    const int d = act & 3;
+    const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
+    const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
+    const bool valid = (unsigned)act < 8u, is_build = valid && act >= 4;
+    const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
+    s.cs = min(s.cs + 1, CNT_MAX);
+    const bool can_move = valid && act < 4 && nd == 0;               // check[act] == 0
+    const int m = (k >= 2 && c2 == 0) ? ((k >= 3 && c3 == 0) ? 3 : 2) : 1;   // move_step (:93-123): consecutive free cells, at most k
+    s.r += can_move ? dr * m : 0;
+    s.c += can_move ? dc * m : 0;
+    o.built = active && is_build && nd != -1;                        // check[act] == 0 for act in 4 .. 7: only the frame refuses a brick
+    o.newh = min(nd + 1, CNT_MAX);
+    s.cb = o.built ? min(s.cb + 1, CNT_MAX) : s.cb;
+    const bool limit = s.cb >= s.tb + brick_gt;
+    const bool bottom = (s.cs >= ts_done) || (!DYN && boxed_pre);    // moves, blocked moves, blocked builds (static :226, dynamic :226)
+    bool fin;
+    if (DYN) {
+        // the neighbours re-evaluated AFTER the build (:199-206): the built cell now blocks its direction
+        const bool boxed_post = o.built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0)) : boxed_pre;
+        fin = is_build && (boxed_post || limit);                     // -100 (:199-206), then the brick limit with reward 0 (:207-213)
+        o.reward0 = (is_build && boxed_post) ? -100 : 0;
+    } else {
+        fin = is_build && (limit || boxed_pre);                      // :210-215, reward 0
+        o.reward0 = 0;
+    }
+    o.sel = is_build && !fin && o.built;
+    o.done = fin ? true : (o.sel ? false : bottom);
+    return o;
+}
+
 // ================================================================================================
 // LDS images.  Every kind keeps the env's grid WITH its frame in LDS, so that neither the transition nor the
 // observation window needs a bounds test: a window cell is one LDS read at (uniform base + lane constant).
@@ -276,20 +344,10 @@ struct K2D {
         const int off = 2 * s.c;
         const bool was = ((w >> off) & 1ull) != 0ull;
         const bool planned = ((lds[P_OFF + (s.r - 3) * RS + lane] >> (s.c - 3)) & 1u) != 0u;
-        const bool drop = act == 4;
-        s.cs = min(s.cs + 1, CNT_MAX);
-        if (drop) {
-            s.cb = min(s.cb + 1, CNT_MAX);
-            *cw = w | (1ull << off);                                 // += 1 then clamp to 1 (:115, :134-135)
-        }
-        if (act == 0) s.c = max(s.c - k, 3);                         // clip_position :74-83
-        if (act == 1) s.c = min(s.c + k, 22);
-        if (act == 2) s.r = min(s.r + k, 22);                        // "up" is row + k (:100-103)
-        if (act == 3) s.r = max(s.r - k, 3);
-        const bool term = drop && s.cb >= s.tb + bg;                 // :117-126, tested before the time limit (bg: SNAC_RULE_BRICK_GT)
-        done = term || s.cs >= ts;
-        // un-clamped cell vs plan (:129-133): 5 iff the cell was empty and is planned
-        reward = (drop && !term && !was && planned) ? 5 : 0;
+        const Rule2D u = rules2d(s, act, k, was, planned, ts, bg);
+        if (u.drop) *cw = w | (1ull << off);
+        done = u.done;
+        reward = u.reward;
     }
     // boolean IoU: script/DQN/2d/DQN_2d_dynamic.py:63-71
     __device__ static double iou(uint32_t* lds, const Lane& s, int lane) {
@@ -362,49 +420,21 @@ struct K3D {
     // step: DMP_simulator_3d_static_circle.py:153-230, DMP_simulator_3d_dynamic_triangle_usedata.py:142-231
     __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r * 26 + s.c;         // the agent's cell
-        s.cs = min(s.cs + 1, CNT_MAX);
-        reward = 0;
-        // check_sur (:88-102 / :77-91): left, right, "up" (row + 1), "down" (row - 1)
-        const int n0 = h[-1], n1 = h[1], n2 = h[26], n3 = h[-26];
-        const bool boxed_pre = n0 != 0 && n1 != 0 && n2 != 0 && n3 != 0;
-        done = (s.cs >= ts) || (!DYN && boxed_pre);                  // bottom of step(): static :226, dynamic :226
         const int d = act & 3;
         const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
         const int dl = dr * 26 + dc;
-        const int nd = d == 0 ? n0 : (d == 1 ? n1 : (d == 2 ? n2 : n3));
-        const int c2 = h[2 * dl], c3 = h[3 * dl];                    // within the frame: |offset| <= 3 cells
-        const bool valid = (unsigned)act < 8u;
-        if (valid && act < 4) {
-            if (nd == 0) {                                           // check[act] == 0
-                // move_step (:104-134): consecutive free cells, at most k; clip_position is then a no-op
-                int m = 1;
-                if (k >= 2 && c2 == 0) { m = 2; if (k >= 3 && c3 == 0) m = 3; }
-                s.r += dr * m; s.c += dc * m;
-            }
-        } else if (valid) {
-            const bool built = nd != -1;                             // check[act] == 0 for act in 4..7
-            const int newh = min(nd + 1, CNT_MAX);
-            int pl = 0;
-            if (built) {
-                s.cb = min(s.cb + 1, CNT_MAX);
-                h[dl] = (int16_t)newh;
-                pl = ((const int16_t*)a.plans)[(size_t)s.pidx * GE + (s.r + dr - 3) * 20 + (s.c + dc - 3)];
-                s.cross += newh <= pl ? 1 : 0;                       // running sum of min(height, plan) for iou()
-            }
-            bool fin = false;
-            if (DYN) {
-                // neighbours re-evaluated AFTER the build (:199-206)
-                const bool boxed_post = built ? ((d == 0 || n0 != 0) && (d == 1 || n1 != 0) && (d == 2 || n2 != 0) && (d == 3 || n3 != 0))
-                                              : boxed_pre;
-                if (boxed_post) { reward = -100; done = true; fin = true; }
-                else if (s.cb >= s.tb + bg) { reward = 0; done = true; fin = true; }     // :207-213
-            } else {
-                if (s.cb >= s.tb + bg || boxed_pre) { reward = 0; done = true; fin = true; }  // :210-215
-            }
-            if (!fin && built) {                                     // reward_check (:232-239); time limit NOT tested
-                reward = newh > pl ? -1 : (newh == pl ? 10 : 1);
-                done = false;
-            }
+        // check_sur (:88-102 / :77-91): left, right, "up" (row + 1), "down" (row - 1); the cells two and three ahead (within the frame)
+        const int n0 = h[-1], n1 = h[1], n2 = h[26], n3 = h[-26];
+        const int c2 = h[2 * dl], c3 = h[3 * dl];
+        const int tcell = (s.r + dr - 3) * 20 + (s.c + dc - 3);      // the build target in plan coordinates (a build does not move)
+        const Rule3D u = rules3d<DYN>(s, act, k, n0, n1, n2, n3, c2, c3, true, ts, bg);   // the rules, once for every 3D kernel
+        reward = u.reward0;
+        done = u.done;
+        if (u.built) {                                               // (the frame refuses a brick: the target lies inside)
+            h[dl] = (int16_t)u.newh;
+            const int pl = ((const int16_t*)a.plans)[(size_t)s.pidx * GE + tcell];
+            s.cross += u.newh <= pl ? 1 : 0;                         // running sum of min(height, plan) for iou()
+            if (u.sel) reward = reward_check3d(u.newh, pl);          // reward_check (:232-239)
         }
     }
     // iou (:257-276) = sum(min(g, plan)) / (tb + cb - sum); the sum is tracked incrementally in s.cross
@@ -679,7 +709,31 @@ __device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, cons
 // nenv < 64: a ragged tile (nenv * 51 * sizeof(OT) must be a multiple of 16: the callers require N % 4 == 0).
 constexpr int TILE_STG_BYTES = 13 * 1024;
 
-template <typename OT, class F>
+// a 16-byte store; NT: non-temporal (streamed rows that nobody reads back soon: they do not displace what a kernel's gathered reads find
+// in L2 / the Infinity Cache -- k_edges2dp's node records)
+template <bool NT>
+__device__ __forceinline__ void store16(char* p, const uint4& v) {
+    if constexpr (NT) {
+        typedef uint32_t u32x4_st __attribute__((ext_vector_type(4)));
+        u32x4_st t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        __builtin_nontemporal_store(t, (u32x4_st*)p);
+    } else {
+        *(uint4*)p = v;
+    }
+}
+
+// Which kernels' rows leave non-temporal is a BUILD constant (a run-time flag does not survive the compiler: two stores that differ in
+// the hint alone are merged into one plain store): bits 1 = snac_step (k_step2d / k_step3d / k_step3dq), 2 = snac_transition with gathered
+// rows (k_edges2d / k_edges3d); k_edges2dp has both forms (SNAC_NODES2D_NT).  A/B builds: make CXXFLAGS+=-DSNAC_ROWS_NT=3 OBJDIR=.obj_nt ...
+// Measured (profiles/r06_edges.txt, 524 288 edges / envs): edges on batch rows 80.4 -> 68.1 us (k_edges2d), 229.9 -> 223.0 (k_edges3d) -- the
+// gathered records stay in the Infinity Cache; snac_step 2D 46.2 -> 53.9 us, 3D 69.7 -> 78.4 per tick (worse: its reads are a stream of their
+// own, 65 536 envs: 8.5 -> 8.1) -- so: edges yes, steps no.
+#ifndef SNAC_ROWS_NT
+#define SNAC_ROWS_NT 2
+#endif
+constexpr bool ROWS_NT_STEP = (SNAC_ROWS_NT & 1) != 0, ROWS_NT_EDGES = (SNAC_ROWS_NT & 2) != 0;
+
+template <typename OT, bool NT = false, class F>
 __device__ __forceinline__ void emit_tile(char* stg, char* g, int lane, int nenv, F cell, double v0, double v1) {
     constexpr int D = 51, W = 49, E = 64;
     constexpr int HALVES = sizeof(OT) == 8 ? 2 : 1, HE = E / HALVES;
@@ -695,19 +749,32 @@ __device__ __forceinline__ void emit_tile(char* stg, char* g, int lane, int nenv
             for (int el = 0; el < W; ++el) S[el] = (OT)cell(el);
             S[W] = (OT)v0; S[W + 1] = (OT)v1;
         }
+        // The lanes exchange their values through LDS without a barrier (one wave: LDS operations complete in order) -- which the
+        // COMPILER does not know: a lane that wrote nothing in this half may be handed the values it read in the half before.  The build
+        // with non-temporal stores did exactly that (round 6: the second half's ds_read_b128 sunk into the writers' branch, rows 32-63 of
+        // every tile stale; tests/test_gpu_nodes2d.py caught it -- the plain form happened not to).  What was tried: an empty asm with a
+        // memory clobber (a vmcnt(0) per tile: 2.3 -> 5.1 ms for the headline pass); fences of wavefront scope (no instruction, but they
+        // end before the machine passes: the reads sink into the ragged path's store blocks, one register quad, a vmcnt(0) per store).
+        // VOLATILE reads are reads the compiler must perform where they stand, and cost nothing (headline 2.300-2.309 against
+        // 2.311-2.313 ms, k_step2d 45.6-46.1 against 45.3-45.4 us: level).  The LDS address space is spelled out: a volatile access
+        // through the generic pointer becomes a flat_load and waits on vmcnt.
         uint4 fv[NF];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) fv[i] = *(const uint4*)(stg + i * 1024 + lane * 16);
+        for (int i = 0; i < NF; ++i) {
+            typedef uint32_t u32x4_ld __attribute__((ext_vector_type(4)));
+            const u32x4_ld t = *(const volatile __attribute__((address_space(3))) u32x4_ld*)(stg + i * 1024 + lane * 16);
+            fv[i] = make_uint4(t.x, t.y, t.z, t.w);
+        }
         char* const gh = g + (size_t)h * STG_BYTES + lane * 16;
         if (full) {
 #pragma unroll
             for (int i = 0; i < NF; ++i)
-                if ((i + 1) * 1024 <= STG_BYTES || i * 1024 + lane * 16 < STG_BYTES) *(uint4*)(gh + i * 1024) = fv[i];
+                if ((i + 1) * 1024 <= STG_BYTES || i * 1024 + lane * 16 < STG_BYTES) store16<NT>(gh + i * 1024, fv[i]);
         } else {
             const int valid = min(max(nenv - h * HE, 0), HE) * D * (int)sizeof(OT);
 #pragma unroll
             for (int i = 0; i < NF; ++i)
-                if (i * 1024 + lane * 16 < valid) *(uint4*)(gh + i * 1024) = fv[i];
+                if (i * 1024 + lane * 16 < valid) store16<NT>(gh + i * 1024, fv[i]);
         }
     }
 }

@@ -97,7 +97,7 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_2D_TP_EB8       */ {"SNAC_2D_TP_EB8", 1025, "k_rollout2dt blocks hold 8 envs instead of 4 from (1536 envs: 0.086 against 0.097 ms)"},
     /* TN_1D_TP           */ {"SNAC_1D_TP", 1, "0: 1D rollouts stay on the tile kernel instead of k_rollout1dt"},
     /* TN_1D_TP_MAX       */ {"SNAC_1D_TP_MAX", 0, "k_rollout1dt up to this many envs (0: the two defaults below)"},
-    /* TN_1D_TP_MAX_F64   */ {"SNAC_1D_TP_MAX_F64", 57344, "k_rollout1dt, float64 rows, up to (57 344 envs: 0.64 against 0.77 ms per 750 ticks, 65 536: 0.92 / 0.72; r05_retune.txt)"},
+    /* TN_1D_TP_MAX_F64   */ {"SNAC_1D_TP_MAX_F64", 65536, "k_rollout1dt, float64 rows, up to (round 6, 8-env blocks: 65 536 envs 0.685 against the tile kernel's 0.720 ms per 750 ticks; 131 072: 1.68 against 1.44; r06_1d.txt)"},
     /* TN_1D_TP_MAX_F32   */ {"SNAC_1D_TP_MAX_F32", 65536, "k_rollout1dt, float32 rows, up to (65 536 envs: 0.65 against 0.73 ms)"},
     /* TN_1D_TP_VAR_MAX   */ {"SNAC_1D_TP_VAR_MAX", 65536, "k_rollout1dt<VAR> (layout variants) up to (r04_1d_layouts.txt)"},
     /* TN_1D_TP_EB16      */ {"SNAC_1D_TP_EB16", 3584, "k_rollout1dt blocks hold 16 envs instead of 4 from (3072 envs: 0.048 against 0.041 ms; 3584: level)"},
@@ -135,6 +135,9 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_STEP3D_QUARTER  */ {"SNAC_STEP3D_QUARTER", 1, "0: the canonical 3D snac_step stays on k_step3d / k_step3ds instead of k_step3dq (16 envs per wave, four lanes per env)"},
     /* TN_STEP3D_QUARTER_MIN*/ {"SNAC_STEP3D_QUARTER_MIN", 4, "k_step3dq from this many envs (1024: 6.9 against k_step3d's 8.0 us per tick, 32 768: 9.5 / 11.5, 65 536: 13.1 / 14.1; r05_step3dq.txt) ..."},
     /* TN_STEP3D_QUARTER_MAX*/ {"SNAC_STEP3D_QUARTER_MAX", 1 << 30, "... up to this many (524 288: 67.5 against k_step3ds' 76.6 us, 131 072: 23.9 / 23.6)"},
+    /* TN_1D_TP_EB8_MIN   */ {"SNAC_1D_TP_EB8_MIN", 3584, "k_rollout1dt blocks hold 8 envs from this many envs (two blocks share a CU: one computes its chunk while the other's rows leave; 4096 envs: 0.045 against 0.048 ms on 16-env blocks, 32 768: 0.351 / 0.421, 65 536: 0.685 / 0.920; r06_1d.txt) ..."},
+    /* TN_1D_TP_EB8_MAX   */ {"SNAC_1D_TP_EB8_MAX", 1 << 30, "... up to this many"},
+    /* TN_NODES2D_NT      */ {"SNAC_NODES2D_NT", 1, "k_edges2dp (2D edges on node records): 1 = the observation rows leave as NON-TEMPORAL stores -- streamed rows then do not displace the node records in the Infinity Cache (65.1 -> 50.3 us per 524 288 edges of a 2^20-record pool, r06_edges.txt)"},
 };
 
 int tune(int id) {

@@ -1,5 +1,5 @@
 """GPU: 1D rollouts against the CPU oracle.  Rollouts that write every row run on the time-parallel kernel (k_rollout1dt, round 3:
-one wavefront per env, lane = tick, blocks of 4 (below 3584 envs) or 16 envs whose rows leave through an LDS staging tile as whole runs per tick) up
+one wavefront per env, lane = tick, blocks of 4 (below 3584 envs) or 8 envs (round 5: 16) whose rows leave through an LDS staging tile as whole runs per tick) up
 to 49 152 envs (float32 rows: 65 536), on the tile kernel beyond: batches on either side of every switch, ragged blocks and blocks
 with idle waves, rows that can and cannot leave as 16-byte pieces (odd N, unaligned outputs), canonical and tile-major layouts,
 odd / tiny tick counts, episodes that end by count_brick and by the time limit (several per chunk of 64 ticks), the `>` rule
@@ -142,12 +142,12 @@ def test_time_parallel_kernel_segments_inside_a_chunk(dyn, total_step, time_gt):
         _end_state(env, orc)
 
 
-@pytest.mark.parametrize("n,f32", [(2050, False), (2051, False), (3586, False), (3587, False), (4100, True), (4102, True), (57344, False), (57360, False), (65536, True), (65552, True)])
+@pytest.mark.parametrize("n,f32", [(2050, False), (2051, False), (3580, False), (3586, False), (3587, False), (4100, True), (4102, True), (57344, False), (65536, False), (65552, False), (65536, True), (65552, True)])
 def test_staged_rows_alignments_layouts_and_the_switch_to_the_tile_kernel(n, f32):
     """Rows of a block leave as 16-byte pieces when every run of a tick starts and ends on 16 bytes (float64: even N; float32:
     N % 4 = 0) and element by element otherwise -- also when the output itself is not 16-byte aligned; tile-major outputs hold the
-    same rows at [env // 64, t, env % 64].  57 344 / 65 536 are the largest batches of the time-parallel kernel (float64 / float32
-    rows), 16 envs more run on the tile kernel: the same rows either way."""
+    same rows at [env // 64, t, env % 64].  Blocks of 4 envs below 3584, of 8 envs from there (round 6; 16 before); 65 536 is the largest
+    batch of the time-parallel kernel (round 5: 57 344 with float64 rows), 16 envs more run on the tile kernel: the same rows either way."""
     import torch
 
     dt = torch.float32 if f32 else torch.float64

@@ -2,7 +2,7 @@
 Modes: `one` = every edge has its own random parent (what bench.py's extras time), `all` = random parents x all actions (children of a
 parent share its record: tools/bench_configs.py).  SNAC_EDGES3D=0 keeps 3D edges on k_transition3d.
 
-    gpurun -- python tools/edges_time.py [kind] [m] [one|all] [reps]
+    gpurun -- python tools/edges_time.py [kind] [m] [one|all] [reps] [nodes]        nodes: 2D on one-record-per-node pools (snac_transition_nodes2d)
 """
 import ctypes as C
 import os
@@ -40,8 +40,18 @@ def main():
     rew = torch.empty(m, dtype=torch.float32, device=dev)
     done = torch.empty(m, dtype=torch.uint8, device=dev)
     vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    nodes = None
+    if len(sys.argv) > 5 and sys.argv[5] == "nodes":
+        from snac_amd import NodePool2D
+
+        nodes = NodePool2D(env, pool)
+        nodes.load()
 
     def call():
+        if nodes is not None:
+            _lib.check(env._lib.snac_transition_nodes2d(C.byref(env._desc), C.byref(env._state), vp(nodes.records), pool, m, vp(src), vp(dst), 0, vp(acts), None,
+                                                        vp(obs), vp(rew), vp(done), env._stream()))
+            return
         _lib.check(env._lib.snac_transition(C.byref(env._desc), C.byref(env._state), m, vp(src), vp(dst), 0, vp(acts), None, vp(obs), vp(rew), vp(done), env._stream()))
 
     for _ in range(10):
@@ -55,6 +65,8 @@ def main():
     ms = a.elapsed_time(b) / reps
     rec = {1: 64, 2: 80, 3: 800}[kind] + 20
     per = 2 * rec + env.obs_dim * 8 + 5 + 9
+    if len(sys.argv) <= 5 or sys.argv[5] != "nodes" or True:
+        pass
     print("%dD %s: %d edges (%s) %.4f ms  %.3e edges/s  %.0f GB/s of %d B per edge = %.2f of 8 TB/s" % (
         kind, _lib.lib().snac_last_kernel().decode(), m, mode, ms, m / ms * 1e3, per * m / ms / 1e6, per, per * m / ms / 1e6 / 8000))
 

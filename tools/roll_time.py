@@ -56,11 +56,13 @@ def main():
     while time.perf_counter() < t_end:
         run(8)
     t = run(reps)
+    from snac_amd import _lib
+    kern = _lib.lib().snac_last_kernel().decode()
     esz = 4 if dt == torch.float32 else 8
     wb = (env.obs_dim * esz + 5) * n * T
     med = t[len(t) // 2]
-    print("%dD N=%d T=%d %s %s%s stage=%s table=%s plans=%d layout=%s (%d values): min %.3f  median %.3f ms   %.2f TB/s written   %.3e env-steps/s" % (
-        kind, n, T, "f32" if esz == 4 else "f64", mem, " tiled" if tiled else "", os.environ.get("SNAC_2D_STAGE", "1"),
+    print("%dD %s N=%d T=%d %s %s%s stage=%s table=%s plans=%d layout=%s (%d values): min %.3f  median %.3f ms   %.2f TB/s written   %.3e env-steps/s" % (
+        kind, kern, n, T, "f32" if esz == 4 else "f64", mem, " tiled" if tiled else "", os.environ.get("SNAC_2D_STAGE", "1"),
         os.environ.get("SNAC_2D_TABLE", "-"), env.num_plans, layout, env.obs_dim, t[0], med,
         wb / med / 1e9, n * T / med * 1e3), flush=True)
 
