@@ -1,8 +1,8 @@
 """Randomised parity fuzz on the GPU box (not part of the test suite): random env kind, batch size (small, and around the
 dispatch thresholds of the specialised kernels), time limit, rule bits, observation dtype and seed; then a random sequence of
 operations -- fused rollouts (counter RNG or explicit inputs), per-tick step() with and without auto-reset, step_scalar, waves of
-tree-search edges (gathered / scattered and in place), masked resets, and for batches of up to 64 envs steps through the
-resident wavefront (the mailbox) -- each compared with the CPU oracle bit for bit, the full state at the end.  Prints one line per trial; stops at the first difference.
+tree-search edges (gathered / scattered and in place; 2D also on node records), masked resets, and for batches of up to 256 envs steps through the
+resident wavefronts (the mailbox) -- each compared with the CPU oracle bit for bit, the full state at the end.  Prints one line per trial; stops at the first difference.
 
     gpurun -- python tools/fuzz.py [trials] [seed]
 """
@@ -74,7 +74,7 @@ def trial(rng, idx):
     t = 0
     ops = []
     for _ in range(int(rng.integers(2, 7))):
-        op = str(rng.choice(["rollout", "rollout", "rollout_x", "steps", "steps_x", "scalar", "edges", "reset"] + (["mailbox", "mailbox"] if n <= 64 else [])))
+        op = str(rng.choice(["rollout", "rollout", "rollout_x", "steps", "steps_x", "scalar", "edges", "reset"] + (["mailbox", "mailbox"] if n <= 256 else [])))
         ops.append(op)
         ctx["ops"] = ops
         if op in ("rollout", "rollout_x"):
@@ -130,7 +130,16 @@ def trial(rng, idx):
                 src = np.where(inplace | (len(free) == 0), dst, rng.choice(free if len(free) else dst, n_dst)).astype(np.int32)
                 acts = rng.integers(0, A, n_dst).astype(np.int8)
                 ks = rng.integers(1, 4, n_dst).astype(np.int8) if rng.random() < 0.5 else None
-                o, r, d = env.transition(acts, ks, src, dst, t=w)
+                if dim == 2 and not lay and rng.random() < 0.5:      # the same wave on node records (one 128-byte record per node): pack, step, unpack
+                    from snac_amd import NodePool2D
+
+                    pool = NodePool2D(env, n)
+                    pool.load()
+                    o, r, d = pool.transition(acts, ks, src, dst, t=w)
+                    pool.store()
+                    ops[-1] = "edges/nodes"
+                else:
+                    o, r, d = env.transition(acts, ks, src, dst, t=w)
                 oo, ro, do = orc.transition(acts, ks, src, dst, t=w)
                 same(o.cpu().numpy(), cast(oo), "edge obs", ctx)
                 same(r.cpu().numpy(), ro, "edge reward", ctx)
