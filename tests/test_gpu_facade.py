@@ -134,8 +134,9 @@ def test_invalid_action_raises_like_the_reference():
         _cls(1, False)(plan_choose=5).reset()
 
 
+@pytest.mark.parametrize("n", [24, 200])                              # one resident wave; four (round 6: up to 256 envs)
 @pytest.mark.parametrize("name,kind", [("1DStatic", (1, False)), ("2DDynamic", (2, True)), ("3DDynamic", (3, True))])
-def test_vectorized_wrapper_follows_the_reference_loop(name, kind):
+def test_vectorized_wrapper_follows_the_reference_loop(name, kind, n):
     """multiprocess.py:78-84 with N independent envs: seed, reset, T ticks of np.random actions.  The oracle side
     replays numpy's stream (MT19937 restatement) in the same order: N plan draws, then per tick N action draws
     and N step-size draws."""
@@ -143,11 +144,12 @@ def test_vectorized_wrapper_follows_the_reference_loop(name, kind):
     from snac_amd.multiprocess import make_plans
 
     dim, dyn = kind
-    n, T, seed = 24, 120, 5
+    T, seed = 120 if n < 100 else 40, 5
     orc_mod = helpers.oracle()
     plans = make_plans(name, 0)
     np.random.seed(seed)
     env = VectorizedEnvWrapper(plans, num_envs=n)
+    assert env._mrows is not None                                     # the resident waves, not the launch path
     obs = env.reset()
     A = env.action_dim
     table = np.ascontiguousarray(plans[2].reshape(len(plans[2]), -1), np.int32)
