@@ -101,7 +101,11 @@ class VectorizedEnvWrapper:
             for i in range(n):                                   # np.random.randint(1, 4, size=n): the same words of the global stream, in element order
                 k[i] = _draw_step_size()
         else:
-            if actions.min() < 0 or actions.max() >= self.action_dim:
+            if actions.dtype == np.int64 and actions.flags.c_contiguous:
+                bad = int(actions.view(np.uint64).max()) >= self.action_dim   # one reduction: a negative value is a huge unsigned one
+            else:
+                bad = actions.min() < 0 or actions.max() >= self.action_dim
+            if bad:
                 raise ValueError("action outside [0, %d)" % self.action_dim)
             self._k_np[:] = np.random.randint(1, 4, size=n)
         self._a_np[:] = actions

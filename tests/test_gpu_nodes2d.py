@@ -134,3 +134,36 @@ def test_no_indices_unaligned_rows_and_argument_errors():
         nodes.transition(acts[:4], ks[:4], src=[0, 1, 2, 3], dst=[9, 9, 10, 11])
     with pytest.raises(ValueError):
         nodes.transition(acts[:4], ks[:4], src=[0, 1, 2, 600], dst=[9, 8, 10, 11])
+
+
+def test_full_size_wave_on_a_million_records_equals_the_batch_pool():
+    """The bench's shape (transition_2d_nodes_524288_edges): a 2^20-record pool, 524 288 random-parent edges into fresh records -- at that
+    size the oracle is out of reach, so the same wave runs on the batch pool (k_edges2d, oracle-checked at small sizes) and every row,
+    reward, done flag and resulting record must be equal; pack -> unpack over the whole pool is the identity."""
+    import torch
+    from snac_amd import BatchedDMPEnv, NodePool2D
+
+    pool, m = 1 << 20, 524288
+    env = BatchedDMPEnv(2, True, pool, seed=1)
+    env.reset()
+    env.rollout(20, obs=None)
+    twin = env.fork(torch.arange(pool, device=env.device))
+    nodes = NodePool2D(env, pool)
+    assert nodes.load() == pool
+    g = torch.Generator(device="cuda").manual_seed(3)
+    src = torch.randint(0, pool - m, (m,), device="cuda", dtype=torch.int32, generator=g)
+    dst = (pool - m + torch.arange(m, device="cuda", dtype=torch.int32)).contiguous()
+    acts = torch.randint(0, 5, (m,), device="cuda", generator=g).to(torch.int8)
+    ks = torch.randint(1, 4, (m,), device="cuda", generator=g).to(torch.int8)
+    o1, r1, d1 = nodes.transition(acts, ks, src=src, dst=dst, check=False)
+    assert env._lib.snac_last_kernel() == b"k_edges2dp"
+    o2, r2, d2 = twin.transition(acts, ks, src=src, dst=dst)
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    other = BatchedDMPEnv(2, True, pool, seed=2)
+    other.reset()
+    assert nodes.store(env=other) == pool
+    assert torch.equal(other._hdr, twin._hdr) and torch.equal(other._grid, twin._grid) and torch.equal(other._episode, twin._episode)
+    # a second wave from the children (in place), counter-RNG step sizes
+    o1, r1, d1 = nodes.transition(acts, None, src=dst, dst=dst, t=7, check=False)
+    o2, r2, d2 = twin.transition(acts, None, src=dst, dst=dst, t=7)
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
