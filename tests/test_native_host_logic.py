@@ -73,3 +73,70 @@ def test_traj_empty_falls_back_to_torch_empty_only_for_an_exhausted_address_spac
         trajmem.traj_empty((3, 5, 7), torch.float64, "cuda:0")
     with pytest.raises(_lib.SnacError):
         trajmem.traj_empty((4,), torch.float32, "cpu")
+
+
+def test_trajectory_cache_recycles_bounds_and_trims_without_a_gpu(monkeypatch):
+    """snac_amd/trajmem.py cached_empty / _Lease / cache_trim (the recycling cache behind rollout()'s own outputs) with the block and the
+    torch view injected: a released block is reused by the next request of its size, a request on another stream waits for the device
+    first, the free list is bounded by SNAC_TRAJ_CACHE_BYTES (what does not fit is unmapped), cache_trim() unmaps the rest, sizes are
+    rounded to whole 32 MB handles."""
+    import contextlib
+
+    import torch
+
+    from snac_amd import trajmem
+
+    built, freed, syncs = [], [], []
+
+    class FakeBlock:
+        def __init__(self, nbytes, index, pool_cap=0):
+            self.ptr, self.nbytes, self.device_index = 0x7000000000 + len(built) * (1 << 34), int(nbytes), int(index)
+            self.__cuda_array_interface__ = {}
+            built.append(self)
+
+        def free(self):
+            freed.append(self)
+
+    class View:                                                     # what _view() hands out: keeps its owner (a _Lease) alive
+        def __init__(self, owner):
+            self.owner = owner
+
+    stream = [111]
+    monkeypatch.setattr(trajmem, "_Block", FakeBlock)
+    monkeypatch.setattr(trajmem, "_view", lambda owner, index, numel, shape, dtype: View(owner))
+    monkeypatch.setattr(trajmem, "_free", {})
+    monkeypatch.setattr(trajmem, "_stats", {"built": 0, "reused": 0, "returned": 0, "trimmed": 0})
+    monkeypatch.setattr(torch.cuda, "device", lambda index: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda index=None: syncs.append(index))
+    monkeypatch.setattr(torch._C, "_cuda_getCurrentRawStream", lambda index: stream[0], raising=False)
+    monkeypatch.setenv("SNAC_TRAJ_CACHE_BYTES", str(3 << 30))
+    monkeypatch.delenv("SNAC_TRAJ_CACHE", raising=False)
+    G = 1 << 30
+    a = trajmem.cached_empty((G + 5,), torch.uint8, "cuda:0")
+    assert len(built) == 1 and built[0].nbytes == G + (32 << 20)      # whole 32 MB handles
+    blk = a.owner.block
+    a.owner.free()                                                   # the last tensor viewing the block died
+    assert trajmem.cache_stats() == {"built": 1, "reused": 0, "returned": 1, "trimmed": 0, "free_bytes": G + (32 << 20)} and not freed
+    b = trajmem.cached_empty((G + 9,), torch.uint8, "cuda:0")        # the same size class: recycled, same stream: no wait
+    assert b.owner.block is blk and len(built) == 1 and not syncs and trajmem.cache_stats()["reused"] == 1
+    b.owner.free()
+    b.owner.free()                                                   # (idempotent)
+    stream[0] = 222
+    c = trajmem.cached_empty((G + 9,), torch.uint8, "cuda:0")        # another stream: the device goes idle before the block is handed out
+    assert c.owner.block is blk and syncs == [0]
+    d = trajmem.cached_empty((2 * G,), torch.uint8, "cuda:0")        # another size: its own block
+    e = trajmem.cached_empty((2 * G,), torch.uint8, "cuda:0")
+    assert len(built) == 3
+    c.owner.free(); d.owner.free()                                   # 1.03 + 2 GiB would be 3.03: above the 3 GiB bound
+    held = trajmem.cache_stats()["free_bytes"]
+    assert held <= (3 << 30) and (held == G + (32 << 20) and freed == [built[1]])     # d did not fit: unmapped at once
+    e.owner.free()                                                   # 1.03 + 2 = 3.03 GiB again: unmapped too
+    assert freed == [built[1], built[2]] and trajmem.cache_stats()["trimmed"] == 2
+    assert trajmem.cache_trim(1) == 0                                # another device: nothing
+    assert trajmem.cache_trim() == G + (32 << 20) and freed[-1] is blk and trajmem.cache_stats()["free_bytes"] == 0
+    monkeypatch.setenv("SNAC_TRAJ_CACHE", "0")                       # the cache switched off: a released block is unmapped
+    f = trajmem.cached_empty((G,), torch.uint8, "cuda:0")
+    f.owner.free()
+    assert freed[-1] is built[3] and trajmem.cache_stats()["free_bytes"] == 0
+    with pytest.raises(trajmem._lib.SnacError):
+        trajmem.cached_empty((4,), torch.uint8, "cpu")
