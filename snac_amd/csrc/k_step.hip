@@ -26,7 +26,7 @@ namespace {
 // tens of thousands of envs per tick reads): the rows leave through emit_rows_var (k_rollout2d's row assembly), the plan tail from the
 // lanes' plan rows in LDS.  25 KB of LDS per wave, one block of four waves per CU -- 65 536 envs are exactly one round.
 // TE = 32: half-filled tiles (lanes 32 .. 63 idle) -- twice the waves for batches that do not fill the CUs with 64 rows of kilobytes per wave.
-template <bool DYN, typename OT, int WPB, bool VAR = false, int TE = 64>
+template <bool DYN, typename OT, int WPB, bool VAR = false, int TE = 64, bool NTL = true>
 __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
     using K = K2D<DYN, 64>;
     constexpr int E = TE, GE = K::GE;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
         for (int i = 0; i < 5; ++i) {
             const int g = i * 64 + lane;
             rv[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (g < nenv * 5) { const u32x4 t = __builtin_nontemporal_load((const u32x4*)(g4 + g)); rv[i] = make_uint4(t.x, t.y, t.z, t.w); }
+            if (g < nenv * 5) { const u32x4 t = load_nt_if<NTL>((const u32x4*)(g4 + g)); rv[i] = make_uint4(t.x, t.y, t.z, t.w); }   // (NTL: outside SNAC_STEP2D_PLAIN_LO .. _HI envs)
         }
     }
     Lane s;
@@ -536,9 +536,12 @@ void launch_step2d(const snac_env_desc* d, const KArgs& a, bool half, hipStream_
     } else if (a.variant) {
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, true>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, true>), grid, block, 0, s, a); }
-    } else {
+    } else if (a.n < tune(TN_STEP2D_PLAIN_LO) || a.n > tune(TN_STEP2D_PLAIN_HI)) {   // the records as non-temporal loads (small batches and the largest)
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4>), grid, block, 0, s, a); }
+    } else {                                                     // state and rows fit the Infinity Cache: plain loads keep the state there
+        if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, false, 64, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, false, 64, false>), grid, block, 0, s, a); }
+        else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, false, 64, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, false, 64, false>), grid, block, 0, s, a); }
     }
 }
 

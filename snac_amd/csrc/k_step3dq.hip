@@ -18,7 +18,7 @@ namespace {
 // Four times the waves of k_step3d (4096 at 65 536 envs: four per SIMD), each with a quarter of its loads, a quarter of its window
 // cells and a quarter of its row stores.  Semantics are K3D::step's in k_step3ds' formulation.  Canonical layout, identity rows,
 // N % 4 = 0, aligned obs; the dispatch table's SNAC_STEP3D_QUARTER_* entries say for which N.
-template <bool DYN, typename OT, int WPB>
+template <bool DYN, typename OT, int WPB, bool NTL>
 __global__ __launch_bounds__(WPB * 64) void k_step3dq(const KArgs a) {
     using K = K3D<DYN, 8>;
     constexpr int E = 16, GE = K::GE, NPC = 26, SPAN = NPC * 16, NIT = (E * NPC + 63) / 64;   // pieces and bytes per env; load instructions per wave
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WPB * 64) void k_step3dq(const KArgs a) {
             const bool hit = (q1 >= ql && q1 <= qh && c1 <= ch && e1 >= cl) || (e2 >= 0 && q1 + 1 >= ql && q1 + 1 <= qh && cl <= e2);
             pc[it] = make_uint4(0u, 0u, 0u, 0u);
             if (P < E * NPC && !sk && off + 16 <= GE * 2 && hit) {
-                const u32x4 t = __builtin_nontemporal_load((const u32x4*)((const char*)a.grid + (size_t)(env0 + e) * (GE * 2) + off));
+                const u32x4 t = load_nt_if<NTL>((const u32x4*)((const char*)a.grid + (size_t)(env0 + e) * (GE * 2) + off));
                 pc[it] = make_uint4(t.x, t.y, t.z, t.w);
             }
         }
@@ -172,7 +172,9 @@ template <bool DYN, typename OT>
 void launch_q(const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + 15) / 16;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    hipLaunchKernelGGL((k_step3dq<DYN, OT, 4>), grid, block, 0, s, a);
+    // the spans as non-temporal loads from SNAC_STEP3D_NTLOAD_MIN envs on (below, state and rows fit the Infinity Cache: the state is better kept there)
+    if (a.n >= snac_detail::tune(snac_detail::TN_STEP3D_NTLOAD_MIN)) hipLaunchKernelGGL((k_step3dq<DYN, OT, 4, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_step3dq<DYN, OT, 4, false>), grid, block, 0, s, a);
 }
 
 }  // namespace

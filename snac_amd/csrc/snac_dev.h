@@ -709,6 +709,15 @@ __device__ __forceinline__ void emit_obs(uint32_t* lds, OT* orow, int nenv, cons
 // nenv < 64: a ragged tile (nenv * 51 * sizeof(OT) must be a multiple of 16: the callers require N % 4 == 0).
 constexpr int TILE_STG_BYTES = 13 * 1024;
 
+// a load that is, or is not, non-temporal: state that a step kernel reads once per tick should not stay in the caches when the batch is
+// large (k_step3dq at 524 288 envs: 70 us with non-temporal span loads, 101 with plain ones) and SHOULD when the whole state fits
+// them (65 536 envs: 12.8 us non-temporal, 11.5 plain) -- the launch picks by batch size (SNAC_STEP3D_NTLOAD_MIN, SNAC_STEP2D_PLAIN_LO / _HI; profiles/r06_step_loads.txt)
+template <bool NT, typename V>
+__device__ __forceinline__ V load_nt_if(const V* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
 // a 16-byte store; NT: non-temporal (streamed rows that nobody reads back soon: they do not displace what a kernel's gathered reads find
 // in L2 / the Infinity Cache -- k_edges2dp's node records)
 template <bool NT>

@@ -109,3 +109,12 @@ def test_unaligned_rows_and_odd_batches_stay_on_the_other_kernels():
     assert _lib.lib().snac_last_kernel() != b"k_step3dq"             # rows that do not start on 16 bytes
     e.step(auto_reset=True)
     assert _lib.lib().snac_last_kernel() == b"k_step3dq"
+
+
+@pytest.mark.parametrize("n", [245756, 245760])
+def test_both_forms_of_the_span_loads_at_their_threshold(n):
+    """Round 6: below 245 760 envs (SNAC_STEP3D_NTLOAD_MIN) the spans are read with plain loads -- state and rows fit the Infinity Cache,
+    the state is better kept there --, from there on with non-temporal ones: the same rows either side (and the largest batch this file
+    steps against the oracle)."""
+    env, orc, cast = _pair(True, n, seed=21, f32=False, total_step=25)
+    _walk(env, orc, cast, 8, np.random.default_rng(3), explicit_from=4)

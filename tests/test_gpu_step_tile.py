@@ -205,3 +205,19 @@ def test_layout_variants_of_large_batches_step_on_the_tile_form(dim, dyn, kw, f3
         s, e = orc.stats(), env.episodic_stats()
         assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
         assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+
+
+@pytest.mark.parametrize("n", [73724, 73728, 491520, 491524])
+def test_2d_records_by_plain_and_by_non_temporal_loads(n):
+    """Round 6: k_step2d reads its records with plain loads from 73 728 to 491 520 envs (state and rows fit the Infinity Cache: the state is
+    better kept there) and with non-temporal loads outside -- the same rows on either side of both thresholds, against the oracle."""
+    from snac_amd import _lib
+
+    env, orc = _pair(2, True, n, seed=8, total_step=12)
+    for t in range(6):
+        og, rg, dg = env.step(auto_reset=True)
+        assert _lib.lib().snac_last_kernel() == b"k_step2d"
+        oc, rc, dc = orc.step(t, auto_reset=True, nthreads=16)
+        assert og.cpu().numpy().tobytes() == oc.tobytes(), t
+        assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
+    _end_state(env, orc)
