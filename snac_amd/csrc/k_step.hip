@@ -26,7 +26,9 @@ namespace {
 // tens of thousands of envs per tick reads): the rows leave through emit_rows_var (k_rollout2d's row assembly), the plan tail from the
 // lanes' plan rows in LDS.  25 KB of LDS per wave, one block of four waves per CU -- 65 536 envs are exactly one round.
 // TE = 32: half-filled tiles (lanes 32 .. 63 idle) -- twice the waves for batches that do not fill the CUs with 64 rows of kilobytes per wave.
-template <bool DYN, typename OT, int WPB, bool VAR = false, int TE = 64, bool NTL = true>
+// NTL / NTS (canonical rows only): the records by non-temporal loads / the rows by non-temporal stores -- which pays depends on whether state
+// and rows fit the Infinity Cache: the launch picks one of three forms by batch size (profiles/r06_step_loads.txt)
+template <bool DYN, typename OT, int WPB, bool VAR = false, int TE = 64, bool NTL = true, bool NTS = false>
 __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
     using K = K2D<DYN, 64>;
     constexpr int E = TE, GE = K::GE;
@@ -149,8 +151,8 @@ __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
         emit_rows_var<OT>((char*)rec, cmp, (char*)a.obs + (size_t)env0 * (size_t)a.ld * sizeof(OT), lane, nenv, a.ld, a.tail, a.frame_val, wr, v0, v1,
                           recv, [&](int e, int row) { return pl[row * 65 + e]; });
     } else {
-        emit_tile<OT, ROWS_NT_STEP>((char*)rec, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv,
-                                    [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; }, v0, v1);
+        emit_tile<OT, NTS>((char*)rec, (char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv,
+                           [&](int el) { const int i = el / 7, j = el - 7 * i; return ((int)(wr[i] << (30 - 2 * j))) >> 30; }, v0, v1);
     }
 }
 
@@ -536,10 +538,13 @@ void launch_step2d(const snac_env_desc* d, const KArgs& a, bool half, hipStream_
     } else if (a.variant) {
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, true>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, true>), grid, block, 0, s, a); }
-    } else if (a.n < tune(TN_STEP2D_PLAIN_LO) || a.n > tune(TN_STEP2D_PLAIN_HI)) {   // the records as non-temporal loads (small batches and the largest)
+    } else if (a.n < tune(TN_STEP2D_PLAIN_LO) || a.n > tune(TN_STEP2D_PLAIN_HI)) {   // small batches and the largest: non-temporal record loads, plain rows
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4>), grid, block, 0, s, a); }
-    } else {                                                     // state and rows fit the Infinity Cache: plain loads keep the state there
+    } else if (a.n <= tune(TN_STEP2D_RES_HI)) {                  // the "resident" form: plain loads keep the state in the Infinity Cache, non-temporal rows stay out of it
+        if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, false, 64, false, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, false, 64, false, true>), grid, block, 0, s, a); }
+        else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, false, 64, false, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, false, 64, false, true>), grid, block, 0, s, a); }
+    } else {                                                     // in between: plain loads, plain rows
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, false, 64, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, false, 64, false>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, false, 64, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, false, 64, false>), grid, block, 0, s, a); }
     }

@@ -138,7 +138,8 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_1D_TP_EB8_MIN   */ {"SNAC_1D_TP_EB8_MIN", 3584, "k_rollout1dt blocks hold 8 envs from this many envs (two blocks share a CU: one computes its chunk while the other's rows leave; 4096 envs: 0.045 against 0.048 ms on 16-env blocks, 32 768: 0.351 / 0.421, 65 536: 0.685 / 0.920; r06_1d.txt) ..."},
     /* TN_1D_TP_EB8_MAX   */ {"SNAC_1D_TP_EB8_MAX", 1 << 30, "... up to this many"},
     /* TN_STEP3D_NTLOAD_MIN */ {"SNAC_STEP3D_NTLOAD_MIN", 245760, "k_step3dq from this many envs on: non-temporal span loads + plain row stores; below, where state and rows fit the Infinity Cache: plain span loads (the state stays cached) + non-temporal row stores (65 536 envs: 12.9 -> 10.5 us per tick, 131 072: 24.1 -> 19.1; 262 144: 39.6 against 41.3 / 43.5 the other way, 524 288: 71 against 101; r06_step_loads.txt)"},
-    /* TN_STEP2D_PLAIN_LO */ {"SNAC_STEP2D_PLAIN_LO", 73728, "k_step2d reads its records with PLAIN loads from this many envs ..."},
+    /* TN_STEP2D_PLAIN_LO */ {"SNAC_STEP2D_PLAIN_LO", 20480, "k_step2d reads its records with PLAIN loads from this many envs (below: non-temporal loads, plain rows: 16 384 envs 6.5 against 6.8 us) ..."},
+    /* TN_STEP2D_RES_HI   */ {"SNAC_STEP2D_RES_HI", 278528, "k_step2d inside SNAC_STEP2D_PLAIN_LO .. this many envs also stores its rows NON-TEMPORALLY (the resident form: 32 768 envs 7.9 -> 6.8 us per tick, 65 536: 8.4 -> 7.7-7.8, 262 144: 22.6 -> 22.3; 294 912: 24.7 against 24.9, 458 752: 37.0 against 39.7)"},
     /* TN_STEP2D_PLAIN_HI */ {"SNAC_STEP2D_PLAIN_HI", 491520, "... up to this many, with non-temporal loads outside (81 920 envs: 10.6 -> 10.4 us, 262 144: 26.5 -> 22.7, 458 752: 41.5 -> 37.0; 65 536: 8.4 against 8.75 plain, 524 288: 46.5 against 49.4)"},
     /* TN_NODES2D_NT      */ {"SNAC_NODES2D_NT", 1, "k_edges2dp (2D edges on node records): 1 = the observation rows leave as NON-TEMPORAL stores -- streamed rows then do not displace the node records in the Infinity Cache (65.1 -> 50.3 us per 524 288 edges of a 2^20-record pool, r06_edges.txt)"},
 };
