@@ -151,13 +151,34 @@ __global__ __launch_bounds__(256) void k_nodes2d_copy(int4* hdr, int32_t* episod
 }
 
 template <bool DYN, typename OT>
-void launch_edges2dp(const KArgs& a, hipStream_t s) {
-    // whole 16-byte pieces of rows (m % 4 = 0, an aligned obs) through emit_tile; a ragged or unaligned wave writes its rows value by value
-    const bool vec = ((uintptr_t)a.obs & 15) == 0 && (a.n & 3) == 0;
+void launch_edges2dp_part(const KArgs& a, bool vec, hipStream_t s) {
     const dim3 grid((unsigned)(((a.n + 63) / 64 + 3) / 4)), block(256);
     if (!vec) hipLaunchKernelGGL((k_edges2dp<DYN, OT, 4, false, false>), grid, block, 0, s, a);
     else if (snac_detail::tune(snac_detail::TN_NODES2D_NT) != 0) hipLaunchKernelGGL((k_edges2dp<DYN, OT, 4, true, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_edges2dp<DYN, OT, 4, true, false>), grid, block, 0, s, a);
+}
+
+template <bool DYN, typename OT>
+void launch_edges2dp(const KArgs& a, hipStream_t s) {
+    // whole 16-byte pieces of rows (m % 4 = 0, an aligned obs) through emit_tile; otherwise rows value by value.  A wave of m % 4 != 0
+    // edges -- five actions per parent make most expansions such -- runs its first m & ~3 edges the fast way and the last one to three as a
+    // launch of their own (possible when both index arrays are given: edge i of the tail is edge head + i of the call)
+    const bool aligned = !a.obs || ((uintptr_t)a.obs & 15) == 0;
+    const int head = a.n & ~3;
+    if (aligned && head == a.n) { launch_edges2dp_part<DYN, OT>(a, true, s); return; }
+    if (!aligned || head == 0 || !a.src_index || !a.dst_index) { launch_edges2dp_part<DYN, OT>(a, false, s); return; }
+    KArgs h = a, t = a;
+    h.n = head;
+    t.n = a.n - head;
+    t.src_index += head; t.dst_index += head;
+    if (t.actions) t.actions += head;
+    if (t.step_size) t.step_size += head;
+    if (t.reward) t.reward += head;
+    if (t.done) t.done += head;
+    if (t.obs) t.obs = (char*)t.obs + (size_t)head * 51 * sizeof(OT);
+    t.env_id_base += head;                                           // the counter RNG is keyed by the edge's index in the call
+    launch_edges2dp_part<DYN, OT>(h, true, s);
+    launch_edges2dp_part<DYN, OT>(t, false, s);                      // (its rows start where the head's end: 16-byte alignment is not needed here)
 }
 
 }  // namespace
