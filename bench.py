@@ -835,9 +835,10 @@ def main():
 
         def facade_cfg(name, steps=3000):
             """The single-env drop-in class as a DQN script drives it (Env/2D/DMP_Env_2D_dynamic_usedata_plan.py: one env.step(action) per
-            loop turn, np.random step sizes, reset on done), host-timed: one launch + one wait per step.  The reference's own class does
-            110 k steps/s on one core of the build container: the drop-in classes are the PARITY surface -- a
-            script runs unchanged, at about half the reference's single-env rate -- and BatchedDMPEnv is the THROUGHPUT surface."""
+            loop turn, np.random step sizes, reset on done), host-timed: a doorbell and an acknowledgement of the env's resident wavefront per
+            step.  For scale only: the reference's own class does 110 k steps/s on one core of the BUILD container (another CPU, BASELINE.md
+            section 2); this box's own host is timed in cpu_baseline.python_loop_n1024.  The drop-in classes are the PARITY surface,
+            BatchedDMPEnv is the THROUGHPUT surface."""
             import numpy as np
 
             from snac_amd.envs import deep_mobile_printing_2d1r_dynamic
@@ -866,7 +867,7 @@ def main():
 
         def vector_cfg(name, nn, steps=1500):
             """VectorizedEnvWrapper.step(actions) (multiprocess.py:15-32 on the HIP path: numpy in, numpy out), host-timed, with the
-            reference's default --num_envs 3, 64 envs (the largest batch of the resident-wave path) and 256 (one launch + one wait per
+            reference's default --num_envs 3, 64 envs (one resident wave) and 256 (four: the largest batch of the resident path; round 5: one launch + one wait per
             vector step).  The reference wrapper steps its N envs one after the other at ~9 us each."""
             import numpy as np
 
