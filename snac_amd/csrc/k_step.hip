@@ -538,15 +538,29 @@ void launch_step2d(const snac_env_desc* d, const KArgs& a, bool half, hipStream_
     } else if (a.variant) {
         if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, true>), grid, block, 0, s, a); }
         else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, true>), grid, block, 0, s, a); }
-    } else if (a.n < tune(TN_STEP2D_PLAIN_LO) || a.n > tune(TN_STEP2D_PLAIN_HI)) {   // small batches and the largest: non-temporal record loads, plain rows
-        if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4>), grid, block, 0, s, a); }
-        else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4>), grid, block, 0, s, a); }
-    } else if (a.n <= tune(TN_STEP2D_RES_HI)) {                  // the "resident" form: plain loads keep the state in the Infinity Cache, non-temporal rows stay out of it
-        if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, false, 64, false, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, false, 64, false, true>), grid, block, 0, s, a); }
-        else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, false, 64, false, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, false, 64, false, true>), grid, block, 0, s, a); }
-    } else {                                                     // in between: plain loads, plain rows
-        if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, false, 64, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, false, 64, false>), grid, block, 0, s, a); }
-        else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, false, 64, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, false, 64, false>), grid, block, 0, s, a); }
+    } else {
+        // canonical rows: four forms (bit 0: the records by non-temporal loads, bit 1: the rows by non-temporal stores), picked by what fits
+        // the Infinity Cache at this batch size (profiles/r06_step_loads.txt); SNAC_STEP2D_FORM forces one
+        int form = tune(TN_STEP2D_FORM);
+        if (form < 0) {
+            if (a.n < tune(TN_STEP2D_PLAIN_LO)) form = 1;            // small batches: round 5's form
+            else if (a.n <= tune(TN_STEP2D_RES_HI)) form = 2;        // "resident": plain loads keep the state cached, non-temporal rows stay out of it
+            else if (a.n <= tune(TN_STEP2D_PLAIN_HI)) form = 0;      // plain loads, plain rows
+            else if (a.n < tune(TN_STEP2D_HUGE_MIN)) form = 1;       // the state streams
+            else form = tune(TN_STEP2D_HUGE_FORM);                   // the rows of one tick alone overflow the cache
+        }
+#define SNAC_STEP2D_LAUNCH(NTL, NTS)                                                                                                                                            \
+        do {                                                                                                                                                                   \
+            if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, false, 64, NTL, NTS>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, false, 64, NTL, NTS>), grid, block, 0, s, a); } \
+            else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, false, 64, NTL, NTS>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, false, 64, NTL, NTS>), grid, block, 0, s, a); } \
+        } while (0)
+        switch (form & 3) {
+            case 0: SNAC_STEP2D_LAUNCH(false, false); break;
+            case 1: SNAC_STEP2D_LAUNCH(true, false); break;
+            case 2: SNAC_STEP2D_LAUNCH(false, true); break;
+            default: SNAC_STEP2D_LAUNCH(true, true); break;
+        }
+#undef SNAC_STEP2D_LAUNCH
     }
 }
 

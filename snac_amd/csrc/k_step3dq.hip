@@ -18,10 +18,11 @@ namespace {
 // Four times the waves of k_step3d (4096 at 65 536 envs: four per SIMD), each with a quarter of its loads, a quarter of its window
 // cells and a quarter of its row stores.  Semantics are K3D::step's in k_step3ds' formulation.  Canonical layout, identity rows,
 // N % 4 = 0, aligned obs; the dispatch table's SNAC_STEP3D_QUARTER_* entries say for which N.
-// RES: the batch is small enough for state AND rows to fit the Infinity Cache (below SNAC_STEP3D_NTLOAD_MIN envs): the spans are read with
-// plain loads (they stay cached for the next tick) and the rows leave as non-temporal stores (they do not displace the state); above, the
-// other way round -- non-temporal span loads, plain row stores (profiles/r06_step_loads.txt: 65 536 envs 12.9 -> 10.5 us per tick).
-template <bool DYN, typename OT, int WPB, bool RES>
+// NTL / NTS: the spans by non-temporal loads / the rows by non-temporal stores.  Which pays depends on what fits the 256 MB Infinity Cache
+// (profiles/r06_step_loads.txt): while the STATE fits (below ~360 000 envs) plain loads keep it there for the next tick and non-temporal
+// rows stay out of its way ("resident": 65 536 envs 12.9 -> 10.4 us per tick); from there to ~600 000 envs the state streams (non-temporal
+// loads) and plain rows do best; beyond, the rows alone overflow the cache and must not go through it.  The launch picks the form.
+template <bool DYN, typename OT, int WPB, bool NTL, bool NTS>
 __global__ __launch_bounds__(WPB * 64) void k_step3dq(const KArgs a) {
     using K = K3D<DYN, 8>;
     constexpr int E = 16, GE = K::GE, NPC = 26, SPAN = NPC * 16, NIT = (E * NPC + 63) / 64;   // pieces and bytes per env; load instructions per wave
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(WPB * 64) void k_step3dq(const KArgs a) {
             const bool hit = (q1 >= ql && q1 <= qh && c1 <= ch && e1 >= cl) || (e2 >= 0 && q1 + 1 >= ql && q1 + 1 <= qh && cl <= e2);
             pc[it] = make_uint4(0u, 0u, 0u, 0u);
             if (P < E * NPC && !sk && off + 16 <= GE * 2 && hit) {
-                const u32x4 t = load_nt_if<!RES>((const u32x4*)((const char*)a.grid + (size_t)(env0 + e) * (GE * 2) + off));
+                const u32x4 t = load_nt_if<NTL>((const u32x4*)((const char*)a.grid + (size_t)(env0 + e) * (GE * 2) + off));
                 pc[it] = make_uint4(t.x, t.y, t.z, t.w);
             }
         }
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(WPB * 64) void k_step3dq(const KArgs a) {
         for (int i = 0; i < NF; ++i) fv[i] = *(const uint4*)(scr + min(i * 1024 + lane * 16, WAVE_LDS - 16));
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-            if (i * 1024 + lane * 16 < validb) store16<RES>(g + i * 1024 + lane * 16, fv[i]);
+            if (i * 1024 + lane * 16 < validb) store16<NTS>(g + i * 1024 + lane * 16, fv[i]);
     }
 }
 
@@ -175,8 +176,15 @@ template <bool DYN, typename OT>
 void launch_q(const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + 15) / 16;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    if (a.n >= snac_detail::tune(snac_detail::TN_STEP3D_NTLOAD_MIN)) hipLaunchKernelGGL((k_step3dq<DYN, OT, 4, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_step3dq<DYN, OT, 4, true>), grid, block, 0, s, a);
+    using namespace snac_detail;
+    int form = tune(TN_STEP3D_FORM);                                 // bit 0: non-temporal span loads, bit 1: non-temporal row stores; < 0: by batch size
+    if (form < 0) form = a.n < tune(TN_STEP3D_NTLOAD_MIN) ? 2 : (a.n < tune(TN_STEP3D_HUGE_MIN) ? 1 : tune(TN_STEP3D_HUGE_FORM));
+    switch (form & 3) {
+        case 0: hipLaunchKernelGGL((k_step3dq<DYN, OT, 4, false, false>), grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_step3dq<DYN, OT, 4, true, false>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_step3dq<DYN, OT, 4, false, true>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_step3dq<DYN, OT, 4, true, true>), grid, block, 0, s, a); break;
+    }
 }
 
 }  // namespace

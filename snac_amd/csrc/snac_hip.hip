@@ -137,10 +137,16 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_STEP3D_QUARTER_MAX*/ {"SNAC_STEP3D_QUARTER_MAX", 1 << 30, "... up to this many (524 288: 67.5 against k_step3ds' 76.6 us, 131 072: 23.9 / 23.6)"},
     /* TN_1D_TP_EB8_MIN   */ {"SNAC_1D_TP_EB8_MIN", 3584, "k_rollout1dt blocks hold 8 envs from this many envs (two blocks share a CU: one computes its chunk while the other's rows leave; 4096 envs: 0.045 against 0.048 ms on 16-env blocks, 32 768: 0.351 / 0.421, 65 536: 0.685 / 0.920; r06_1d.txt) ..."},
     /* TN_1D_TP_EB8_MAX   */ {"SNAC_1D_TP_EB8_MAX", 1 << 30, "... up to this many"},
-    /* TN_STEP3D_NTLOAD_MIN */ {"SNAC_STEP3D_NTLOAD_MIN", 245760, "k_step3dq from this many envs on: non-temporal span loads + plain row stores; below, where state and rows fit the Infinity Cache: plain span loads (the state stays cached) + non-temporal row stores (65 536 envs: 12.9 -> 10.5 us per tick, 131 072: 24.1 -> 19.1; 262 144: 39.6 against 41.3 / 43.5 the other way, 524 288: 71 against 101; r06_step_loads.txt)"},
+    /* TN_STEP3D_NTLOAD_MIN */ {"SNAC_STEP3D_NTLOAD_MIN", 376832, "k_step3dq from this many envs on: non-temporal span loads + plain row stores; below, where state and rows fit the Infinity Cache: plain span loads (the state stays cached) + non-temporal row stores (65 536 envs: 12.9 -> 10.5 us per tick, 131 072: 24.1 -> 19.1; 262 144: 39.6 against 41.3 / 43.5 the other way, 524 288: 71 against 101; r06_step_loads.txt)"},
+    /* TN_STEP3D_HUGE_MIN */ {"SNAC_STEP3D_HUGE_MIN", 557056, "k_step3dq from this many envs on (the rows of one tick alone overflow the Infinity Cache): the form SNAC_STEP3D_HUGE_FORM"},
+    /* TN_STEP3D_HUGE_FORM*/ {"SNAC_STEP3D_HUGE_FORM", 3, "bit 0: non-temporal span loads, bit 1: non-temporal row stores (655 360 envs: 135 us per tick with 1, 109 with 2, 99 with 3; 1 048 576: 237 / 160 / 157)"},
+    /* TN_STEP3D_FORM     */ {"SNAC_STEP3D_FORM", -1, "k_step3dq: force a form (bits as above) whatever the batch size; -1: by batch size"},
     /* TN_STEP2D_PLAIN_LO */ {"SNAC_STEP2D_PLAIN_LO", 20480, "k_step2d reads its records with PLAIN loads from this many envs (below: non-temporal loads, plain rows: 16 384 envs 6.5 against 6.8 us) ..."},
     /* TN_STEP2D_RES_HI   */ {"SNAC_STEP2D_RES_HI", 278528, "k_step2d inside SNAC_STEP2D_PLAIN_LO .. this many envs also stores its rows NON-TEMPORALLY (the resident form: 32 768 envs 7.9 -> 6.8 us per tick, 65 536: 8.4 -> 7.7-7.8, 262 144: 22.6 -> 22.3; 294 912: 24.7 against 24.9, 458 752: 37.0 against 39.7)"},
-    /* TN_STEP2D_PLAIN_HI */ {"SNAC_STEP2D_PLAIN_HI", 491520, "... up to this many, with non-temporal loads outside (81 920 envs: 10.6 -> 10.4 us, 262 144: 26.5 -> 22.7, 458 752: 41.5 -> 37.0; 65 536: 8.4 against 8.75 plain, 524 288: 46.5 against 49.4)"},
+    /* TN_STEP2D_PLAIN_HI */ {"SNAC_STEP2D_PLAIN_HI", 475136, "... up to this many, with non-temporal loads outside (81 920 envs: 10.6 -> 10.4 us, 262 144: 26.5 -> 22.7, 458 752: 41.5 -> 37.0; 65 536: 8.4 against 8.75 plain, 524 288: 46.5 against 49.4)"},
+    /* TN_STEP2D_HUGE_MIN */ {"SNAC_STEP2D_HUGE_MIN", 475137, "k_step2d from this many envs on: the form SNAC_STEP2D_HUGE_FORM (the 2D state of a million envs is 105 MB: it fits the Infinity Cache at every batch size, the rows of a tick do not)"},
+    /* TN_STEP2D_HUGE_FORM*/ {"SNAC_STEP2D_HUGE_FORM", 2, "bit 0: non-temporal record loads, bit 1: non-temporal row stores (524 288 envs: 46.4 us per tick with 1, 43.5 with 2; 1 048 576: 146 / 82; r06_step_loads.txt)"},
+    /* TN_STEP2D_FORM     */ {"SNAC_STEP2D_FORM", -1, "k_step2d, canonical rows: force a form (bits as above) whatever the batch size; -1: by batch size"},
     /* TN_NODES2D_NT      */ {"SNAC_NODES2D_NT", 1, "k_edges2dp (2D edges on node records): 1 = the observation rows leave as NON-TEMPORAL stores -- streamed rows then do not displace the node records in the Infinity Cache (65.1 -> 50.3 us per 524 288 edges of a 2^20-record pool, r06_edges.txt)"},
 };
 

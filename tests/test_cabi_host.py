@@ -168,7 +168,7 @@ def test_dispatch_table_is_one_table_with_documented_entries():
     assert len(t) >= 62 and all(k.startswith("SNAC_") and what for k, (v, what) in t.items())
     want = {"SNAC_3D_PIPELINE": 1, "SNAC_2D_STAGE_MIN_F64": 32769, "SNAC_2D_STAGE_MIN_F32": 32768, "SNAC_2D_TP_MAX_F64": 19456, "SNAC_2D_TP_GAP_LO": 15873,
             "SNAC_2D_TP_GAP_HI": 16384, "SNAC_2D_TP_MAX_F32": 30719, "SNAC_2D_TP_VAR_MAX_PLAN": 49152, "SNAC_2D_TP_VAR_MAX_SHORT": 6144, "SNAC_2D_TILE32_MIN": 22528,
-            "SNAC_1D_TP_MAX_F64": 65536, "SNAC_1D_TP_EB8_MIN": 3584, "SNAC_NODES2D_NT": 1, "SNAC_STEP3D_NTLOAD_MIN": 245760, "SNAC_STEP2D_PLAIN_LO": 20480, "SNAC_STEP2D_RES_HI": 278528, "SNAC_STEP2D_PLAIN_HI": 491520, "SNAC_1D_TP_MAX_F32": 65536, "SNAC_3D_BLOCK_MIN_F64": 4096, "SNAC_3D_BLOCK_MIN_F32": 4096,
+            "SNAC_1D_TP_MAX_F64": 65536, "SNAC_1D_TP_EB8_MIN": 3584, "SNAC_NODES2D_NT": 1, "SNAC_STEP3D_NTLOAD_MIN": 376832, "SNAC_STEP3D_HUGE_MIN": 557056, "SNAC_STEP3D_HUGE_FORM": 3, "SNAC_STEP3D_FORM": -1, "SNAC_STEP2D_PLAIN_LO": 20480, "SNAC_STEP2D_RES_HI": 278528, "SNAC_STEP2D_PLAIN_HI": 475136, "SNAC_STEP2D_HUGE_MIN": 475137, "SNAC_STEP2D_HUGE_FORM": 2, "SNAC_STEP2D_FORM": -1, "SNAC_1D_TP_MAX_F32": 65536, "SNAC_3D_BLOCK_MIN_F64": 4096, "SNAC_3D_BLOCK_MIN_F32": 4096,
             "SNAC_STEP3D_SPAN_MIN": 81920, "SNAC_3D_BLOCK_VAR": 1, "SNAC_3D_BLOCK_VAR_MIN": 64, "SNAC_3D_BLOCK_VAR_PLAN_F64": 10240, "SNAC_3D_BLOCK_VAR_PLAN_F32": 16384,
             "SNAC_2D_BLOCK": 1, "SNAC_2D_BLOCK_MIN_F64": 11264, "SNAC_2D_BLOCK_MAX_F64": 32768, "SNAC_2D_BLOCK_MIN_F32": 15360, "SNAC_2D_BLOCK_MAX_F32": 32768,
             "SNAC_2D_BLOCK_TWO_F64": 16384, "SNAC_2D_BLOCK_TWO_F32": 16385, "SNAC_2D_BLOCK_VAR_MIN": 6148, "SNAC_2D_BLOCK_VAR_MAX": 32768, "SNAC_2D_BLOCK_VAR_TWO": 16385, "SNAC_STEP3D_QUARTER": 1, "SNAC_STEP3D_QUARTER_MIN": 4, "SNAC_STEP3D_QUARTER_MAX": 1 << 30, "SNAC_2D_BLOCK_FOUR_MAX_F64": 38912, "SNAC_2D_BLOCK_FOUR_MAX_F32": 45056, "SNAC_STEP_VAR_MIN_SHORT": 24576, "SNAC_STEP_VAR_FULL_F64": 45056, "SNAC_STEP_VAR_FULL_F32": 32769, "SNAC_STEP_VAR3_MIN": 24576}

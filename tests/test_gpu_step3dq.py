@@ -111,10 +111,10 @@ def test_unaligned_rows_and_odd_batches_stay_on_the_other_kernels():
     assert _lib.lib().snac_last_kernel() == b"k_step3dq"
 
 
-@pytest.mark.parametrize("n", [245756, 245760])
-def test_both_forms_of_the_span_loads_at_their_threshold(n):
-    """Round 6: below 245 760 envs (SNAC_STEP3D_NTLOAD_MIN) the spans are read with plain loads -- state and rows fit the Infinity Cache,
-    the state is better kept there --, from there on with non-temporal ones: the same rows either side (and the largest batch this file
-    steps against the oracle)."""
+@pytest.mark.parametrize("n", [376828, 376832, 557052, 557056])
+def test_the_forms_of_loads_and_stores_at_their_thresholds(n):
+    """Round 6: k_step3dq picks a form by batch size -- below 376 832 envs (SNAC_STEP3D_NTLOAD_MIN) the "resident" form: plain span loads
+    (the state stays in the Infinity Cache) + non-temporal row stores; up to 557 056 (SNAC_STEP3D_HUGE_MIN) non-temporal loads + plain rows;
+    above, both non-temporal -- the same rows on either side of both thresholds (and the largest batches this file steps against the oracle)."""
     env, orc, cast = _pair(True, n, seed=21, f32=False, total_step=25)
-    _walk(env, orc, cast, 8, np.random.default_rng(3), explicit_from=4)
+    _walk(env, orc, cast, 6, np.random.default_rng(3), explicit_from=3)

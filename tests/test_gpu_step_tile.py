@@ -207,11 +207,11 @@ def test_layout_variants_of_large_batches_step_on_the_tile_form(dim, dyn, kw, f3
         assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
 
 
-@pytest.mark.parametrize("n", [20476, 20480, 278528, 278532, 491520, 491524])
+@pytest.mark.parametrize("n", [20476, 20480, 278528, 278532, 475136, 475140])
 def test_2d_records_by_plain_and_by_non_temporal_loads(n):
-    """Round 6: k_step2d has three forms by batch size -- non-temporal record loads + plain rows below 20 480 and above 491 520 envs; the
-    "resident" form from 20 480 to 278 528 envs (plain loads keep the state in the Infinity Cache, non-temporal rows stay out of it); plain
-    loads + plain rows in between -- the same rows on either side of every threshold, against the oracle."""
+    """Round 6: k_step2d picks a form by batch size -- non-temporal record loads + plain rows below 20 480 envs; the "resident" form (plain
+    loads keep the state in the Infinity Cache, non-temporal rows stay out of it) from 20 480 to 278 528 envs and again above 475 136;
+    plain loads + plain rows in between -- the same rows on either side of every threshold, against the oracle."""
     from snac_amd import _lib
 
     env, orc = _pair(2, True, n, seed=8, total_step=12)
