@@ -79,15 +79,17 @@ CROSSOVERS = [
      {"SNAC_3D_BLOCK_VAR_PLAN_F32": "4"}, {"SNAC_3D_BLOCK_VAR": "0"}, "min", [8192, 10240, 12288, 14336, 16384, 32768, 65536]),
     ("SNAC_STEP3D_SPAN_MIN", "k_step3ds (cooperative span loads) | k_step3d, 3D canonical rows per tick", dict(kind=3, T=1, f32=0, layout=None, mode="step"),
      {"SNAC_STEP3D_SPAN_MIN": "4"}, {"SNAC_STEP3D_SPAN": "0"}, "min", [32768, 65536, 81920, 98304, 131072, 262144]),
-    # round 6: which FORM of a kernel a batch size takes (state loads / row stores non-temporal or plain: whether state and rows fit the Infinity Cache)
-    ("SNAC_STEP3D_NTLOAD_MIN", "k_step3dq: non-temporal span loads + plain rows | resident form (plain loads + non-temporal rows), 3D canonical rows per tick",
-     dict(kind=3, T=1, f32=0, layout=None, mode="step"), {"SNAC_STEP3D_NTLOAD_MIN": "1"}, {"SNAC_STEP3D_NTLOAD_MIN": "100000000"}, "min", [131072, 196608, 229376, 245760, 262144, 327680]),
-    ("SNAC_STEP2D_PLAIN_LO", "k_step2d: resident form (plain loads + non-temporal rows) | non-temporal loads + plain rows, 2D canonical rows per tick",
-     dict(kind=2, T=1, f32=0, layout=None, mode="step"), {"SNAC_STEP2D_PLAIN_LO": "1", "SNAC_STEP2D_RES_HI": "100000000", "SNAC_STEP2D_PLAIN_HI": "100000000"}, {"SNAC_STEP2D_PLAIN_LO": "100000000"}, "min", [12288, 16384, 20480, 24576, 32768, 49152]),
-    ("SNAC_STEP2D_RES_HI", "k_step2d: resident form | plain loads + plain rows", dict(kind=2, T=1, f32=0, layout=None, mode="step"),
-     {"SNAC_STEP2D_PLAIN_LO": "1", "SNAC_STEP2D_RES_HI": "100000000", "SNAC_STEP2D_PLAIN_HI": "100000000"}, {"SNAC_STEP2D_PLAIN_LO": "1", "SNAC_STEP2D_RES_HI": "1", "SNAC_STEP2D_PLAIN_HI": "100000000"}, "max", [229376, 262144, 278528, 294912, 327680]),
-    ("SNAC_STEP2D_PLAIN_HI", "k_step2d: plain loads + plain rows | non-temporal loads + plain rows", dict(kind=2, T=1, f32=0, layout=None, mode="step"),
-     {"SNAC_STEP2D_PLAIN_LO": "1", "SNAC_STEP2D_RES_HI": "1", "SNAC_STEP2D_PLAIN_HI": "100000000"}, {"SNAC_STEP2D_PLAIN_LO": "100000000"}, "max", [393216, 458752, 491520, 524288, 589824]),
+    # round 6: which FORM of a step kernel a batch size takes (form bits: 1 = non-temporal state loads, 2 = non-temporal row stores; what fits the Infinity Cache)
+    ("SNAC_STEP3D_NTLOAD_MIN", "k_step3dq: form 1 (non-temporal span loads + plain rows) | form 2 (resident: plain loads + non-temporal rows), 3D canonical rows per tick",
+     dict(kind=3, T=1, f32=0, layout=None, mode="step"), {"SNAC_STEP3D_FORM": "1"}, {"SNAC_STEP3D_FORM": "2"}, "min", [262144, 327680, 360448, 376832, 393216, 458752]),
+    ("SNAC_STEP3D_HUGE_MIN", "k_step3dq: form 3 (both non-temporal) | form 1", dict(kind=3, T=1, f32=0, layout=None, mode="step"),
+     {"SNAC_STEP3D_FORM": "3"}, {"SNAC_STEP3D_FORM": "1"}, "min", [491520, 524288, 557056, 589824, 655360]),
+    ("SNAC_STEP2D_PLAIN_LO", "k_step2d: form 2 (resident) | form 1 (round 5's), 2D canonical rows per tick", dict(kind=2, T=1, f32=0, layout=None, mode="step"),
+     {"SNAC_STEP2D_FORM": "2"}, {"SNAC_STEP2D_FORM": "1"}, "min", [12288, 16384, 20480, 24576, 32768, 49152]),
+    ("SNAC_STEP2D_RES_HI", "k_step2d: form 2 (resident) | form 0 (plain loads, plain rows)", dict(kind=2, T=1, f32=0, layout=None, mode="step"),
+     {"SNAC_STEP2D_FORM": "2"}, {"SNAC_STEP2D_FORM": "0"}, "max", [229376, 262144, 278528, 294912, 327680]),
+    ("SNAC_STEP2D_HUGE_MIN", "k_step2d: form 2 (resident) | form 0, the upper end of form 0's range (SNAC_STEP2D_PLAIN_HI = this - 1)", dict(kind=2, T=1, f32=0, layout=None, mode="step"),
+     {"SNAC_STEP2D_FORM": "2"}, {"SNAC_STEP2D_FORM": "0"}, "min", [393216, 458752, 475137, 491520, 524288]),
     ("SNAC_1D_TP_EB8_MIN", "k_rollout1dt in blocks of 8 envs | blocks of 4, 1D float64 rows", dict(kind=1, T=0, f32=0, layout=None, mode="rollout"),
      {"SNAC_1D_TP_EB8_MIN": "1", "SNAC_1D_TP_EB16": "100000000"}, {"SNAC_1D_TP_EB8_MIN": "100000000", "SNAC_1D_TP_EB16": "100000000"}, "min", [1024, 2048, 3072, 3584, 4096, 8192]),
 ]
