@@ -402,7 +402,9 @@ int snac_export_grid(const snac_env_desc* desc, const snac_state* st, double* ou
  *                        device) is waited for, up to SNAC_MAILBOX_TIMEOUT_S seconds (default 120); then the command is WITHDRAWN
  *                        (replaced by a quit of the same sequence number: a wave that starts later leaves without stepping) and the
  *                        call returns SNAC_ERR_HIP with st as the last acknowledged step left it -- or SNAC_OK if the step was served
- *                        while it was being withdrawn.  The mailbox belongs to the device that was current at snac_mailbox_create:
+ *                        while it was being withdrawn.  (A batch of several waves whose launch the limit cut in two: the error string
+ *                        names the waves, as a bit mask, whose 64 envs each HAVE taken the step; the others have not.)
+ *                        The mailbox belongs to the device that was current at snac_mailbox_create:
  *                        its waves are launched there whatever is current later.  While a thread keeps stepping, a wave stays
  *                        resident: a device-wide synchronisation (hipDeviceSynchronize, hipFree) in ANOTHER thread returns only once the
  *                        stepping pauses for idle_us -- synchronise streams or events there instead

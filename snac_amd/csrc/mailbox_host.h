@@ -22,6 +22,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -135,8 +136,10 @@ inline int arm(snac_mailbox* mb, const snac_env_desc* d, const snac_state* st) {
     return SNAC_OK;
 }
 
-// The command cannot be served (in time): take it back.  true: it turns out to have been served after all.  (Leaves the error string alone.)
-inline bool withdraw(snac_mailbox* mb, uint32_t req) {
+// The command cannot be served (in time): take it back.  Returns the set of waves (bit w) that turn out to have served it after all
+// (all of them: the step counts as served; some of them: a batch of several waves whose launch was cut in two by the limit -- the caller
+// is told which envs stepped).  Leaves the error string alone.
+inline uint32_t withdraw(snac_mailbox* mb, uint32_t req) {
     __atomic_store_n(&mb->cmd, command_word(req, MB_QUIT, 0, 1, mb->state_gen), __ATOMIC_RELEASE);
     // a wave that had fetched the step before the word changed is serving it right now (microseconds); one that starts later obeys the QUIT
     const auto t0 = std::chrono::steady_clock::now();
@@ -144,10 +147,12 @@ inline bool withdraw(snac_mailbox* mb, uint32_t req) {
         if (all_acked(mb, req)) break;
         cpu_relax();
     }
-    bool served = all_acked(mb, req);
-    for (int w = 0; w < mb->num_waves && served; ++w) served = host_load(&mb->quit_seq[w]) != req;
+    uint32_t served = 0;
+    for (int w = 0; w < mb->num_waves; ++w)
+        if (host_load(&mb->ack_seq[w]) == req && host_load(&mb->quit_seq[w]) != req) served |= 1u << w;
     return served;
 }
+inline uint32_t all_waves(const snac_mailbox* mb) { return (1u << mb->num_waves) - 1u; }
 
 // a wave that is not resident and has not acknowledged `req`: it left (idle timeout) before it saw the command -- or none was ever launched
 inline bool wave_missing(const snac_mailbox* mb, uint32_t req) {
@@ -198,9 +203,15 @@ inline int await_ack(snac_mailbox* mb, const snac_env_desc* d, const snac_state*
             }
         }
         if (el > std::chrono::milliseconds(mb->timeout_ms)) {
-            if (withdraw(mb, req)) return SNAC_OK;
-            return fail(SNAC_ERR_HIP, "mailbox: no acknowledgement in time (the waves' launch is still queued behind other work); the command was "
-                                      "withdrawn, the state is as the last acknowledged step left it");
+            const uint32_t served = withdraw(mb, req);
+            if (served == all_waves(mb)) return SNAC_OK;
+            if (served == 0)
+                return fail(SNAC_ERR_HIP, "mailbox: no acknowledgement in time (the waves' launch is still queued behind other work); the command was "
+                                          "withdrawn, the state is as the last acknowledged step left it");
+            char msg[200];
+            std::snprintf(msg, sizeof msg, "mailbox: no acknowledgement from every wave in time; the command was withdrawn, but the envs of the waves in "
+                                           "mask 0x%x (64 envs each, wave w = envs 64 w ..) HAVE taken the step", served);
+            return fail(SNAC_ERR_HIP, msg);
         }
     }
 }
@@ -254,7 +265,7 @@ int snac_mailbox_touch(snac_mailbox* mb) {
 int snac_mailbox_step(snac_mailbox* mb, const snac_env_desc* d, const snac_state* st, int32_t action, int32_t step_size) {
     using namespace snac_mb;
     if (!mb || !d || !st) return fail(SNAC_ERR_ARG, "null mailbox / desc / state");
-    if (mb->num_envs != 1) return fail(SNAC_ERR_ARG, "snac_mailbox_step is for a batch of one env (snac_mailbox_step_n)");
+    if (mb->num_envs != 1 || d->num_envs != 1) return fail(SNAC_ERR_ARG, "snac_mailbox_step is for a batch of one env (snac_mailbox_step_n)");
     const int lim = d->kind == SNAC_ENV_1D ? 3 : (d->kind == SNAC_ENV_2D ? 5 : 8);
     post(mb, MB_STEP, (action >= 0 && action < lim) ? action : -1, step_size < 1 ? 1 : (step_size > 3 ? 3 : step_size));   // (every invalid action steps alike)
     return await_ack(mb, d, st);
@@ -263,6 +274,7 @@ int snac_mailbox_step(snac_mailbox* mb, const snac_env_desc* d, const snac_state
 int snac_mailbox_step_n(snac_mailbox* mb, const snac_env_desc* d, const snac_state* st, const int8_t* actions, const int8_t* step_size) {
     using namespace snac_mb;
     if (!mb || !d || !st || !actions || !step_size) return fail(SNAC_ERR_ARG, "null mailbox / desc / state / actions / step_size");
+    if (d->num_envs != mb->num_envs) return fail(SNAC_ERR_ARG, "mailbox of another batch size");   // (before anything is read by its size)
     std::memcpy(mb->actions, actions, (size_t)mb->num_envs);
     std::memcpy(mb->steps, step_size, (size_t)mb->num_envs);
     post(mb, MB_STEP_N, actions[0], step_size[0] < 1 ? 1 : (step_size[0] > 3 ? 3 : step_size[0]));

@@ -21,6 +21,7 @@ extern "C" const char* snac_last_error(void) { return snac_detail::g_err; }
 static constexpr int LD = 4;                                         // values per row: {steps taken by this env, action, step size, env index}
 static std::atomic<int> g_launch_device{-1}, g_reloads{0}, g_hold_ms{0}, g_step_ms{0}, g_launch_fail{0};
 static std::atomic<long long> g_env_steps[MB_MAX_ENVS];
+static std::atomic<int> g_wave_late_ms[MB_MAX_WAVES];                 // wave w of the NEXT launches starts this late (a launch cut in two)
 
 template <typename T> static T dload(const T* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 template <typename T> static void dstore(T* p, T v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
@@ -30,6 +31,7 @@ static void fake_wave(snac_mailbox* mb, int wv) {
     const int env0 = wv * MB_WAVE_ENVS, nenv = std::min(MB_WAVE_ENVS, mb->num_envs - env0);
     uint32_t seen = dload(&mb->ack_seq[wv]), served = dload(&mb->steps_served[wv]), gen = 0xFFFFFFFFu;
     bool quit = false, wt_pending = false;
+    if (const int late = g_wave_late_ms[wv].load()) std::this_thread::sleep_for(std::chrono::milliseconds(late));
     auto last = clk::now();
     for (;;) {
         const uint64_t cmd = __atomic_load_n(&mb->cmd, __ATOMIC_ACQUIRE);
@@ -157,11 +159,11 @@ static void case_one_env_steps_idles_and_comes_back() {
     const int r0 = g_reloads.load();
     CHECK(snac_mailbox_touch(mb) == SNAC_OK && snac_mailbox_step(mb, &d, &st, 0, 1) == SNAC_OK && g_reloads.load() == r0 + 1);
     CHECK(snac_mailbox_step(mb, &d, &st, 0, 1) == SNAC_OK && g_reloads.load() == r0 + 1);
-    // another batch size than the mailbox's is refused when a wave has to be armed
+    // another batch size than the mailbox's is refused (at once: nothing is posted)
     std::this_thread::sleep_for(std::chrono::milliseconds(30));
     snac_env_desc d2 = desc(2);
     CHECK(snac_mailbox_step(mb, &d2, &st, 0, 1) == SNAC_ERR_ARG);
-    CHECK(g_env_steps[0].load() == 20004);                           // ... and the refused command was withdrawn: nobody steps it later
+    CHECK(g_env_steps[0].load() == 20004);                           // ... and nobody steps it later
     CHECK(snac_mailbox_step(mb, &d, &st, 0, 1) == SNAC_OK && snac_mailbox_row(mb)[0] == 20005.0);
     CHECK(snac_mailbox_quit(mb) == SNAC_OK && snac_mailbox_quit(mb) == SNAC_OK);
     CHECK(snac_mailbox_step(mb, &d, &st, 0, 1) == SNAC_OK && snac_mailbox_row(mb)[0] == 20006.0);   // usable after quit: a new wave
@@ -244,12 +246,34 @@ static void case_the_limit_withdraws_the_command() {
     CHECK(snac_mailbox_step(mb, &d, &st, 2, 1) == SNAC_OK && snac_mailbox_row(mb)[0] == 1.0 && g_env_steps[0].load() == 1);
     g_step_ms = 0;
     CHECK(snac_mailbox_destroy(mb) == SNAC_OK);
+    // a launch cut in two by the limit: wave 0 serves the step, wave 1 starts after the limit -- the error says whose envs stepped
+    reset_counts();
+    setenv("SNAC_MAILBOX_TIMEOUT_S", "0.2", 1);
+    d = desc(100);
+    CHECK(snac_mailbox_create(&d, 300, &mb) == SNAC_OK);
+    {
+        std::vector<int8_t> a2(100, 2), k2(100, 1);
+        g_wave_late_ms[1] = 700;
+        const int rc2 = snac_mailbox_step_n(mb, &d, &st, a2.data(), k2.data());
+        CHECK(rc2 == SNAC_ERR_HIP && std::strstr(snac_last_error(), "mask 0x1") != nullptr);
+        std::this_thread::sleep_for(std::chrono::milliseconds(800));   // wave 1 wakes up, finds the QUIT, steps nothing
+        for (int e = 0; e < 100; ++e) CHECK(g_env_steps[e].load() == (e < 64 ? 1 : 0));
+        g_wave_late_ms[1] = 0;
+        CHECK(snac_mailbox_step_n(mb, &d, &st, a2.data(), k2.data()) == SNAC_OK);
+        for (int e = 0; e < 100; ++e) CHECK(g_env_steps[e].load() == (e < 64 ? 2 : 1));
+        snac_env_desc d3 = desc(99);                                 // another batch size: refused before its arrays are read
+        CHECK(snac_mailbox_step_n(mb, &d3, &st, a2.data(), k2.data()) == SNAC_ERR_ARG);
+        for (int e = 0; e < 100; ++e) CHECK(g_env_steps[e].load() == (e < 64 ? 2 : 1));
+    }
+    CHECK(snac_mailbox_destroy(mb) == SNAC_OK);
+    d = desc(1);
+    reset_counts();
     // a launch that fails: the error comes back, the command is withdrawn, the next step works
     unsetenv("SNAC_MAILBOX_TIMEOUT_S");
     CHECK(snac_mailbox_create(&d, 300, &mb) == SNAC_OK);
     g_launch_fail = 1;
     CHECK(snac_mailbox_step(mb, &d, &st, 2, 1) == SNAC_ERR_HIP && std::strstr(snac_last_error(), "injected") != nullptr);
-    CHECK(snac_mailbox_step(mb, &d, &st, 2, 1) == SNAC_OK && g_env_steps[0].load() == 2);
+    CHECK(snac_mailbox_step(mb, &d, &st, 2, 1) == SNAC_OK && g_env_steps[0].load() == 1);
     CHECK(snac_mailbox_destroy(mb) == SNAC_OK);
 }
 
