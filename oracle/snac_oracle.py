@@ -230,10 +230,13 @@ class OracleBatch:
 
     def set_total_step(self, total_step):
         """The time limit of every env (snac_env_desc.total_step)."""
-        for i in range(self.n):
-            self.b.contents.envs[i].total_step = int(total_step)
+        self._words()[:, _Env.total_step.offset // 4] = int(total_step)
         self.b.contents.total_step = self.total_step = int(total_step)
         return self
+
+    def _words(self):
+        """The env structs as one int32 array [n, words per struct] (every field of orc_env is an int32): a view, not a copy."""
+        return np.ctypeslib.as_array(C.cast(self.b.contents.envs, C.POINTER(C.c_int32)), shape=(self.n, C.sizeof(_Env) // 4))
 
     def __del__(self):
         if getattr(self, "b", None):
@@ -315,16 +318,11 @@ class OracleBatch:
 
     def state(self):
         """-> dict of numpy arrays: grid [n,H*W] int32 (bordered), pos [n,2], cb, cs, tb, plan_idx, episode."""
-        envs = self.b.contents.envs
-        n = self.n
-        cells = envs[0].H * envs[0].W
-        grid = np.zeros((n, cells), np.int32)
-        pos = np.zeros((n, 2), np.int32)
-        cb = np.zeros(n, np.int32); cs = np.zeros(n, np.int32); tb = np.zeros(n, np.int32); pi = np.zeros(n, np.int32)
-        for i in range(n):
-            e = envs[i]
-            grid[i] = e.grid[:cells]
-            pos[i] = (e.pos[0], e.pos[1])
-            cb[i], cs[i], tb[i], pi[i] = e.cb, e.cs, e.tb, e.plan_idx
+        w = self._words()
+        col = lambda f: w[:, getattr(_Env, f).offset // 4].copy()
+        cells = int(w[0, _Env.H.offset // 4]) * int(w[0, _Env.W.offset // 4])
+        g0, p0 = _Env.grid.offset // 4, _Env.pos.offset // 4
+        grid, pos = w[:, g0:g0 + cells].copy(), w[:, p0:p0 + 2].copy()
+        cb, cs, tb, pi = col("cb"), col("cs"), col("tb"), col("plan_idx")
         return dict(grid=grid, pos=pos, cb=cb, cs=cs, tb=tb, plan_idx=pi, episode=self._arr("episode", np.int32),
                     need_reset=self._arr("need_reset", np.uint8), ep_return=self._arr("ep_return", np.int32))

@@ -88,6 +88,15 @@ def oracle():
 _PERF_NOTES = {}
 
 
+def same_bytes(a, b):
+    """a.tobytes() == b.tobytes() without the two copies (the large batches' rows are hundreds of megabytes)."""
+    a, b = np.ascontiguousarray(a).reshape(-1), np.ascontiguousarray(b).reshape(-1)
+    if a.nbytes != b.nbytes:
+        return False
+    word = np.uint64 if a.nbytes % 8 == 0 else np.uint8
+    return bool(np.array_equal(a.view(word), b.view(word)))
+
+
 def perf_note(name, value):
     _PERF_NOTES[name] = value
 

@@ -86,7 +86,7 @@ def test_raw_c_abi_reset_step_rollout_iou():
     assert iou.cpu().numpy().tobytes() == orc.iou().tobytes()
     mem = torch.empty((N, 26, 26), dtype=torch.float64, device=dev)
     assert L.snac_export_grid(C.byref(desc), C.byref(st), vp(mem), stream) == 0
-    assert np.array_equal(mem.cpu().numpy().reshape(N, -1), orc.state()["grid"].astype(np.float64))
+    assert np.array_equal(mem.cpu().numpy().reshape(N, -1), orc.state()["grid"])
     s = orc.stats()
     assert stats.sum(dim=1).tolist() == [int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum())]
     # errors are reported, not raised: obs_mode without a buffer

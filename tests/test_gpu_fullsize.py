@@ -31,7 +31,7 @@ def _compare_chunks(env, orc, T, chunk, memory="malloc"):
     import torch
 
     nt = _threads()
-    assert env.reset().cpu().numpy().tobytes() == orc.reset().tobytes()
+    assert helpers.same_bytes(env.reset().cpu().numpy(), orc.reset())
     if memory == "vmm":                                           # trajectory memory (snac_traj_alloc): chunks of two slices taking turns
         from snac_amd import trajmem
 
@@ -43,14 +43,14 @@ def _compare_chunks(env, orc, T, chunk, memory="malloc"):
         c = min(chunk, T - t)
         og, rg, dg = env.rollout(c, out=buf[:c])
         oc, rc, dc = orc.rollout(c, t0=t, nthreads=nt)
-        assert og.cpu().numpy().tobytes() == oc.tobytes(), ("obs", t)
-        assert rg.cpu().numpy().tobytes() == rc.tobytes(), ("reward", t)
+        assert helpers.same_bytes(og.cpu().numpy(), oc), ("obs", t)
+        assert helpers.same_bytes(rg.cpu().numpy(), rc), ("reward", t)
         assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc), ("done", t)
         t += c
     s = orc.stats()
     e = env.episodic_stats()
     assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
-    assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+    assert helpers.same_bytes(env.iou().cpu().numpy(), orc.iou())
     return e
 
 
@@ -109,12 +109,12 @@ def test_masked_reset_and_explicit_plan_indices():
     pidx = rng.integers(0, 400, size=n).astype(np.int32)
     og = env.reset(torch.from_numpy(mask), torch.from_numpy(pidx))
     oc = orc.reset(mask, pidx)
-    assert og.cpu().numpy().tobytes() == oc.tobytes()             # untouched envs report their current observation
+    assert helpers.same_bytes(og.cpu().numpy(), oc)             # untouched envs report their current observation
     assert np.array_equal(env.plan_idx.cpu().numpy()[mask == 1], pidx[mask == 1])
     assert np.array_equal(env.count_step.cpu().numpy()[mask == 0], np.full(int((mask == 0).sum()), 50))
     og, rg, dg = env.rollout(30, obs="last")
     oc, rc, dc = orc.rollout(30, t0=50, obs="last")
-    assert og.cpu().numpy().tobytes() == oc.tobytes() and rg.cpu().numpy().tobytes() == rc.tobytes()
+    assert helpers.same_bytes(og.cpu().numpy(), oc) and helpers.same_bytes(rg.cpu().numpy(), rc)
     with pytest.raises(ValueError):
         env.reset(plan_idx=np.full(n, 400))
 
@@ -131,7 +131,7 @@ def test_step_without_auto_reset_keeps_mutating_like_the_reference():
     for t in range(70):                                           # total_brick = 60: done at step 60, then keep dropping
         og, rg, dg = env.step(a, k)
         oc, rc, dc = orc.step(t, a.numpy(), k.numpy())
-        assert og.cpu().numpy().tobytes() == oc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+        assert helpers.same_bytes(og.cpu().numpy(), oc) and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
     assert int(env.count_brick[0]) == 70 and bool(env.need_reset[0])
 
 
@@ -191,7 +191,7 @@ def _one_launch(dim, dyn, n, T, slab, tag):
 
     env, orc = _pair(dim, dyn, n, tag)
     nt = _threads()
-    assert env.reset().cpu().numpy().tobytes() == orc.reset().tobytes()
+    assert helpers.same_bytes(env.reset().cpu().numpy(), orc.reset())
     buf = trajmem.traj_empty((T, n, env.obs_dim), torch.float64, env.device)
     og, rg, dg = env.rollout(T, out=buf)                          # the launch bench.py times
     assert og.data_ptr() == buf.data_ptr()
@@ -205,8 +205,8 @@ def _one_launch(dim, dyn, n, T, slab, tag):
         t += c
     s, e = orc.stats(), env.episodic_stats()
     assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
-    assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
-    assert env.observe().cpu().numpy().tobytes() == og[T - 1].cpu().numpy().tobytes()
+    assert helpers.same_bytes(env.iou().cpu().numpy(), orc.iou())
+    assert helpers.same_bytes(env.observe().cpu().numpy(), og[T - 1].cpu().numpy())
 
 
 def test_config3_headline_pass_as_one_launch():

@@ -408,7 +408,7 @@ def test_large_waves_of_2d_edges(dyn, f32):
     cb = env.count_brick.cpu().numpy()
     assert [int(cb[i]) for i in idx] == [int(orc.b.contents.envs[int(i)].cb) for i in idx]
     st = orc.state()
-    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(pool, -1), st["grid"].astype(np.float64))
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(pool, -1), st["grid"])
     # the other kernel on the same edges: m - 2 of them (m % 4 != 0), rows and records compared on the device
     twin = env.fork(torch.arange(pool, device=env.device))
     dst = (pool // 2 + rng.choice(pool // 2, m, replace=False)).astype(np.int32)
@@ -454,7 +454,7 @@ def test_large_waves_of_3d_edges_through_lds(dyn, f32):
         assert r.cpu().numpy().tobytes() == ro.tobytes() and np.array_equal(d.cpu().numpy().astype(np.uint8), do), wave
     assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
     st = orc.state()
-    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(pool, -1), st["grid"].astype(np.float64))
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(pool, -1), st["grid"])
     # the other kernel on the same edges: m - 2 of them (m % 4 != 0), rows compared on the device
     twin = env.fork(torch.arange(pool, device=env.device))
     dst = (pool // 2 + rng.choice(pool // 2, m, replace=False)).astype(np.int32)

@@ -44,7 +44,7 @@ def _check_state(env, orc):
     st = orc.state()
     H, W = (1, 34) if env.kind == 1 else (26, 26)
     mem = env.environment_memory().cpu().numpy()
-    assert np.array_equal(mem.reshape(env.num_envs, -1), st["grid"].astype(np.float64))
+    assert np.array_equal(mem.reshape(env.num_envs, -1), st["grid"])
     pos = env.position.cpu().numpy()
     assert np.array_equal(pos[:, 0], st["pos"][:, 0])
     if env.kind != 1:

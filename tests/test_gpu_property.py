@@ -46,7 +46,7 @@ def test_random_rollouts_match_the_oracle(kind, n, seed, base, cuts, explicit, b
         assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
         t0 += T
     st_ = orc.state()
-    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(n, -1), st_["grid"].astype(np.float64))
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(n, -1), st_["grid"])
     assert np.array_equal(env.count_brick.cpu().numpy(), st_["cb"]) and np.array_equal(env.plan_idx.cpu().numpy(), st_["plan_idx"])
     assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
     s = orc.stats()
@@ -108,6 +108,6 @@ def test_random_tree_edges_match_the_oracle(kind, pool, seed, warm, waves, data)
         assert o.cpu().numpy().tobytes() == oo.tobytes() and r.cpu().numpy().tobytes() == ro.tobytes()
         assert np.array_equal(d.cpu().numpy().astype(np.uint8), do)
     st_o = orc.state()
-    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(pool, -1), st_o["grid"].astype(np.float64))
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(pool, -1), st_o["grid"])
     assert np.array_equal(env.count_step.cpu().numpy(), st_o["cs"]) and np.array_equal(env.count_brick.cpu().numpy(), st_o["cb"])
     assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()

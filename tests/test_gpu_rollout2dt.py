@@ -47,7 +47,7 @@ def _compare(env, orc, T, t0, f32=False, kernel="k_rollout2dt", **kw):
 
 def _end_state(env, orc):
     st = orc.state()
-    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(env.num_envs, -1), st["grid"].astype(np.float64))
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(env.num_envs, -1), st["grid"])
     for name, key in (("count_brick", "cb"), ("count_step", "cs"), ("plan_idx", "plan_idx"), ("episode", "episode"), ("episode_return", "ep_return")):
         assert np.array_equal(getattr(env, name).cpu().numpy(), st[key]), name
     assert np.array_equal(env.need_reset.cpu().numpy().astype(np.uint8), st["need_reset"])

@@ -69,7 +69,7 @@ def _end_state(env, orc):
     assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
     assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
     st = orc.state()
-    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(env.num_envs, -1), st["grid"].astype(np.float64))
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(env.num_envs, -1), st["grid"])
 
 
 SHORT = [dict(obs_tail=("record",)), dict(obs_tail=("position", "record"), obs_scalars="raw"), dict(obs_tail=("position",)), dict(obs_scalars="raw"),

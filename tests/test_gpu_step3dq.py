@@ -21,7 +21,7 @@ def _pair(dyn, n, seed, f32, total_step=40):
     orc = helpers.oracle().OracleBatch(3, dyn, n, table, seed=seed)
     orc.set_total_step(total_step)
     cast = (lambda x: x.astype(np.float32)) if f32 else (lambda x: x)
-    assert env.reset().cpu().numpy().tobytes() == cast(orc.reset()).tobytes()
+    assert helpers.same_bytes(env.reset().cpu().numpy(), cast(orc.reset()))
     return env, orc, cast
 
 
@@ -39,10 +39,10 @@ def _walk(env, orc, cast, ticks, rng, kernel=b"k_step3dq", explicit_from=15, pro
         og, rg, dg = env.step(None if a is None else torch.from_numpy(a).cuda(), None if k is None else torch.from_numpy(k).cuda(), auto_reset=True, out=out)
         assert _lib.lib().snac_last_kernel() == kernel
         oc, rc, dc = orc.step(t, a, k, auto_reset=True, nthreads=16)
-        assert og.cpu().numpy().tobytes() == cast(oc).tobytes(), t
-        assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
+        assert helpers.same_bytes(og.cpu().numpy(), cast(oc)), t
+        assert helpers.same_bytes(rg.cpu().numpy(), rc) and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
     st = orc.state()
-    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(n, -1), st["grid"].astype(np.float64))
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(n, -1), st["grid"])
     assert np.array_equal(env.count_brick.cpu().numpy(), st["cb"]) and np.array_equal(env.episode.cpu().numpy(), st["episode"])
     s, e = orc.stats(), env.episodic_stats()
     assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
@@ -87,10 +87,10 @@ def test_steps_without_observations_and_scalar_inputs():
         else:
             og, rg, dg = env.step(torch.from_numpy(a).cuda(), torch.from_numpy(k).cuda(), auto_reset=True)
             oc, rc, dc = orc.step(t, a, k, auto_reset=True, nthreads=16)
-            assert og.cpu().numpy().tobytes() == oc.tobytes(), t
-        assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
+            assert helpers.same_bytes(og.cpu().numpy(), oc), t
+        assert helpers.same_bytes(rg.cpu().numpy(), rc) and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
     st = orc.state()
-    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(n, -1), st["grid"].astype(np.float64))
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(n, -1), st["grid"])
 
 
 def test_unaligned_rows_and_odd_batches_stay_on_the_other_kernels():

@@ -29,13 +29,13 @@ def _pair(dim, dyn, n, seed, total_step=None, f32=False, base=0):
     if total_step:
         orc.set_total_step(total_step)
     o = orc.reset()
-    assert env.reset().cpu().numpy().tobytes() == (o.astype(np.float32) if f32 else o).tobytes()
+    assert helpers.same_bytes(env.reset().cpu().numpy(), (o.astype(np.float32) if f32 else o))
     return env, orc
 
 
 def _end_state(env, orc):
     st = orc.state()
-    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(env.num_envs, -1), st["grid"].astype(np.float64))
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(env.num_envs, -1), st["grid"])
     for name, key in (("count_brick", "cb"), ("count_step", "cs"), ("plan_idx", "plan_idx"), ("episode", "episode"), ("episode_return", "ep_return"),
                       ("total_brick", "tb")):
         assert np.array_equal(getattr(env, name).cpu().numpy(), st[key]), name
@@ -43,7 +43,7 @@ def _end_state(env, orc):
     assert np.array_equal(env.need_reset.cpu().numpy().astype(np.uint8), st["need_reset"])
     s, e = orc.stats(), env.episodic_stats()
     assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
-    assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+    assert helpers.same_bytes(env.iou().cpu().numpy(), orc.iou())
 
 
 @pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
@@ -55,8 +55,8 @@ def test_counter_rng_steps_with_auto_reset(kind, n, f32):
     for t in range(70):
         og, rg, dg = env.step(auto_reset=True)
         oc, rc, dc = orc.step(t, auto_reset=True, nthreads=8)
-        assert og.cpu().numpy().tobytes() == (oc.astype(np.float32) if f32 else oc).tobytes(), (t, "obs")
-        assert rg.cpu().numpy().tobytes() == rc.tobytes(), (t, "reward")
+        assert helpers.same_bytes(og.cpu().numpy(), (oc.astype(np.float32) if f32 else oc)), (t, "obs")
+        assert helpers.same_bytes(rg.cpu().numpy(), rc), (t, "reward")
         assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc), (t, "done")
     _end_state(env, orc)
     assert env.episodic_stats()["episodes"] >= 2 * n
@@ -80,8 +80,8 @@ def test_explicit_inputs_walk_to_every_edge(kind):
         k = rng.integers(1, 4, size=n).astype(np.int8)
         og, rg, dg = env.step(torch.from_numpy(a), torch.from_numpy(k))
         oc, rc, dc = orc.step(t, a, k)
-        assert og.cpu().numpy().tobytes() == oc.tobytes(), (t, "obs")
-        assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
+        assert helpers.same_bytes(og.cpu().numpy(), oc), (t, "obs")
+        assert helpers.same_bytes(rg.cpu().numpy(), rc) and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
     _end_state(env, orc)
     pos = env.position.cpu().numpy()
     assert pos.min() <= 4 and pos.max() >= 21
@@ -101,8 +101,8 @@ def test_steps_without_observation_and_reused_outputs(kind):
         blind = t % 3 == 1
         og, rg, dg = env.step(auto_reset=True, want_obs=not blind, out=out)
         oc, rc, dc = orc.step(t, auto_reset=True, nthreads=8)
-        assert (og is None) if blind else og.cpu().numpy().tobytes() == oc.tobytes()
-        assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+        assert (og is None) if blind else helpers.same_bytes(og.cpu().numpy(), oc)
+        assert helpers.same_bytes(rg.cpu().numpy(), rc) and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
     _end_state(env, orc)
 
 
@@ -189,7 +189,7 @@ def test_layout_variants_of_large_batches_step_on_the_tile_form(dim, dyn, kw, f3
         orc = helpers.oracle().OracleBatch(dim, dyn, nn, table, seed=3)
         orc.configure(obs_norm={None: dyn, "raw": False, "norm": True}[env.obs_scalars], frame=env.frame_value, tail=env.obs_tail)
         orc.set_total_step(9)
-        assert env.reset().cpu().numpy().tobytes() == cast(orc.reset()).tobytes()
+        assert helpers.same_bytes(env.reset().cpu().numpy(), cast(orc.reset()))
         rng = np.random.default_rng(2)
         for t in range(40 if nn == n else (20 if nn > 20000 else 12)):
             if t % 3 == 2:
@@ -200,11 +200,11 @@ def test_layout_variants_of_large_batches_step_on_the_tile_form(dim, dyn, kw, f3
                 og, rg, dg = env.step(auto_reset=True)
                 oc, rc, dc = orc.step(t, auto_reset=True, nthreads=16)
             assert _lib.lib().snac_last_kernel().decode() == kern
-            assert og.cpu().numpy().tobytes() == cast(oc).tobytes(), (t, "obs")
-            assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
+            assert helpers.same_bytes(og.cpu().numpy(), cast(oc)), (t, "obs")
+            assert helpers.same_bytes(rg.cpu().numpy(), rc) and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
         s, e = orc.stats(), env.episodic_stats()
         assert (e["episodes"], e["return_sum"], e["iou_fx_sum"]) == (int(s["episodes"].sum()), int(s["ret"].sum()), int(s["iou_fx"].sum()))
-        assert env.iou().cpu().numpy().tobytes() == orc.iou().tobytes()
+        assert helpers.same_bytes(env.iou().cpu().numpy(), orc.iou())
 
 
 @pytest.mark.parametrize("n", [20476, 20480, 278528, 278532, 475136, 475140])
@@ -219,6 +219,6 @@ def test_2d_records_by_plain_and_by_non_temporal_loads(n):
         og, rg, dg = env.step(auto_reset=True)
         assert _lib.lib().snac_last_kernel() == b"k_step2d"
         oc, rc, dc = orc.step(t, auto_reset=True, nthreads=16)
-        assert og.cpu().numpy().tobytes() == oc.tobytes(), t
-        assert rg.cpu().numpy().tobytes() == rc.tobytes() and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
+        assert helpers.same_bytes(og.cpu().numpy(), oc), t
+        assert helpers.same_bytes(rg.cpu().numpy(), rc) and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
     _end_state(env, orc)

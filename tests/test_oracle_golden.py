@@ -140,3 +140,28 @@ def test_counter_rng_matches_numpy_statement():
         env = int(rng.integers(0, 2**40))
         t = int(rng.integers(0, 2**32))
         assert L.orc_rng_word(seed, stream, env, t) == int(rng_spec.words(seed, stream, env, t))
+
+
+def test_batch_state_view_equals_the_structs_read_one_by_one():
+    """OracleBatch.state() / set_total_step() go through ONE int32 view of the env structs (the per-env ctypes loops took seconds at the
+    large batches of the GPU suite): the view's columns are the structs' fields."""
+    orc_mod = helpers.oracle()
+    for dim, dyn in ((1, False), (2, True), (3, True)):
+        table = helpers.plan_table(dim, dyn, "dense_train" if dyn else "p1")
+        b = orc_mod.OracleBatch(dim, dyn, 37, table, seed=5)
+        b.set_total_step(23)
+        b.reset()
+        for t in range(40):
+            b.step(t, None, None, auto_reset=True)
+        st = b.state()
+        envs = b.b.contents.envs
+        cells = envs[0].H * envs[0].W
+        for i in range(37):
+            e = envs[i]
+            assert e.total_step == 23
+            assert list(st["grid"][i]) == list(e.grid[:cells]) and tuple(st["pos"][i]) == (e.pos[0], e.pos[1])
+            assert (st["cb"][i], st["cs"][i], st["tb"][i], st["plan_idx"][i]) == (e.cb, e.cs, e.tb, e.plan_idx)
+        cs0, grid0 = st["cs"].copy(), st["grid"].copy()
+        b.step(40, None, None, auto_reset=True)                      # copies, not views: the next step does not change them
+        assert np.array_equal(st["cs"], cs0) and np.array_equal(st["grid"], grid0)
+        assert not np.array_equal(b.state()["cs"], cs0)
