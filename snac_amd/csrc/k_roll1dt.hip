@@ -113,7 +113,7 @@ __global__ __launch_bounds__(EB * 64, VLD ? 1 : 16 / EB) void k_rollout1dt(const
             const int cs = min(cs0 + (lane - first_lane + 1), CNT_MAX);
             const unsigned long long dropm = __ballot(drop);
             const int cb = min(cb0 + (int)__popcll(dropm & le), CNT_MAX);
-            const bool term = drop && cb >= tb + a.brick_gt;         // :107-114, before the time limit
+            const bool term = term_rule(drop, cb, tb, a.brick_gt);   // :107-114, before the time limit (the rules' pieces: snac_dev.h)
             const bool done = seg && (term || cs >= a.ts_done);
             const unsigned long long donem = __ballot(done);
             const int last = donem ? (__ffsll((long long)donem) - 1) : (nl - 1);     // the segment's last lane
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(EB * 64, VLD ? 1 : 16 / EB) void k_rollout1dt(const
             }
             const int hnew = win[2];                                 // a drop does not move: the agent's cell after the brick
             const int pl = P[min(max(posb - 2, 0), 31)];
-            const int reward = (drop && !term) ? (hnew > pl ? -1 : (hnew == pl ? 10 : 1)) : 0;   // :117-123
+            const int reward = reward1d(drop, term, hnew, pl);       // :117-123
             // running return: rewards are -1 / 1 / 10, three ballots
             const unsigned long long inm = __ballot(in);
             const unsigned long long r10 = __ballot(in && reward == 10), r1 = __ballot(in && reward == 1), rm = __ballot(in && reward == -1);

@@ -219,7 +219,7 @@ __global__ __launch_bounds__((EB + WR) * 64) void k_rollout2dt(const KArgs a) {
             const int cs = min(cs0 + (lane - first_lane + 1), CNT_MAX);
             const unsigned long long dropm = __ballot(drop);
             const int cb = min(cb0 + (int)__popcll(dropm & le), CNT_MAX);
-            const bool term = drop && cb >= tb + a.brick_gt;         // :117-126, before the time limit
+            const bool term = term_rule(drop, cb, tb, a.brick_gt);   // :117-126, before the time limit (the rules' pieces: snac_dev.h)
             const bool done = seg && (term || cs >= a.ts_done);
             const unsigned long long donem = __ballot(done);
             const int last = donem ? (__ffsll((long long)donem) - 1) : (nl - 1);     // the segment's last lane
@@ -281,7 +281,7 @@ __global__ __launch_bounds__((EB + WR) * 64) void k_rollout2dt(const KArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < 7; ++i) wr[i] |= spread16((uint32_t)(dmask >> (7 * i)) & 0x7Fu);
-            const int reward = (drop && !term && !was && planned) ? 5 : 0;   // un-clamped cell vs plan (:129-133)
+            const int reward = reward2d(drop, term, was, planned);   // un-clamped cell vs plan (:129-133)
             const unsigned long long r5 = __ballot(in && reward != 0);
             const int ret = clamp16(ret0 + 5 * (int)__popcll(r5 & le));
             // ---- outputs of the segment's lanes: compact rows into the block's staging tile

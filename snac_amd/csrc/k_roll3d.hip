@@ -144,7 +144,7 @@ struct Roll3D {
         for (int u = 0; u < E; ++u) val[u] = is_win ? (double)pv[u] : psv[u];
         // ---- W: the first use of q_pl is the iteration's only vmcnt wait
         const bool le = q_newh <= q_pl;
-        const int rc = q_newh > q_pl ? -1 : (q_newh == q_pl ? 10 : 1);   // reward_check on the built cell
+        const int rc = reward_check3d(q_newh, q_pl);                     // reward_check on the built cell (snac_dev.h)
         const int reward = q_sel ? rc : q_reward;
         const int inc = (q_built && le) ? 1 : 0;                     // min(height, plan) grows by one
         if constexpr (EXPL) {

@@ -197,6 +197,15 @@ struct Lane {
 // `planned`: the plan wants one; what a step does to the counters, the position, the reward and `done` is decided here and nowhere
 // else (round 5 had seven copies).  When `drop` comes back the caller sets the cell's bit (+= 1, then clamped to 1: :115, :134-135).
 // k_rollout2dt is time-parallel (counters by ballots, positions by scans of composed clamps): the same rules in another formulation.
+// The pieces of the rules that the TIME-PARALLEL kernels (k_rollout1dt, k_rollout2dt: a lane per tick, counters by ballots, positions by
+// scans of composed clamps) share with the lane-per-env formulation below: when a drop ends the episode, and what a drop earns.
+__device__ __forceinline__ bool term_rule(bool drop, int cb, int tb, int brick_gt) { return drop && cb >= tb + brick_gt; }   // 1D :107-114, 2D :117-126 (brick_gt: SNAC_RULE_BRICK_GT)
+__device__ __forceinline__ int reward1d(bool drop, bool term, int hnew, int pl) {                                           // DMP_Env_1D_static.py:117-123
+    return (drop && !term) ? (hnew > pl ? -1 : (hnew == pl ? 10 : 1)) : 0;
+}
+__device__ __forceinline__ int reward2d(bool drop, bool term, bool was, bool planned) {   // the un-clamped cell against the plan (:129-133): 5 iff it was empty and is planned
+    return (drop && !term && !was && planned) ? 5 : 0;
+}
 struct Rule2D { bool drop, term, done; int reward; };
 __device__ __forceinline__ Rule2D rules2d(Lane& s, int act, int k, bool was, bool planned, int ts_done, int brick_gt) {
     Rule2D o;
@@ -207,9 +216,9 @@ __device__ __forceinline__ Rule2D rules2d(Lane& s, int act, int k, bool was, boo
     if (act == 1) s.c = min(s.c + k, 22);
     if (act == 2) s.r = min(s.r + k, 22);                            // "up" is row + k (:100-103)
     if (act == 3) s.r = max(s.r - k, 3);
-    o.term = o.drop && s.cb >= s.tb + brick_gt;                      // :117-126, tested before the time limit (brick_gt: SNAC_RULE_BRICK_GT)
+    o.term = term_rule(o.drop, s.cb, s.tb, brick_gt);                // :117-126, tested before the time limit
     o.done = o.term || s.cs >= ts_done;
-    o.reward = (o.drop && !o.term && !was && planned) ? 5 : 0;       // the un-clamped cell against the plan (:129-133): 5 iff it was empty and is planned
+    o.reward = reward2d(o.drop, o.term, was, planned);
     return o;
 }
 
@@ -510,9 +519,9 @@ struct K1D {
         if (drop) { s.cb = min(s.cb + 1, CNT_MAX); *h = (int16_t)hnew; }
         if (act == 0) s.r = max(s.r - k, 2);                         // clip_position :57-64
         if (act == 1) s.r = min(s.r + k, 31);
-        const bool term = drop && s.cb >= s.tb + bg;                 // :107-114, before the time limit
+        const bool term = term_rule(drop, s.cb, s.tb, bg);           // :107-114, before the time limit
         done = term || s.cs >= ts;
-        reward = (drop && !term) ? (hnew > pl ? -1 : (hnew == pl ? 10 : 1)) : 0;   // :117-123
+        reward = reward1d(drop, term, hnew, pl);
     }
     // iou: DMP_Env_1D_static.py:138-151
     __device__ static double iou(uint32_t* lds, const Lane& s, int lane) {
