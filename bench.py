@@ -813,14 +813,19 @@ def main():
             slot = torch.randint(1, cap, (batch,), device=dev)
             ei = torch.randint(0, nn, (batch,), device=dev)
             import ctypes as C
+            import itertools
 
-            slot32, ei32 = slot.to(torch.int32), ei.to(torch.int32)
+            # NEW samples every launch, as a trainer draws them: one repeated set would keep its 70 MB of rows in the 256 MB Infinity Cache
+            # from launch to launch (35 us against 39: tools/gather_probe.py).  32 sets = 2.2 GB of rows between two uses of a set.
+            sets = itertools.cycle([(torch.randint(1, cap, (batch,), device=dev).to(torch.int32), torch.randint(0, nn, (batch,), device=dev).to(torch.int32))
+                                    for _ in range(32)])
             so = torch.empty((batch, e.obs_dim), dtype=torch.float32, device=dev)
             sn = torch.empty_like(so)
             pl = torch.empty((batch, 400), dtype=torch.float32, device=dev)
             vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
             def call():
+                slot32, ei32 = next(sets)
                 _lib.check(e._lib.snac_replay_gather(C.byref(e._desc), C.byref(e._state), cap, vp(ring.obs), vp(ring.first), vp(ring.plan_idx),
                                                      vp(slot32), vp(ei32), batch, vp(so), vp(sn), vp(pl), e._stream()))
 
@@ -831,7 +836,7 @@ def main():
             gbs = algb * batch / (ms * 1e-3) / 1e9
             res[name] = {"kernel": "k_gather", "kernel_ms": ms, "samples_per_s": batch / (ms * 1e-3), "alg_bytes_per_sample": algb, "achieved_GBs": gbs,
                          "frac": gbs / HBM_PEAK_GBS, "launches": GROUPS * reps, "timing": tm, "wrapper_ms": ms_wrapped,
-                         "note": "kernel_ms: snac_replay_gather alone (raw C ABI); wrapper_ms: ReplayRing.gather, which also gathers action / reward / done with torch"}
+                         "note": "kernel_ms: snac_replay_gather alone (raw C ABI), new random samples every launch; wrapper_ms: ReplayRing.gather, which also gathers action / reward / done with torch"}
 
         def facade_cfg(name, steps=3000):
             """The single-env drop-in class as a DQN script drives it (Env/2D/DMP_Env_2D_dynamic_usedata_plan.py: one env.step(action) per
@@ -929,8 +934,11 @@ def main():
 
         default_alloc_cfg("headline_default_alloc", 12)
         rollout_cfg("c2_1d_static_n4096_T750", 1, False, 4096, False, 40,
-                    "time-parallel kernel k_rollout1dt (one wave per env, lane = tick, the rows of 16 envs through an LDS tile as 896-byte runs: "
-                    "0.29 -> 0.05 ms); the pass writes only 187 MB and is bound by instruction issue (7.3 per env-step by the counters), not by the HBM rate")
+                    "time-parallel kernel k_rollout1dt (one wave per env, lane = tick, the rows of 8 envs through an LDS tile as 448-byte runs: "
+                    "0.29 -> 0.045 ms); the pass writes only 187 MB and is bound by its vector instructions (5.4 per env-step by the counters), not by the HBM rate")
+        # the same kind at the headline's batch size: from 45 056 envs there is a 64-env wave for every SIMD and the rollout is lane-per-env
+        # (k_rollout1dl, round 6: 0.72 ms on the time-parallel / tile kernels before)
+        rollout_cfg("rollout_1d_dynamic_n65536_T750", 1, True, 65536, False, 24)
         rollout_cfg("c5_3d_dynamic_n16384_T1000", 3, True, 16384, False, 24)
         rollout_cfg("headline_f32_obs", 2, True, 65536, True, 24)
         # the headline on a table of 2000 GENERATED plans (snac_make_plans: what generate_plans() is for) and in the observation layout

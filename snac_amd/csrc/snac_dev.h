@@ -9,6 +9,7 @@
 //                                 plan rows per wave in LDS, refilled through the scalar cache; no vector load in the loop
 //   k_roll2dt.hip   k_rollout2dt  2D rollouts of small and middle batches, time-parallel: one wave per env, lane = tick
 //   k_roll1dt.hip   k_rollout1dt  the same idea for 1D
+//   k_roll1dl.hip   k_rollout1dl  1D rollouts of large batches: lane = env, the headline kernel's shape
 //   k_roll3db.hip   k_rollout3db  3D rollouts: one stepper wave (lane = env) and eight writer waves per 64 envs, one barrier per tick
 //   k_roll3d.hip    k_rollout3d   3D rollouts of small / odd batches: 8 envs per wave, software-pipelined round the store stream
 //   k_step.hip      k_step2d / 3d snac_step on identity rows: wide loads, rows through emit_tile
@@ -105,6 +106,7 @@ void launch_tile3d(Op op, bool dyn, int E, int obs_dtype, const KArgs& a, hipStr
 void launch_roll2d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                     // k_roll2d.hip
 void launch_roll2dt(const snac_env_desc* d, const KArgs& a, hipStream_t s);                    // k_roll2dt.hip
 void launch_roll1dt(const snac_env_desc* d, const KArgs& a, hipStream_t s);                    // k_roll1dt.hip
+void launch_roll1dl(const snac_env_desc* d, const KArgs& a, hipStream_t s);                    // k_roll1dl.hip
 void launch_roll3d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                     // k_roll3d.hip
 void launch_roll3db(const snac_env_desc* d, const KArgs& a, hipStream_t s);                    // k_roll3db.hip
 void launch_step2d(const snac_env_desc* d, const KArgs& a, bool half, hipStream_t s);          // k_step.hip
@@ -206,6 +208,24 @@ __device__ __forceinline__ int reward1d(bool drop, bool term, int hnew, int pl) 
 __device__ __forceinline__ int reward2d(bool drop, bool term, bool was, bool planned) {   // the un-clamped cell against the plan (:129-133): 5 iff it was empty and is planned
     return (drop && !term && !was && planned) ? 5 : 0;
 }
+// The RULES of the 1D step (Env/1D/DMP_Env_1D_static.py:85-136, dynamic: DMP_Env_1D_dynamic_usedata_plan.py), ONCE, for the lane-per-env
+// kernels (K1D::step of the tile kernels and the mailbox, k_rollout1dl): the caller hands in the height under the agent (`hold`) and the
+// plan's height there (`pl`); when `drop` comes back it stores `hnew` in that cell.  s.cs, s.cb and s.r are updated here.
+struct Rule1D { bool drop, done; int hnew, reward; };
+__device__ __forceinline__ Rule1D rules1d(Lane& s, int act, int k, int hold, int pl, int ts_done, int brick_gt) {
+    Rule1D o;
+    o.hnew = min(hold + 1, CNT_MAX);
+    o.drop = act == 2;
+    s.cs = min(s.cs + 1, CNT_MAX);
+    if (o.drop) s.cb = min(s.cb + 1, CNT_MAX);
+    if (act == 0) s.r = max(s.r - k, 2);                             // clip_position :57-64
+    if (act == 1) s.r = min(s.r + k, 31);
+    const bool term = term_rule(o.drop, s.cb, s.tb, brick_gt);       // :107-114, before the time limit
+    o.done = term || s.cs >= ts_done;
+    o.reward = reward1d(o.drop, term, o.hnew, pl);
+    return o;
+}
+
 struct Rule2D { bool drop, term, done; int reward; };
 __device__ __forceinline__ Rule2D rules2d(Lane& s, int act, int k, bool was, bool planned, int ts_done, int brick_gt) {
     Rule2D o;
@@ -512,16 +532,9 @@ struct K1D {
     // step: DMP_Env_1D_static.py:85-136
     __device__ static void step(uint32_t* lds, const KArgs& a, Lane& s, int act, int k, int ts, int bg, int lane, int& reward, bool& done) {
         int16_t* h = hmap(lds) + lane * ES + s.r;
-        const int hnew = min((int)*h + 1, CNT_MAX);
-        const int pl = plan(lds)[lane * ES + s.r - 2];
-        const bool drop = act == 2;
-        s.cs = min(s.cs + 1, CNT_MAX);
-        if (drop) { s.cb = min(s.cb + 1, CNT_MAX); *h = (int16_t)hnew; }
-        if (act == 0) s.r = max(s.r - k, 2);                         // clip_position :57-64
-        if (act == 1) s.r = min(s.r + k, 31);
-        const bool term = term_rule(drop, s.cb, s.tb, bg);           // :107-114, before the time limit
-        done = term || s.cs >= ts;
-        reward = reward1d(drop, term, hnew, pl);
+        const Rule1D u = rules1d(s, act, k, (int)*h, (int)plan(lds)[lane * ES + s.r - 2], ts, bg);   // the rules: above
+        if (u.drop) *h = (int16_t)u.hnew;
+        reward = u.reward; done = u.done;
     }
     // iou: DMP_Env_1D_static.py:138-151
     __device__ static double iou(uint32_t* lds, const Lane& s, int lane) {

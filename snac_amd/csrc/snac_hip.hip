@@ -148,6 +148,10 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_STEP2D_HUGE_FORM*/ {"SNAC_STEP2D_HUGE_FORM", 2, "bit 0: non-temporal record loads, bit 1: non-temporal row stores (524 288 envs: 46.4 us per tick with 1, 43.5 with 2; 1 048 576: 146 / 82; r06_step_loads.txt)"},
     /* TN_STEP2D_FORM     */ {"SNAC_STEP2D_FORM", -1, "k_step2d, canonical rows: force a form (bits as above) whatever the batch size; -1: by batch size"},
     /* TN_NODES2D_NT      */ {"SNAC_NODES2D_NT", 1, "k_edges2dp (2D edges on node records): 1 = the observation rows leave as NON-TEMPORAL stores -- streamed rows then do not displace the node records in the Infinity Cache (65.1 -> 50.3 us per 524 288 edges of a 2^20-record pool, r06_edges.txt)"},
+    /* TN_1D_LANE         */ {"SNAC_1D_LANE", 1, "1D rollouts of large batches on k_rollout1dl (lane = env; canonical rows, every row written, N % 4 == 0, aligned obs) ..."},
+    /* TN_1D_LANE_MIN_F64 */ {"SNAC_1D_LANE_MIN_F64", 45056, "... float64 rows from this many envs (a wave of 64 envs per SIMD at 65 536: 0.454 ms per 750 ticks = 6.6 TB/s against 0.69-0.73 on the time-parallel kernel; 45 056: 7.5e10 env-steps/s against 6.7e10, 40 960: 6.7 against 6.9; r06_1d_lane.txt) ..."},
+    /* TN_1D_LANE_MIN_F32 */ {"SNAC_1D_LANE_MIN_F32", 40960, "... float32 rows from this many (40 960: 8.3e10 against 7.9e10, 36 864: 7.4 against 8.0)"},
+    /* TN_1D_LANE_NT      */ {"SNAC_1D_LANE_NT", 0, "k_rollout1dl: 1 = its rows leave as non-temporal stores (65 536 envs: 0.468 against 0.454 ms with float64 rows, level with float32: off)"},
 };
 
 int tune(int id) {
@@ -225,6 +229,11 @@ bool roll1dt_ok(const KArgs& a, bool f32) {
     return a.n <= (tune(TN_1D_TP_MAX) ? tune(TN_1D_TP_MAX) : tune(f32 ? TN_1D_TP_MAX_F32 : TN_1D_TP_MAX_F64));
 }
 
+// lane-per-env 1D rollouts (k_rollout1dl): batches with a 64-env wave for (nearly) every SIMD; canonical rows, every row written, 16-byte pieces
+bool roll1dl_ok(const KArgs& a, bool f32) {
+    return tune(TN_1D_LANE) != 0 && !a.variant && every_row(a) && pieces16(a) && !pipeline_off() && a.n >= tune(f32 ? TN_1D_LANE_MIN_F32 : TN_1D_LANE_MIN_F64);
+}
+
 // snac_step on identity rows: k_step2d / k_step3d (wide loads, rows through emit_tile)
 bool step_stage_ok(const KArgs& a) { return tune(TN_STEP_STAGE) != 0 && !a.src_index && !a.dst_index && pieces16(a); }
 // ... with a layout variant: 64 envs per wave are 64 rows of kilobytes per wave -- batches large enough to fill the CUs that way;
@@ -250,6 +259,7 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     switch (d->kind) {
         case SNAC_ENV_1D:
             // rollouts that write every row: the time-parallel kernel while its rate beats the tile kernel's (lane-per-env transition)
+            if (op == OP_ROLLOUT && roll1dl_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout1dl"; launch_roll1dl(d, a, s); break; }
             if (op == OP_ROLLOUT && roll1dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout1dt"; launch_roll1dt(d, a, s); break; }
             launch_tile1d(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D:

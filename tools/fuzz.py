@@ -21,7 +21,7 @@ import helpers  # noqa: E402
 from snac_amd import BatchedDMPEnv, trajmem  # noqa: E402
 
 SIZES = [1, 2, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 255, 300, 1000, 2047, 2048, 2049, 3584, 3585, 4095, 4096, 4100, 8191, 8192, 8193, 8200, 11260, 11264, 11268, 15356, 15360, 15872, 15880, 16380, 16384, 16388, 16390, 17408, 19456, 19460,
-         24576, 30716, 30720, 32764, 32768, 32772, 33000, 38912, 38916, 45056, 45060, 49152, 49153, 65536, 65540, 65600, 66000]
+         24576, 30716, 30720, 32764, 32768, 32772, 33000, 38912, 38916, 40956, 40960, 45052, 45056, 45060, 49152, 49153, 65536, 65540, 65600, 66000]
 
 
 def same(a, b, what, ctx):

@@ -92,6 +92,10 @@ CROSSOVERS = [
      {"SNAC_STEP2D_FORM": "2"}, {"SNAC_STEP2D_FORM": "0"}, "min", [393216, 458752, 475137, 491520, 524288]),
     ("SNAC_1D_TP_EB8_MIN", "k_rollout1dt in blocks of 8 envs | blocks of 4, 1D float64 rows", dict(kind=1, T=0, f32=0, layout=None, mode="rollout"),
      {"SNAC_1D_TP_EB8_MIN": "1", "SNAC_1D_TP_EB16": "100000000"}, {"SNAC_1D_TP_EB8_MIN": "100000000", "SNAC_1D_TP_EB16": "100000000"}, "min", [1024, 2048, 3072, 3584, 4096, 8192]),
+    ("SNAC_1D_LANE_MIN_F64", "k_rollout1dl (lane = env) | k_rollout1dt, 1D float64 rows", dict(kind=1, T=0, f32=0, layout=None, mode="rollout"),
+     {"SNAC_1D_LANE_MIN_F64": "1"}, {"SNAC_1D_LANE": "0"}, "min", [32768, 36864, 40960, 45056, 49152, 57344]),
+    ("SNAC_1D_LANE_MIN_F32", "k_rollout1dl (lane = env) | k_rollout1dt, 1D float32 rows", dict(kind=1, T=0, f32=1, layout=None, mode="rollout"),
+     {"SNAC_1D_LANE_MIN_F32": "1"}, {"SNAC_1D_LANE": "0"}, "min", [28672, 32768, 36864, 40960, 45056, 49152]),
 ]
 
 
