@@ -150,7 +150,7 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_NODES2D_NT      */ {"SNAC_NODES2D_NT", 1, "k_edges2dp (2D edges on node records): 1 = the observation rows leave as NON-TEMPORAL stores -- streamed rows then do not displace the node records in the Infinity Cache (65.1 -> 50.3 us per 524 288 edges of a 2^20-record pool, r06_edges.txt)"},
     /* TN_1D_LANE         */ {"SNAC_1D_LANE", 1, "1D rollouts of large batches on k_rollout1dl (lane = env; canonical rows, every row written, N % 4 == 0, aligned obs) ..."},
     /* TN_1D_LANE_MIN_F64 */ {"SNAC_1D_LANE_MIN_F64", 45056, "... float64 rows from this many envs (a wave of 64 envs per SIMD at 65 536: 0.454 ms per 750 ticks = 6.6 TB/s against 0.69-0.73 on the time-parallel kernel; 45 056: 7.5e10 env-steps/s against 6.7e10, 40 960: 6.7 against 6.9; r06_1d_lane.txt) ..."},
-    /* TN_1D_LANE_MIN_F32 */ {"SNAC_1D_LANE_MIN_F32", 40960, "... float32 rows from this many (40 960: 8.3e10 against 7.9e10, 36 864: 7.4 against 8.0)"},
+    /* TN_1D_LANE_MIN_F32 */ {"SNAC_1D_LANE_MIN_F32", 36864, "... float32 rows from this many (the lane kernel: 0.37 ms per 750 ticks whatever the batch up to 65 536 envs; the time-parallel one by box: 36 864 envs 0.35-0.42 ms, 40 960 0.39-0.49, 32 768 0.31-0.39; r06_1d_lane.txt, r06_retune_1d.txt)"},
     /* TN_1D_LANE_NT      */ {"SNAC_1D_LANE_NT", 0, "k_rollout1dl: 1 = its rows leave as non-temporal stores (65 536 envs: 0.468 against 0.454 ms with float64 rows, level with float32: off)"},
 };
 

@@ -1,6 +1,6 @@
 """GPU: 1D rollouts against the CPU oracle.  Rollouts that write every row run on the time-parallel kernel (k_rollout1dt, round 3:
 one wavefront per env, lane = tick, blocks of 4 (below 3584 envs) or 8 envs (round 5: 16) whose rows leave through an LDS staging tile as whole runs per tick) up
-to 65 536 envs -- canonical rows on aligned outputs with N % 4 = 0 leave it for k_rollout1dl from 45 056 envs (float32: 40 960; tests/test_gpu_rollout1dl.py) --, on the tile kernel beyond: batches on either side of every switch, ragged blocks and blocks
+to 65 536 envs -- canonical rows on aligned outputs with N % 4 = 0 leave it for k_rollout1dl from 45 056 envs (float32: 36 864; tests/test_gpu_rollout1dl.py) --, on the tile kernel beyond: batches on either side of every switch, ragged blocks and blocks
 with idle waves, rows that can and cannot leave as 16-byte pieces (odd N, unaligned outputs), canonical and tile-major layouts,
 odd / tiny tick counts, episodes that end by count_brick and by the time limit (several per chunk of 64 ticks), the `>` rule
 bits, float32 observations, the per-step record outputs and explicit inputs."""

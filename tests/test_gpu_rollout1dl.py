@@ -1,6 +1,6 @@
 """GPU: k_rollout1dl (round 6) -- 1D rollouts of large batches with a lane per env (the headline kernel's shape: K1D::step per lane on the
 wave's LDS image, the wave's rows of a tick as one run of 64 x 56 bytes through a staging tile).  It takes canonical rows, every row
-written, N % 4 == 0 and an aligned output from 45 056 envs on (float32 rows: 40 960; SNAC_1D_LANE_MIN_*); here against the CPU oracle on both sides of the
+written, N % 4 == 0 and an aligned output from 45 056 envs on (float32 rows: 36 864; SNAC_1D_LANE_MIN_*); here against the CPU oracle on both sides of the
 threshold: ragged last tiles, float64 / float32, static / dynamic plans, the `>` rule bits, short episodes (many resets and plan changes per
 launch), launches that continue each other, tile-major outputs, the record outputs and explicit inputs; what it does not take (odd N,
 an unaligned output, layout variants) stays on the kernels behind it with the same rows."""
