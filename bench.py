@@ -959,6 +959,9 @@ def main():
         for kind in (2, 3):
             for nn in (65536, 524288):
                 step_cfg("step_%dd_dynamic_n%d" % (kind, nn), kind, nn, 200)
+        # 1D: k_step1d since the end of round 6 (the tile kernel before: 39 us).  By SURVEY 8d's 88 bytes per env-step; what the tick moves is
+        # 163 -- the record is 64 bytes whatever the step reads of it, the header goes in and out
+        step_cfg("step_1d_dynamic_n524288", 1, 524288, 200)
         step_cfg("step_2d_ppo_layout_n65536", 2, 65536, 100, layout="ppo")   # what a trainer that steps 65 536 envs per tick reads: 451-value rows
         step_cfg("step_3d_ppo_layout_n65536", 3, 65536, 100, layout="ppo")
         for kind in (2, 3):

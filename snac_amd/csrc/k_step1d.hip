@@ -1,0 +1,156 @@
+// k_step1d.hip -- k_step1d: the canonical 1D snac_step on identity rows (round 6)
+#include "snac_dev.h"
+#include "rows1d.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Until the end of round 6 a 1D snac_step ran on the tile kernel k_transition<K1D> at every batch size: 32 envs per wave, two-byte loads
+// of the records, rows an element per lane, two divisions per lane: 39 us per tick at 524 288 envs where the tick's bytes -- a row of 56,
+// reward, done flag, header in and out, the record read, one cell written: 193 per env -- would take 13 at the HBM peak.  This is
+// k_step2d's shape for 1D: a wave takes 64 consecutive envs and every memory instruction is wide --
+//   records   the tile's 64 records (64 x 64 bytes, contiguous) arrive as four 16-byte-per-lane loads and are laid out in LDS as K1D's
+//             bordered rows (34 int16 per env, odd dword stride, the frame stored as -1);
+//   step      lane l steps env l with rules1d() (snac_dev.h) on the cell under its agent; the plan's height there is the one dependent
+//             load (L2);
+//   rows      the 5 cells round the new position and the two scalars leave through Rows1D (rows1d.h): one run of 64 x 56 bytes.
+// Write-back: the header, the ONE changed cell (a reset env: its record and episode counter); episodic sums by no-return atomics.
+// Identity rows (snac_step, snac_step_scalar), the canonical layout, N % 4 == 0 and a 16-byte aligned obs (or none); everything else -- tree
+// edges with gathered rows, the layout variants, odd batches -- stays on k_transition<K1D>.
+// NTL / NTS: the records by non-temporal loads / the rows by non-temporal stores (k_step2d's forms; SNAC_STEP1D_FORM).
+template <bool DYN, typename OT, int WPB, bool NTL, bool NTS>
+__global__ __launch_bounds__(WPB * 64) void k_step1d(const KArgs a) {
+    using K = K1D<DYN, 64>;
+    constexpr int E = 64, GE = K::GE, ES = K::ES, RW = ES / 2;      // 32 cells per record; 34 per bordered row = 17 dwords
+    constexpr int IMG_WORDS = (E * RW + 3) & ~3, STG_WORDS = E * K::D * (int)sizeof(OT) / 4, WAVE_WORDS = IMG_WORDS + STG_WORDS;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * WAVE_WORDS];
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const int env0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * WPB + wv) * E);
+    if (env0 >= a.n) return;
+    const int nenv = min(E, a.n - env0);
+    const bool active = lane < nenv;
+    const int env = env0 + (active ? lane : 0);
+    uint32_t* const img = lds_all + wv * WAVE_WORDS;                 // [64][17] dwords: the bordered rows
+    char* const stg = (char*)(img + IMG_WORDS);
+    // ---- every load that does not depend on another: the tile's records (16 bytes per lane), header, episode counter
+    uint4 rv[4];
+    {
+        const uint4* const g4 = (const uint4*)a.grid + (size_t)env0 * 4;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = i * 64 + lane;
+            rv[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (g < nenv * 4) { const u32x4 t = load_nt_if<NTL>((const u32x4*)(g4 + g)); rv[i] = make_uint4(t.x, t.y, t.z, t.w); }
+        }
+    }
+    Lane s;
+    s.clear();
+    s.r = 2;                                                         // idle lanes keep an in-range position and plan row 0
+    int episode = 0;
+    if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
+    const uint64_t gid = (uint64_t)(a.env_id_base + env);
+    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+    if (a.actions && active) act = (int)a.actions[env];
+    if (a.step_size && active) k = (int)a.step_size[env];
+    k = min(max(k, 1), 3);
+    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+    if (nr) {
+        const int old_pidx = s.pidx, old_tb = s.tb;
+        episode += 1;
+        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    }
+    const int16_t* const prow = (const int16_t*)a.plans + (size_t)s.pidx * GE;
+    const int pl = (int)prow[min(max(s.r - 2, 0), 29)];              // the one dependent load: the plan's height under the agent (L2)
+    // ---- the records into K1D's bordered rows: piece p of env e holds cells 8 p .. 8 p + 7 = bordered 2 + 8 p ..: dwords 1 + 4 p .. of the row;
+    // dword 0 (bordered cells 0, 1) and dword 16 (cells 32, 33: the record's two padding cells) are the frame
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = i * 64 + lane, e = g >> 2, p = g & 3;
+        uint32_t* const d = img + e * RW + 1 + 4 * p;
+        d[0] = rv[i].x; d[1] = rv[i].y; d[2] = rv[i].z;
+        d[3] = p == 3 ? 0xFFFFFFFFu : rv[i].w;
+        if (p == 0) d[-1] = 0xFFFFFFFFu;
+    }
+    int16_t* const mine = (int16_t*)(img + lane * RW);               // bordered cell index = position
+    if (nr) {                                                        // a freshly reset row is empty
+#pragma unroll
+        for (int q = 1; q < 16; ++q) ((uint32_t*)mine)[q] = 0u;
+    }
+    // ---- the 1D step (rules1d, snac_dev.h) on the cell under the agent
+    const int r_old = s.r;
+    const Rule1D u = rules1d(s, act, k, (int)mine[r_old], pl, a.ts_done, a.brick_gt);
+    const bool drop = active && u.drop;
+    if (drop) mine[r_old] = (int16_t)u.hnew;
+    const bool done = active && u.done;
+    const int reward = u.reward;
+    s.ep_ret = clamp16(s.ep_ret + reward);
+    s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    if (active) {
+        if (a.reward) a.reward[env] = (float)reward;
+        if (a.done) a.done[env] = done ? 1 : 0;
+        a.hdr[env] = s.pack();
+        if (nr) {
+            a.episode[env] = episode;
+            uint4* const gw = (uint4*)a.grid + (size_t)env * 4;
+            const uint32_t cell = drop ? ((uint32_t)u.hnew & 0xFFFFu) << (((r_old - 2) & 1) * 16) : 0u;   // empty but for the cell it built
+            const int cw = (r_old - 2) >> 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                gw[q] = make_uint4(cw == 4 * q ? cell : 0u, cw == 4 * q + 1 ? cell : 0u, cw == 4 * q + 2 ? cell : 0u, cw == 4 * q + 3 ? cell : 0u);
+        } else if (drop) {
+            ((int16_t*)a.grid)[(size_t)env * GE + r_old - 2] = (int16_t)u.hnew;
+        }
+    }
+    if (a.stats_on && __builtin_expect(__any(done), 0)) {            // snac_step: episodic sums; iou :138-151 needs row and plan
+        if (done) {
+            int a1 = 0, a2 = 0, kk = 0;
+            for (int i = 0; i < 30; ++i) {
+                const int g = (int)mine[i + 2], p = (int)prow[i];
+                a1 += p; a2 += g; kk += max(g - p, 0);
+            }
+            const int cross = a2 - kk;
+            const double v = (double)cross / (double)(a1 + a2 - cross);
+            stat_add(a.stat_episodes + env, 1);
+            stat_add(a.stat_return + env, s.ep_ret);
+            stat_add(a.stat_iou_fx + env, __double2ll_rn(v * FX40));
+        }
+    }
+    if (!a.obs) return;
+    int win[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) win[i] = (int)mine[s.r - 2 + i];
+    const double c0 = (double)s.cb, c1 = (double)s.cs;
+    const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
+    Rows1D<OT> rows;
+    rows.stage(stg, lane, win, v0, v1);
+    rows.template flush<NTS>((char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv);
+}
+
+template <bool DYN, typename OT>
+void launch_s1(const KArgs& a, hipStream_t s) {
+    const int tiles = (a.n + 63) / 64;
+    const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+    switch (snac_detail::tune(snac_detail::TN_STEP1D_FORM) & 3) {    // bit 0: non-temporal record loads, bit 1: non-temporal row stores
+        case 0: hipLaunchKernelGGL((k_step1d<DYN, OT, 4, false, false>), grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_step1d<DYN, OT, 4, true, false>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_step1d<DYN, OT, 4, false, true>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_step1d<DYN, OT, 4, true, true>), grid, block, 0, s, a); break;
+    }
+}
+
+}  // namespace
+
+namespace snac_detail {
+
+void launch_step1d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
+    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
+    if (dyn) f32 ? launch_s1<true, float>(a, s) : launch_s1<true, double>(a, s);
+    else f32 ? launch_s1<false, float>(a, s) : launch_s1<false, double>(a, s);
+}
+
+}  // namespace snac_detail

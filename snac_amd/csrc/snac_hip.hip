@@ -4,6 +4,7 @@
 
 namespace snac_detail {
 void launch_step3dq(const snac_env_desc* d, const KArgs& a, hipStream_t s);                   // k_step3dq.hip
+void launch_step1d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                    // k_step1d.hip
 void launch_roll2db(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);   // k_roll2db.hip
 void launch_roll2dbv(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);  // k_roll2dbv.hip: the same kernel for the layout variants: k_rollout2db (declared here for the same reason as the next one)
 void launch_roll3dbv(const snac_env_desc* d, const KArgs& a, hipStream_t s);   // k_roll3dbv.hip: k_rollout3db for the layout variants (declared here: snac_dev.h is hashed into profiles/traffic.json)
@@ -152,6 +153,9 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_1D_LANE_MIN_F64 */ {"SNAC_1D_LANE_MIN_F64", 45056, "... float64 rows from this many envs (a wave of 64 envs per SIMD at 65 536: 0.454 ms per 750 ticks = 6.6 TB/s against 0.69-0.73 on the time-parallel kernel; 45 056: 7.5e10 env-steps/s against 6.7e10, 40 960: 6.7 against 6.9; r06_1d_lane.txt) ..."},
     /* TN_1D_LANE_MIN_F32 */ {"SNAC_1D_LANE_MIN_F32", 36864, "... float32 rows from this many (the lane kernel: 0.37 ms per 750 ticks whatever the batch up to 65 536 envs; the time-parallel one by box: 36 864 envs 0.35-0.42 ms, 40 960 0.39-0.49, 32 768 0.31-0.39; r06_1d_lane.txt, r06_retune_1d.txt)"},
     /* TN_1D_LANE_NT      */ {"SNAC_1D_LANE_NT", 0, "k_rollout1dl: 1 = its rows leave as non-temporal stores (65 536 envs: 0.468 against 0.454 ms with float64 rows, level with float32: off)"},
+    /* TN_STEP1D          */ {"SNAC_STEP1D", 1, "the canonical 1D snac_step on identity rows (N % 4 == 0, aligned obs) on k_step1d: 64 envs per wave, wide loads, the rows as one run per wave (0 = the tile kernel k_transition) ..."},
+    /* TN_STEP1D_MIN      */ {"SNAC_STEP1D_MIN", 256, "... from this many envs"},
+    /* TN_STEP1D_FORM     */ {"SNAC_STEP1D_FORM", 2, "k_step1d: bit 0 = its records by non-temporal loads, bit 1 = its rows by non-temporal stores.  Records and rows of every batch size fit the Infinity Cache: the resident form (2) at 524 288 envs 15.5 us per tick, both plain 16.2, non-temporal loads 18.4-18.9 (r06_step1d.txt)"},
 };
 
 int tune(int id) {
@@ -261,6 +265,7 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             // rollouts that write every row: the time-parallel kernel while its rate beats the tile kernel's (lane-per-env transition)
             if (op == OP_ROLLOUT && roll1dl_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout1dl"; launch_roll1dl(d, a, s); break; }
             if (op == OP_ROLLOUT && roll1dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout1dt"; launch_roll1dt(d, a, s); break; }
+            if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && !a.variant && tune(TN_STEP1D) != 0 && a.n >= tune(TN_STEP1D_MIN)) { g_kernel = "k_step1d"; launch_step1d(d, a, s); break; }
             launch_tile1d(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D:
             if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var_ok(a, d->obs_dtype == SNAC_OBS_F32))) { g_kernel = "k_step2d"; launch_step2d(d, a, a.variant && step_var_half(a), s); break; }

@@ -14,7 +14,7 @@ import torch  # noqa: E402
 
 from snac_amd import BatchedDMPEnv  # noqa: E402
 
-STATE = {2: 16 + 4 + 80, 3: 16 + 4 + 800}
+STATE = {1: 16 + 4 + 64, 2: 16 + 4 + 80, 3: 16 + 4 + 800}
 
 
 def main():
@@ -49,7 +49,7 @@ def main():
     run(300)
     t = sorted(run(reps) for _ in range(5))
     esz = 4 if dt == torch.float32 else 8
-    contract = {2: 481, 3: 574}[kind] - (0 if esz == 8 else 204)
+    contract = {1: 88, 2: 481, 3: 574}[kind] - (0 if esz == 8 else (28 if kind == 1 else 204))   # SURVEY 8d's figures (bench.py CONTRACT_BYTES)
     print("%dD step N=%d %s %s%s stage=%s: min %.2f  median %.2f us/tick   %.3e env-steps/s   contract figure %.2f TB/s" % (
         kind, n, "f32" if esz == 4 else "f64", "explicit a,k" if explicit else "counter RNG", " obs in vmm" if vmm else "", os.environ.get("SNAC_STEP_STAGE", "1"),
         t[0] * 1e3, t[2] * 1e3, n / t[2] * 1e3, contract * n / t[2] / 1e9), flush=True)
