@@ -795,7 +795,7 @@ def main():
                                                   vp(rw), vp(dn), e._stream()))
 
             ms = timed(call, reps)
-            rec = {2: 80, 3: 800}[kind] + 20                         # grid record + header + episode counter
+            rec = {1: 64, 2: 80, 3: 800}[kind] + 20                  # grid record + header + episode counter
             algb = 2 * rec + e.obs_dim * 8 + 5 + 8 + 1
             gbs = algb * m / (ms * 1e-3) / 1e9
             res[name] = {"kernel": last_kernel(), "kernel_ms": ms, "edges_per_s": m / (ms * 1e-3), "alg_bytes_per_edge": algb, "achieved_GBs": gbs,
@@ -964,7 +964,7 @@ def main():
         step_cfg("step_1d_dynamic_n524288", 1, 524288, 200)
         step_cfg("step_2d_ppo_layout_n65536", 2, 65536, 100, layout="ppo")   # what a trainer that steps 65 536 envs per tick reads: 451-value rows
         step_cfg("step_3d_ppo_layout_n65536", 3, 65536, 100, layout="ppo")
-        for kind in (2, 3):
+        for kind in (1, 2, 3):                                      # (1D: k_edges1d since the end of round 6; the tile kernel before: 54 us)
             edges_cfg("transition_%dd_524288_edges" % kind, kind, 524288, 20)
         edges_cfg("transition_2d_nodes_524288_edges", 2, 524288, 20, nodes=True)
         gather_cfg("replay_gather_65536", 65536, 64, 65536, 20)

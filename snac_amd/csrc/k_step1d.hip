@@ -1,4 +1,4 @@
-// k_step1d.hip -- k_step1d: the canonical 1D snac_step on identity rows (round 6)
+// k_step1d.hip -- k_step1d: the canonical 1D snac_step on identity rows; k_edges1d: 1D tree edges with gathered rows (round 6)
 #include "snac_dev.h"
 #include "rows1d.h"
 
@@ -131,6 +131,133 @@ __global__ __launch_bounds__(WPB * 64) void k_step1d(const KArgs a) {
     rows.template flush<NTS>((char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv);
 }
 
+// k_edges1d: 1D tree edges with gathered rows (snac_transition with index arrays: Env/1D/DMP_Env_1D_*_MCTS*.py transition(state, action)), the
+// records through LDS like k_edges2d's.  An edge's source record (64 bytes = four 16-byte pieces) is fetched ONCE by four neighbouring lanes
+// (piece g of the wave's 256 belongs to edge g / 4) into K1D's bordered rows, stepped by its lane with rules1d(), and leaves for its
+// destination row the same way (out of place, or in place: every read of the wave comes before its first write); header and episode
+// counter are gathered and scattered per lane.  VEC: rows as one run per wave (m % 4 == 0, an aligned obs); otherwise value by value.
+template <bool DYN, typename OT, int WPB, bool VEC, bool NTS>
+__global__ __launch_bounds__(WPB * 64) void k_edges1d(const KArgs a) {
+    using K = K1D<DYN, 64>;
+    constexpr int E = 64, GE = K::GE, ES = K::ES, RW = ES / 2;
+    constexpr int IMG_WORDS = (E * RW + 3) & ~3, STG_WORDS = E * K::D * (int)sizeof(OT) / 4, WAVE_WORDS = IMG_WORDS + STG_WORDS;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * WAVE_WORDS];
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const int edge0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * WPB + wv) * E);
+    if (edge0 >= a.n) return;
+    const int nedge = min(E, a.n - edge0);
+    const bool active = lane < nedge;
+    const int edge = edge0 + (active ? lane : 0);
+    uint32_t* const img = lds_all + wv * WAVE_WORDS;
+    char* const stg = (char*)(img + IMG_WORDS);
+    const int srow = (int)row_of(a.src_index, a.pool, edge), drow = (int)row_of(a.dst_index, a.pool, edge);
+    // ---- the source records: four 16-byte pieces per edge, fetched by neighbouring lanes (plain loads: children share their parents)
+    uint4 rv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = i * 64 + lane, e = g >> 2, p = g & 3;
+        const int se = __builtin_amdgcn_ds_bpermute(e << 2, srow);
+        rv[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (g < nedge * 4) rv[i] = ((const uint4*)a.grid)[(size_t)se * 4 + p];
+    }
+    Lane s;
+    s.unpack(a.hdr[srow]);
+    int episode = a.episode[srow];
+    const uint64_t gid = (uint64_t)(a.env_id_base + edge);
+    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+    if (a.actions) act = (int)a.actions[edge];
+    if (a.step_size) k = (int)a.step_size[edge];
+    k = min(max(k, 1), 3);
+    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+    if (nr) {
+        const int old_pidx = s.pidx, old_tb = s.tb;
+        episode += 1;
+        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    }
+    const int16_t* const prow = (const int16_t*)a.plans + (size_t)s.pidx * GE;
+    const int r_in = min(max(s.r, 2), 31);                            // (a hand-made header: stay inside the row)
+    const int pl = (int)prow[r_in - 2];                               // the one dependent load: the plan's height under the agent (L2)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                    // into K1D's bordered rows (k_step1d)
+        const int g = i * 64 + lane, e = g >> 2, p = g & 3;
+        uint32_t* const d = img + e * RW + 1 + 4 * p;
+        d[0] = rv[i].x; d[1] = rv[i].y; d[2] = rv[i].z;
+        d[3] = p == 3 ? 0xFFFFFFFFu : rv[i].w;
+        if (p == 0) d[-1] = 0xFFFFFFFFu;
+    }
+    int16_t* const mine = (int16_t*)(img + lane * RW);
+    if (nr) {
+#pragma unroll
+        for (int q = 1; q < 16; ++q) ((uint32_t*)mine)[q] = 0u;
+    }
+    s.r = r_in;
+    const int r_old = s.r;
+    const Rule1D u = rules1d(s, act, k, (int)mine[r_old], pl, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+    const bool drop = active && u.drop;
+    if (drop) mine[r_old] = (int16_t)u.hnew;
+    const bool done = active && u.done;
+    const int reward = u.reward;
+    s.ep_ret = clamp16(s.ep_ret + reward);
+    s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    if (active) {
+        if (a.reward) a.reward[edge] = (float)reward;
+        if (a.done) a.done[edge] = done ? 1 : 0;
+        a.hdr[drow] = s.pack();
+        a.episode[drow] = episode;
+    }
+    if (a.stats_on && __builtin_expect(__any(done), 0)) {            // (snac_step with gathered rows does not exist; kept for completeness)
+        if (done) {
+            int a1 = 0, a2 = 0, kk = 0;
+            for (int i = 0; i < 30; ++i) {
+                const int g = (int)mine[i + 2], p = (int)prow[i];
+                a1 += p; a2 += g; kk += max(g - p, 0);
+            }
+            const int cross = a2 - kk;
+            const double v = (double)cross / (double)(a1 + a2 - cross);
+            stat_add(a.stat_episodes + drow, 1);
+            stat_add(a.stat_return + drow, s.ep_ret);
+            stat_add(a.stat_iou_fx + drow, __double2ll_rn(v * FX40));
+        }
+    }
+    // ---- the (updated) records leave for their destination rows, four neighbouring lanes per record (the two padding cells are zero)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = i * 64 + lane, e = g >> 2, p = g & 3;
+        const int de = __builtin_amdgcn_ds_bpermute(e << 2, drow);
+        const uint32_t* const d = img + e * RW + 1 + 4 * p;
+        if (g < nedge * 4) ((uint4*)a.grid)[(size_t)de * 4 + p] = make_uint4(d[0], d[1], d[2], p == 3 ? 0u : d[3]);
+    }
+    if (!a.obs) return;
+    int win[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) win[i] = (int)mine[s.r - 2 + i];
+    const double c0 = (double)s.cb, c1 = (double)s.cs;
+    const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
+    if constexpr (VEC) {
+        Rows1D<OT> rows;
+        rows.stage(stg, lane, win, v0, v1);
+        rows.template flush<NTS>((char*)a.obs + (size_t)edge0 * K::D * sizeof(OT), lane, nedge);
+    } else if (active) {
+        OT* const o = (OT*)a.obs + (size_t)edge * K::D;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) o[i] = (OT)win[i];
+        o[5] = (OT)v0; o[6] = (OT)v1;
+    }
+}
+
+template <bool DYN, typename OT>
+void launch_e1(const KArgs& a, hipStream_t s) {
+    const int tiles = (a.n + 63) / 64;
+    const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+    const bool vec = !a.obs || ((a.n & 3) == 0 && ((uintptr_t)a.obs & 15) == 0);
+    if (vec) hipLaunchKernelGGL((k_edges1d<DYN, OT, 4, true, ROWS_NT_EDGES>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_edges1d<DYN, OT, 4, false, false>), grid, block, 0, s, a);
+}
+
 template <bool DYN, typename OT>
 void launch_s1(const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + 63) / 64;
@@ -151,6 +278,12 @@ void launch_step1d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
     if (dyn) f32 ? launch_s1<true, float>(a, s) : launch_s1<true, double>(a, s);
     else f32 ? launch_s1<false, float>(a, s) : launch_s1<false, double>(a, s);
+}
+
+void launch_edges1d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
+    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
+    if (dyn) f32 ? launch_e1<true, float>(a, s) : launch_e1<true, double>(a, s);
+    else f32 ? launch_e1<false, float>(a, s) : launch_e1<false, double>(a, s);
 }
 
 }  // namespace snac_detail

@@ -5,6 +5,7 @@
 namespace snac_detail {
 void launch_step3dq(const snac_env_desc* d, const KArgs& a, hipStream_t s);                   // k_step3dq.hip
 void launch_step1d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                    // k_step1d.hip
+void launch_edges1d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                   // k_step1d.hip
 void launch_roll2db(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);   // k_roll2db.hip
 void launch_roll2dbv(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);  // k_roll2dbv.hip: the same kernel for the layout variants: k_rollout2db (declared here for the same reason as the next one)
 void launch_roll3dbv(const snac_env_desc* d, const KArgs& a, hipStream_t s);   // k_roll3dbv.hip: k_rollout3db for the layout variants (declared here: snac_dev.h is hashed into profiles/traffic.json)
@@ -156,6 +157,8 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_STEP1D          */ {"SNAC_STEP1D", 1, "the canonical 1D snac_step on identity rows (N % 4 == 0, aligned obs) on k_step1d: 64 envs per wave, wide loads, the rows as one run per wave (0 = the tile kernel k_transition) ..."},
     /* TN_STEP1D_MIN      */ {"SNAC_STEP1D_MIN", 256, "... from this many envs"},
     /* TN_STEP1D_FORM     */ {"SNAC_STEP1D_FORM", 2, "k_step1d: bit 0 = its records by non-temporal loads, bit 1 = its rows by non-temporal stores.  Records and rows of every batch size fit the Infinity Cache: the resident form (2) at 524 288 envs 15.5 us per tick, both plain 16.2, non-temporal loads 18.4-18.9 (r06_step1d.txt)"},
+    /* TN_EDGES1D         */ {"SNAC_EDGES1D", 1, "1D tree edges with gathered rows (snac_transition with index arrays, canonical layout) on k_edges1d: the records through LDS, four lanes per record (0 = the tile kernel k_transition) ..."},
+    /* TN_EDGES1D_MIN     */ {"SNAC_EDGES1D_MIN", 64, "... from this many edges per call"},
 };
 
 int tune(int id) {
@@ -265,6 +268,7 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             // rollouts that write every row: the time-parallel kernel while its rate beats the tile kernel's (lane-per-env transition)
             if (op == OP_ROLLOUT && roll1dl_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout1dl"; launch_roll1dl(d, a, s); break; }
             if (op == OP_ROLLOUT && roll1dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout1dt"; launch_roll1dt(d, a, s); break; }
+            if (op == OP_TRANSITION && !pipeline_off() && (a.src_index || a.dst_index) && !a.variant && tune(TN_EDGES1D) != 0 && a.n >= tune(TN_EDGES1D_MIN)) { g_kernel = "k_edges1d"; launch_edges1d(d, a, s); break; }
             if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && !a.variant && tune(TN_STEP1D) != 0 && a.n >= tune(TN_STEP1D_MIN)) { g_kernel = "k_step1d"; launch_step1d(d, a, s); break; }
             launch_tile1d(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D:

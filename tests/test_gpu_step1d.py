@@ -2,7 +2,7 @@
 rows in LDS, rules1d() per lane, the rows of a wave as one run of 64 x 56 bytes (rows1d.h).  It takes N % 4 == 0 and an aligned (or no)
 observation output from 256 envs on; against the CPU oracle: ragged last waves, float64 / float32, static / dynamic plans, counter RNG and
 explicit inputs biased to moves and to drops, scalar inputs, steps without observations, auto-reset with plan changes (short episodes), the
-`>` rule bits, manual reset(mask) between steps; what it does not take (odd N, an unaligned output) stays on the tile kernel, same rows."""
+`>` rule bits, manual reset(mask) between steps; what it does not take (odd N, an unaligned output) stays on the tile kernel, same rows.  Also k_edges1d, the same shape for 1D tree edges with gathered rows."""
 import numpy as np
 import pytest
 
@@ -143,3 +143,56 @@ def test_what_the_kernel_does_not_take_steps_the_same_on_the_tile_kernel():
         assert helpers.same_bytes(og.cpu().numpy(), oc) and helpers.same_bytes(rg.cpu().numpy(), rc), t
         assert np.array_equal(dg.cpu().numpy().view(np.uint8), dc), t
     _end(twin[0], twin[1])
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn", [False, True], ids=["sta", "dyn"])
+def test_large_waves_of_1d_tree_edges(dyn, f32):
+    """k_edges1d: a wave of 65 536 + 36 edges on a pool of 2^18 rows -- every source record fetched once by four neighbouring lanes, through
+    K1D's bordered rows in LDS, out to its destination row the same way, rows as one run per wave.  Shared random parents from the lower
+    half, distinct children in the upper half, some edges in place; against the oracle, and a second wave on the children; m % 4 != 0 takes
+    the same kernel's value-by-value rows; 40 edges (below SNAC_EDGES1D_MIN) the tile kernel: the same rows for the same edges."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    pool, m = 1 << 18, 65536 + 36
+    table = helpers.plan_table(1, dyn, "sin_train" if dyn else "p1")
+    env = BatchedDMPEnv(1, dyn, pool, plans=table.reshape(len(table), 30), seed=21, obs_dtype=torch.float32 if f32 else torch.float64)
+    orc = helpers.oracle().OracleBatch(1, dyn, pool, table, seed=21)
+    env.reset(); orc.reset()
+    env.rollout(25, obs=None); orc.rollout(25, obs=None, nthreads=16)
+    rng = np.random.default_rng(5)
+    for wave in range(2):
+        dst = (pool // 2 + rng.choice(pool // 2, m, replace=False)).astype(np.int32)
+        src = rng.integers(0, pool // 2, m).astype(np.int32)
+        inplace = rng.random(m) < 0.1
+        src = np.where(inplace, dst, src).astype(np.int32)
+        acts = rng.integers(0, 3, m).astype(np.int8)
+        ks = rng.integers(1, 4, m).astype(np.int8) if wave == 0 else None
+        o, r, d = env.transition(acts, ks, src, dst, t=wave)
+        assert _kernel() == "k_edges1d"
+        oo, ro, do = orc.transition(acts, ks, src, dst, t=wave)
+        assert helpers.same_bytes(o.cpu().numpy(), oo.astype(np.float32) if f32 else oo), wave
+        assert helpers.same_bytes(r.cpu().numpy(), ro) and np.array_equal(d.cpu().numpy().astype(np.uint8), do), wave
+    assert helpers.same_bytes(env.iou().cpu().numpy(), orc.iou())
+    st = orc.state()
+    assert np.array_equal(env.environment_memory().cpu().numpy().reshape(pool, -1), st["grid"])
+    for name, key in (("count_brick", "cb"), ("count_step", "cs"), ("plan_idx", "plan_idx")):
+        assert np.array_equal(getattr(env, name).cpu().numpy(), st[key]), name
+    # m % 4 != 0 (rows value by value) and a small wave (the tile kernel): the same rows and records for the same edges, compared on the device
+    twin = env.fork(torch.arange(pool, device=env.device))
+    third = env.fork(torch.arange(pool, device=env.device))
+    dst = (pool // 2 + rng.choice(pool // 2, m, replace=False)).astype(np.int32)
+    src = rng.integers(0, pool // 2, m).astype(np.int32)
+    acts = rng.integers(0, 3, m).astype(np.int8)
+    o1, r1, d1 = env.transition(acts, None, src, dst, t=7)
+    o2, r2, d2 = twin.transition(acts[: m - 2], None, src[: m - 2], dst[: m - 2], t=7)
+    assert _kernel() == "k_edges1d"
+    assert torch.equal(o1[: m - 2], o2) and torch.equal(r1[: m - 2], r2) and torch.equal(d1[: m - 2], d2)
+    keep = torch.from_numpy(dst[: m - 2].astype(np.int64)).to(env.device)
+    assert torch.equal(env._grid[keep], twin._grid[keep]) and torch.equal(env._hdr[keep], twin._hdr[keep]) and torch.equal(env._episode[keep], twin._episode[keep])
+    o3, r3, d3 = third.transition(acts[:40], None, src[:40], dst[:40], t=7)
+    assert _kernel() == "k_transition"
+    assert torch.equal(o1[:40], o3) and torch.equal(r1[:40], r3) and torch.equal(d1[:40], d3)
+    k40 = torch.from_numpy(dst[:40].astype(np.int64)).to(env.device)
+    assert torch.equal(env._grid[k40], third._grid[k40]) and torch.equal(env._hdr[k40], third._hdr[k40])
