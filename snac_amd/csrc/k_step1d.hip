@@ -15,15 +15,20 @@ namespace {
 //             load (L2);
 //   rows      the 5 cells round the new position and the two scalars leave through Rows1D (rows1d.h): one run of 64 x 56 bytes.
 // Write-back: the header, the ONE changed cell (a reset env: its record and episode counter); episodic sums by no-return atomics.
-// Identity rows (snac_step, snac_step_scalar), the canonical layout, N % 4 == 0 and a 16-byte aligned obs (or none); everything else -- tree
-// edges with gathered rows, the layout variants, odd batches -- stays on k_transition<K1D>.
+// Identity rows (snac_step, snac_step_scalar), N % 4 == 0 and a 16-byte aligned obs (or none), the canonical layout and (VAR) its variants;
+// odd batches and unaligned outputs stay on k_transition<K1D>; tree edges with gathered rows: k_edges1d below.
 // NTL / NTS: the records by non-temporal loads / the rows by non-temporal stores (k_step2d's forms; SNAC_STEP1D_FORM).
-template <bool DYN, typename OT, int WPB, bool NTL, bool NTS>
+// VAR: the layout variants of snac_env_desc (rows1d.h: rows of a.ld <= 46 values); the staging tiles are dynamic LDS sized for the rows' length
+// (8-value rows: 8.4 KB per wave, 16 waves per CU; 46-value rows: 28 KB, two waves per block).
+template <bool DYN, typename OT, int WPB, bool NTL, bool NTS, bool VAR = false>
 __global__ __launch_bounds__(WPB * 64) void k_step1d(const KArgs a) {
     using K = K1D<DYN, 64>;
     constexpr int E = 64, GE = K::GE, ES = K::ES, RW = ES / 2;      // 32 cells per record; 34 per bordered row = 17 dwords
-    constexpr int IMG_WORDS = (E * RW + 3) & ~3, STG_WORDS = E * K::D * (int)sizeof(OT) / 4, WAVE_WORDS = IMG_WORDS + STG_WORDS;
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * WAVE_WORDS];
+    constexpr int IMG_WORDS = (E * RW + 3) & ~3, STG_WORDS = E * K::D * (int)sizeof(OT) / 4;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_fix[VAR ? 4 : WPB * (IMG_WORDS + STG_WORDS)];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];   // VAR: the launch sizes the staging tiles for the rows' length (step1d_wave_words)
+    uint32_t* const lds_all = VAR ? lds_dyn : lds_fix;
+    const int WAVE_WORDS = VAR ? IMG_WORDS + ((E * a.ld * (int)sizeof(OT) / 4 + 3) & ~3) : IMG_WORDS + STG_WORDS;
     const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
     const int env0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * WPB + wv) * E);
     if (env0 >= a.n) return;
@@ -125,10 +130,17 @@ __global__ __launch_bounds__(WPB * 64) void k_step1d(const KArgs a) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) win[i] = (int)mine[s.r - 2 + i];
     const double c0 = (double)s.cb, c1 = (double)s.cs;
-    const double v0 = DYN ? c0 / (double)s.tb : c0, v1 = DYN ? c1 / (double)a.total_step : c1;
-    Rows1D<OT> rows;
-    rows.stage(stg, lane, win, v0, v1);
-    rows.template flush<NTS>((char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv);
+    const bool norm = VAR ? (a.sc_norm != 0) : DYN;
+    const double v0 = norm ? c0 / (double)s.tb : c0, v1 = norm ? c1 / (double)a.total_step : c1;
+    if constexpr (VAR) {
+        const int recv[8] = {reward, done ? 1 : 0, s.r, 0, s.cb, s.cs, s.tb, s.pidx};   // SNAC_TAIL_RECORD's values (record_value)
+        fill_row1d_var<OT>((OT*)stg + (size_t)lane * a.ld, a.tail, a.frame_val, win, v0, v1, s.r, prow, recv);
+        flush_rows1d_var<OT, NTS>(stg, (char*)a.obs + (size_t)env0 * (size_t)a.ld * sizeof(OT), lane, nenv, a.ld);
+    } else {
+        Rows1D<OT> rows;
+        rows.stage(stg, lane, win, v0, v1);
+        rows.template flush<NTS>((char*)a.obs + (size_t)env0 * K::D * sizeof(OT), lane, nenv);
+    }
 }
 
 // k_edges1d: 1D tree edges with gathered rows (snac_transition with index arrays: Env/1D/DMP_Env_1D_*_MCTS*.py transition(state, action)), the
@@ -261,6 +273,12 @@ void launch_e1(const KArgs& a, hipStream_t s) {
 template <bool DYN, typename OT>
 void launch_s1(const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + 63) / 64;
+    if (a.variant) {                                                 // the layout variants: plain loads and rows; four waves per block while their tiles fit 64 KB
+        const size_t wave_bytes = (size_t)(((64 * 17 + 3) & ~3) + ((64 * a.ld * (int)sizeof(OT) / 4 + 3) & ~3)) * 4;
+        if (wave_bytes * 4 <= 65536) hipLaunchKernelGGL((k_step1d<DYN, OT, 4, false, false, true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), wave_bytes * 4, s, a);
+        else hipLaunchKernelGGL((k_step1d<DYN, OT, 2, false, false, true>), dim3((unsigned)((tiles + 1) / 2)), dim3(128), wave_bytes * 2, s, a);
+        return;
+    }
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
     switch (snac_detail::tune(snac_detail::TN_STEP1D_FORM) & 3) {    // bit 0: non-temporal record loads, bit 1: non-temporal row stores
         case 0: hipLaunchKernelGGL((k_step1d<DYN, OT, 4, false, false>), grid, block, 0, s, a); break;

@@ -159,6 +159,7 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_STEP1D_FORM     */ {"SNAC_STEP1D_FORM", 2, "k_step1d: bit 0 = its records by non-temporal loads, bit 1 = its rows by non-temporal stores.  Records and rows of every batch size fit the Infinity Cache: the resident form (2) at 524 288 envs 15.5 us per tick, both plain 16.2, non-temporal loads 18.4-18.9 (r06_step1d.txt)"},
     /* TN_EDGES1D         */ {"SNAC_EDGES1D", 1, "1D tree edges with gathered rows (snac_transition with index arrays, canonical layout) on k_edges1d: the records through LDS, four lanes per record (0 = the tile kernel k_transition) ..."},
     /* TN_EDGES1D_MIN     */ {"SNAC_EDGES1D_MIN", 64, "... from this many edges per call"},
+    /* TN_STEP1D_VAR_MIN  */ {"SNAC_STEP1D_VAR_MIN", 256, "k_step1d takes the 1D layout variants (rows of 8 .. 46 values) from this many envs (1024 envs with the 37-value PPO rows: 5.4 against 6.5 us per tick on the tile kernel, 65 536: 6.9 / 23.0, 524 288 with 8-value L-Net rows: 18.3 / 44.1; r06_step1d.txt)"},
 };
 
 int tune(int id) {
@@ -269,7 +270,7 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
             if (op == OP_ROLLOUT && roll1dl_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout1dl"; launch_roll1dl(d, a, s); break; }
             if (op == OP_ROLLOUT && roll1dt_ok(a, d->obs_dtype == SNAC_OBS_F32)) { g_kernel = "k_rollout1dt"; launch_roll1dt(d, a, s); break; }
             if (op == OP_TRANSITION && !pipeline_off() && (a.src_index || a.dst_index) && !a.variant && tune(TN_EDGES1D) != 0 && a.n >= tune(TN_EDGES1D_MIN)) { g_kernel = "k_edges1d"; launch_edges1d(d, a, s); break; }
-            if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && !a.variant && tune(TN_STEP1D) != 0 && a.n >= tune(TN_STEP1D_MIN)) { g_kernel = "k_step1d"; launch_step1d(d, a, s); break; }
+            if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && tune(TN_STEP1D) != 0 && a.n >= tune(a.variant ? TN_STEP1D_VAR_MIN : TN_STEP1D_MIN) && a.ld <= 46) { g_kernel = "k_step1d"; launch_step1d(d, a, s); break; }
             launch_tile1d(op, dyn, E, d->obs_dtype, a, s); break;
         case SNAC_ENV_2D:
             if (op == OP_TRANSITION && !pipeline_off() && step_stage_ok(a) && (!a.variant || step_var_ok(a, d->obs_dtype == SNAC_OBS_F32))) { g_kernel = "k_step2d"; launch_step2d(d, a, a.variant && step_var_half(a), s); break; }

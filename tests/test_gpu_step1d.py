@@ -196,3 +196,45 @@ def test_large_waves_of_1d_tree_edges(dyn, f32):
     assert torch.equal(o1[:40], o3) and torch.equal(r1[:40], r3) and torch.equal(d1[:40], d3)
     k40 = torch.from_numpy(dst[:40].astype(np.int64)).to(env.device)
     assert torch.equal(env._grid[k40], third._grid[k40]) and torch.equal(env._hdr[k40], third._hdr[k40])
+
+
+VARIANTS_1D = [
+    (False, dict(layout="lnet1d")),                                                     # 8 values: the position appended
+    (True, dict(layout="ppo")),                                                         # 37: window, counters, the 30 plan heights
+    (True, dict(obs_tail=("record",), obs_scalars="raw")),                              # 15
+    (False, dict(obs_tail=("position", "plan", "record"), frame_value=2, obs_scalars="norm")),   # 46
+]
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn,kw", VARIANTS_1D, ids=["lnet1d", "ppo", "record", "all"])
+def test_layout_variants_step_on_the_same_kernel(dyn, kw, f32):
+    """The observation layouts of the reference's 1D env copies (frame value, raw / normalised counters, the position, the plan's heights and
+    the record appended) through k_step1d's VAR form (from 256 envs, N % 4 == 0): ragged last waves, short episodes (time limit 9: plan changes every few
+    steps), counter RNG and explicit inputs, against the oracle configured the same way; N % 4 != 0 stays on the tile kernel, same rows."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    table = helpers.plan_table(1, dyn, "sin_train" if dyn else "p1")
+    dt = torch.float32 if f32 else torch.float64
+    cast = (lambda x: x.astype(np.float32)) if f32 else (lambda x: x)
+    for n, kernel in ((4096 + 36, "k_step1d"), (260, "k_step1d"), (1002, "k_transition")):
+        env = BatchedDMPEnv(1, dyn, n, plans=table.reshape(len(table), 30), seed=4, total_step=9, obs_dtype=dt, **kw)
+        orc = helpers.oracle().OracleBatch(1, dyn, n, table, seed=4)
+        norm = {None: dyn, "raw": False, "norm": True}[env.obs_scalars]
+        orc.configure(obs_norm=norm, frame=env.frame_value, tail=env.obs_tail)
+        orc.set_total_step(9)
+        assert helpers.same_bytes(env.reset().cpu().numpy(), cast(orc.reset()))
+        rng = np.random.default_rng(n)
+        out = (torch.empty((n, env.obs_dim), dtype=dt, device="cuda"), torch.empty(n, dtype=torch.float32, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda"))
+        for t in range(30):
+            a = k = None
+            if t >= 12:
+                a = rng.choice(3, size=n, p=[0.25, 0.25, 0.5]).astype(np.int8)
+                k = rng.integers(1, 4, size=n).astype(np.int8)
+            og, rg, dg = env.step(None if a is None else torch.from_numpy(a).cuda(), None if k is None else torch.from_numpy(k).cuda(), auto_reset=True, out=out)
+            assert _kernel() == kernel
+            oc, rc, dc = orc.step(t, a, k, auto_reset=True, nthreads=8)
+            assert helpers.same_bytes(og.cpu().numpy(), cast(oc)), (n, t)
+            assert helpers.same_bytes(rg.cpu().numpy(), rc) and np.array_equal(dg.cpu().numpy().view(np.uint8), dc), (n, t)
+        _end(env, orc)
