@@ -19,12 +19,14 @@ namespace {
 //             and the run leaves 16 bytes per lane, 3.5 (1.75) store instructions per wave-tick.
 // Semantics are K1D's as in the tile kernel (reset, plan pick, iou, episodic sums: the same calls).  Canonical layout, every row written
 // (SNAC_OBS_ALL / SNAC_OBS_TILED), N % 4 == 0 and a 16-byte aligned obs; the dispatch table's SNAC_1D_LANE* entries say from which N.
-template <bool DYN, typename OT, int WPB, bool EXPL, bool NT, bool REC>
+// VARLD > 0: the layout variants of snac_env_desc (rows of a.ld <= VARLD values: rows1d.h's fill / flush), the staging tile sized for VARLD.
+template <bool DYN, typename OT, int WPB, bool EXPL, bool NT, bool REC, int VARLD = 0>
 __global__ __launch_bounds__(WPB * 64) void k_rollout1dl(const KArgs a) {
     using K = K1D<DYN, 64>;
-    constexpr int E = 64, D = K::D, ROWB = D * (int)sizeof(OT);
+    constexpr bool VAR = VARLD > 0;
+    constexpr int E = 64, D = K::D;
     constexpr int IMG_WORDS = (K::LDS_WORDS + 3) & ~3;               // heights and plans of the wave's 64 envs (K1D's image)
-    constexpr int STG_WORDS = E * ROWB / 4;
+    constexpr int STG_WORDS = E * (VAR ? VARLD : D) * (int)sizeof(OT) / 4;
     constexpr int WAVE_WORDS = IMG_WORDS + STG_WORDS;
     static_assert(WAVE_WORDS % 4 == 0, "16-byte aligned staging tiles");
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB * WAVE_WORDS];
@@ -61,8 +63,9 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1dl(const KArgs a) {
     long long d_iou = 0;
     // this tile's first byte of step 0, and the distance to the same place one step later: [T][N][D], or tile-major
     const bool tl = a.obs_mode == SNAC_OBS_TILED;
-    char* const obs0 = (char*)a.obs + (tl ? (((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)a.tiled_t0) * 64 + (size_t)(env0 & 63)) * D : (size_t)env0 * D) * sizeof(OT);
-    const size_t tstride = (tl ? (size_t)64 * D : (size_t)a.n * D) * sizeof(OT);
+    const int LD = VAR ? a.ld : D;                                   // values per row: the layout variants append a tail
+    char* const obs0 = (char*)a.obs + (tl ? (((size_t)(env0 >> 6) * (size_t)a.tiled_T + (size_t)a.tiled_t0) * 64 + (size_t)(env0 & 63)) * LD : (size_t)env0 * LD) * sizeof(OT);
+    const size_t tstride = (tl ? (size_t)64 * LD : (size_t)a.n * LD) * sizeof(OT);
     int na = 0, nk = 1;                                              // EXPL: the bytes of the coming tick
     if constexpr (EXPL) {
         if (active && a.actions) na = (int)a.actions[(size_t)env0 + lane];
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1dl(const KArgs a) {
             if (done) { d_eps += 1; d_ret += s.ep_ret; d_iou += __double2ll_rn(v * FX40); }
         }
         double v0 = (double)s.cb, v1 = (double)s.cs;
-        if (DYN) {                                                   // cb / tb, cs / T: correctly rounded (Roll3D, tests/native/recip_check.c)
+        if (VAR ? (a.sc_norm != 0) : DYN) {                          // cb / tb, cs / T: correctly rounded (Roll3D, tests/native/recip_check.c)
             const double c0 = v0, c1 = v1, q0 = c0 * rtb, q1 = c1 * rT;
             v0 = __builtin_fma(__builtin_fma(-q0, dtb, c0), rtb, q0);
             v1 = __builtin_fma(__builtin_fma(-q1, dT, c1), rT, q1);
@@ -142,9 +145,16 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1dl(const KArgs a) {
                 v0 = c0 / dtb;
             }
         }
-        rows.stage(stg, lane, win, v0, v1);
-        w32 = rng_word(sk, a.t0 + (uint32_t)t + 1u);                 // (behind the staging tile's reads, in front of the stores that wait for them)
-        rows.template flush<NT>(obs0 + (size_t)t * tstride, lane, nenv);
+        if constexpr (VAR) {
+            const int recv[8] = {reward, done ? 1 : 0, s.r, 0, s.cb, s.cs, s.tb, s.pidx};   // SNAC_TAIL_RECORD's values (record_value)
+            fill_row1d_var<OT>((OT*)stg + (size_t)lane * LD, a.tail, a.frame_val, win, v0, v1, s.r, prow, recv);
+            w32 = rng_word(sk, a.t0 + (uint32_t)t + 1u);
+            flush_rows1d_var<OT, NT>(stg, obs0 + (size_t)t * tstride, lane, nenv, LD);
+        } else {
+            rows.stage(stg, lane, win, v0, v1);
+            w32 = rng_word(sk, a.t0 + (uint32_t)t + 1u);             // (behind the staging tile's reads, in front of the stores that wait for them)
+            rows.template flush<NT>(obs0 + (size_t)t * tstride, lane, nenv);
+        }
     }
     K::store_grid(lds, a, env0, nenv, lane);
     if (active) {
@@ -161,6 +171,13 @@ __global__ __launch_bounds__(WPB * 64) void k_rollout1dl(const KArgs a) {
 template <bool DYN, typename OT, bool EXPL, bool REC>
 void launch_roll1dl_x(const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + 63) / 64;
+    if (a.variant) {                                                 // the staging tile sized for rows of 16 / 38 / 46 values (k_rollout1dt's classes)
+        const dim3 g4((unsigned)((tiles + 3) / 4)), b4(256), g2((unsigned)((tiles + 1) / 2)), b2(128);
+        if (a.ld <= 16) hipLaunchKernelGGL((k_rollout1dl<DYN, OT, 4, EXPL, false, REC, 16>), g4, b4, 0, s, a);
+        else if (a.ld <= 38) hipLaunchKernelGGL((k_rollout1dl<DYN, OT, 2, EXPL, false, REC, 38>), g2, b2, 0, s, a);
+        else hipLaunchKernelGGL((k_rollout1dl<DYN, OT, 2, EXPL, false, REC, 46>), g2, b2, 0, s, a);
+        return;
+    }
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
     if (snac_detail::tune(snac_detail::TN_1D_LANE_NT) != 0) hipLaunchKernelGGL((k_rollout1dl<DYN, OT, 4, EXPL, true, REC>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_rollout1dl<DYN, OT, 4, EXPL, false, REC>), grid, block, 0, s, a);

@@ -160,6 +160,8 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_EDGES1D         */ {"SNAC_EDGES1D", 1, "1D tree edges with gathered rows (snac_transition with index arrays, canonical layout) on k_edges1d: the records through LDS, four lanes per record (0 = the tile kernel k_transition) ..."},
     /* TN_EDGES1D_MIN     */ {"SNAC_EDGES1D_MIN", 64, "... from this many edges per call"},
     /* TN_STEP1D_VAR_MIN  */ {"SNAC_STEP1D_VAR_MIN", 256, "k_step1d takes the 1D layout variants (rows of 8 .. 46 values) from this many envs (1024 envs with the 37-value PPO rows: 5.4 against 6.5 us per tick on the tile kernel, 65 536: 6.9 / 23.0, 524 288 with 8-value L-Net rows: 18.3 / 44.1; r06_step1d.txt)"},
+    /* TN_1D_LANE_VAR_MIN */ {"SNAC_1D_LANE_VAR_MIN", 28672, "k_rollout1dl takes the 1D layout variants with rows of more than 16 values from this many envs (37-value PPO rows: 1.75 ms per 750 ticks up to 32 768 envs, 2.19 at 65 536 = 6.8 TB/s; k_rollout1dt's VAR form 1.01 / 2.07 / 4.21 ms at 16 384 / 32 768 / 65 536; r06_1d_lane.txt) ..."},
+    /* TN_1D_LANE_VAR_SHORT_MIN */ {"SNAC_1D_LANE_VAR_SHORT_MIN", 49152, "... and those with rows of at most 16 values from this many (8-value L-Net rows: 0.78 ms flat; k_rollout1dt 0.76 at 45 056, 1.05 at 65 536)"},
 };
 
 int tune(int id) {
@@ -237,9 +239,11 @@ bool roll1dt_ok(const KArgs& a, bool f32) {
     return a.n <= (tune(TN_1D_TP_MAX) ? tune(TN_1D_TP_MAX) : tune(f32 ? TN_1D_TP_MAX_F32 : TN_1D_TP_MAX_F64));
 }
 
-// lane-per-env 1D rollouts (k_rollout1dl): batches with a 64-env wave for (nearly) every SIMD; canonical rows, every row written, 16-byte pieces
+// lane-per-env 1D rollouts (k_rollout1dl): batches with a 64-env wave for (nearly) every SIMD; every row written, 16-byte pieces; canonical rows and the layout variants
 bool roll1dl_ok(const KArgs& a, bool f32) {
-    return tune(TN_1D_LANE) != 0 && !a.variant && every_row(a) && pieces16(a) && !pipeline_off() && a.n >= tune(f32 ? TN_1D_LANE_MIN_F32 : TN_1D_LANE_MIN_F64);
+    if (tune(TN_1D_LANE) == 0 || !every_row(a) || !pieces16(a) || pipeline_off()) return false;
+    if (a.variant) return a.ld <= 46 && a.n >= tune(a.ld > 16 ? TN_1D_LANE_VAR_MIN : TN_1D_LANE_VAR_SHORT_MIN);
+    return a.n >= tune(f32 ? TN_1D_LANE_MIN_F32 : TN_1D_LANE_MIN_F64);
 }
 
 // snac_step on identity rows: k_step2d / k_step3d (wide loads, rows through emit_tile)

@@ -3,7 +3,7 @@ wave's LDS image, the wave's rows of a tick as one run of 64 x 56 bytes through 
 written, N % 4 == 0 and an aligned output from 45 056 envs on (float32 rows: 36 864; SNAC_1D_LANE_MIN_*); here against the CPU oracle on both sides of the
 threshold: ragged last tiles, float64 / float32, static / dynamic plans, the `>` rule bits, short episodes (many resets and plan changes per
 launch), launches that continue each other, tile-major outputs, the record outputs and explicit inputs; what it does not take (odd N,
-an unaligned output, layout variants) stays on the kernels behind it with the same rows."""
+an unaligned output) stays on the kernels behind it with the same rows; the layout variants of large batches take its VARLD forms."""
 import numpy as np
 import pytest
 
@@ -109,9 +109,9 @@ def test_record_outputs_fed_back_as_explicit_inputs():
     assert torch.equal(od, oa)
 
 
-def test_no_auto_reset_beyond_done_and_layout_variants_stay_behind():
-    """Static plans without a time limit in reach: the rollout API always resets, so the saturating counters are the tile kernels' tests;
-    here: a layout variant of a large batch does not take this kernel and still equals the canonical rows in its first 7 values."""
+def test_a_layout_variant_equals_the_canonical_rows_in_its_first_seven_values():
+    """A layout variant of a large batch (the position appended) takes the kernel's VARLD form and equals the canonical rows in its first 7
+    values."""
     import torch
     from snac_amd import BatchedDMPEnv
 
@@ -124,5 +124,53 @@ def test_no_auto_reset_beyond_done_and_layout_variants_stay_behind():
     oa, ra, da = a.rollout(T)
     assert _kernel() == "k_rollout1dl"
     ob, rb, db = b.rollout(T)
-    assert _kernel() != "k_rollout1dl"
+    assert _kernel() == "k_rollout1dl"
     assert torch.equal(oa, ob[..., :7]) and torch.equal(ra, rb) and torch.equal(da, db)
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("dyn,kw", base.VARIANTS_1D, ids=["lnet1d", "ppo", "record", "all"])
+def test_layout_variants_of_large_batches(dyn, kw, f32):
+    """The observation layouts of the reference's 1D env copies on k_rollout1dl's VARLD forms (staging tiles for rows of <= 16 / 38 / 46
+    values): 49 152 + 36 envs, time limit 7 (plan changes every few ticks), launches of 1, 70 and 33 ticks, explicit inputs, the tile-major
+    output -- against the oracle configured the same way; an unaligned output leaves the kernel with the same rows."""
+    import torch
+    from snac_amd import BatchedDMPEnv
+
+    n = 49152 + 36
+    table, full = base._tables(dyn)
+    dt = torch.float32 if f32 else torch.float64
+    cast = (lambda x: x.astype(np.float32)) if f32 else (lambda x: x)
+    env = BatchedDMPEnv(1, dyn, n, plans=full, seed=4, total_step=7, obs_dtype=dt, **kw)
+    orc = helpers.oracle().OracleBatch(1, dyn, n, table, seed=4)
+    norm = {None: dyn, "raw": False, "norm": True}[env.obs_scalars]
+    orc.configure(obs_norm=norm, frame=env.frame_value, tail=env.obs_tail)
+    orc.set_total_step(7)
+    assert helpers.same_bytes(env.reset().cpu().numpy(), cast(orc.reset()))
+    t0 = 0
+    for T in (1, 70, 33):
+        og, rg, dg = env.rollout(T)
+        assert _kernel() == "k_rollout1dl"
+        oc, rc, dc = orc.rollout(T, t0=t0, nthreads=16)
+        assert helpers.same_bytes(og.cpu().numpy(), cast(oc)), ("observations", T)
+        assert helpers.same_bytes(rg.cpu().numpy(), rc) and np.array_equal(dg.cpu().numpy().view(np.uint8), dc)
+        t0 += T
+        del og, oc
+    twin = env.fork(torch.arange(n, device=env.device))
+    third = env.fork(torch.arange(n, device=env.device))
+    rng = np.random.default_rng(1)
+    T = 40
+    acts, ks = rng.integers(0, 3, size=(T, n)).astype(np.int8), rng.integers(1, 4, size=(T, n)).astype(np.int8)
+    ta, tk = torch.from_numpy(acts).to(env.device), torch.from_numpy(ks).to(env.device)
+    og, rg, dg = env.rollout(T, actions=ta, step_size=tk)
+    assert _kernel() == "k_rollout1dl"
+    oc, rc, dc = orc.rollout(T, t0=t0, actions=acts, step_size=ks, nthreads=16)
+    assert helpers.same_bytes(og.cpu().numpy(), cast(oc)) and helpers.same_bytes(rg.cpu().numpy(), rc)
+    ot, rt, dtt = twin.rollout(T, actions=ta, step_size=tk, obs="tiled")
+    assert _kernel() == "k_rollout1dl"
+    assert torch.equal(twin.untile(ot), og) and torch.equal(rt, rg) and torch.equal(dtt, dg)
+    raw = torch.empty(T * n * env.obs_dim + 1, dtype=dt, device=env.device)
+    ou, ru, du = third.rollout(T, actions=ta, step_size=tk, out=raw[1:].view(T, n, env.obs_dim))
+    assert _kernel() != "k_rollout1dl" and torch.equal(ou, og) and torch.equal(ru, rg) and torch.equal(du, dg)
+    base._end_state(env, orc)
+    assert torch.equal(env._hdr, twin._hdr) and torch.equal(env._hdr, third._hdr) and torch.equal(env._grid, third._grid)
