@@ -96,6 +96,10 @@ CROSSOVERS = [
      {"SNAC_1D_LANE_MIN_F64": "1"}, {"SNAC_1D_LANE": "0"}, "min", [32768, 36864, 40960, 45056, 49152, 57344]),
     ("SNAC_1D_LANE_MIN_F32", "k_rollout1dl (lane = env) | k_rollout1dt, 1D float32 rows", dict(kind=1, T=0, f32=1, layout=None, mode="rollout"),
      {"SNAC_1D_LANE_MIN_F32": "1"}, {"SNAC_1D_LANE": "0"}, "min", [28672, 32768, 36864, 40960, 45056, 49152]),
+    ("SNAC_1D_LANE_VAR_MIN", "k_rollout1dl<VARLD> | k_rollout1dt<VAR>, 1D 37-value PPO rows", dict(kind=1, T=0, f32=0, layout="ppo", mode="rollout"),
+     {"SNAC_1D_LANE_VAR_MIN": "1"}, {"SNAC_1D_LANE": "0"}, "min", [16384, 20480, 24576, 28672, 32768, 40960]),
+    ("SNAC_1D_LANE_VAR_SHORT_MIN", "k_rollout1dl<VARLD> | k_rollout1dt<VAR>, 1D 8-value L-Net rows", dict(kind=1, T=0, f32=0, layout="lnet1d", mode="rollout"),
+     {"SNAC_1D_LANE_VAR_SHORT_MIN": "1"}, {"SNAC_1D_LANE": "0"}, "min", [32768, 40960, 45056, 49152, 57344, 65536]),
 ]
 
 
