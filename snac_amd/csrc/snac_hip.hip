@@ -6,6 +6,7 @@ namespace snac_detail {
 void launch_step3dq(const snac_env_desc* d, const KArgs& a, hipStream_t s);                   // k_step3dq.hip
 void launch_step1d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                    // k_step1d.hip
 void launch_edges1d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                   // k_step1d.hip
+void launch_reset(const snac_env_desc* d, const KArgs& a, hipStream_t s);                     // k_reset.hip
 void launch_roll2db(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);   // k_roll2db.hip
 void launch_roll2dbv(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);  // k_roll2dbv.hip: the same kernel for the layout variants: k_rollout2db (declared here for the same reason as the next one)
 void launch_roll3dbv(const snac_env_desc* d, const KArgs& a, hipStream_t s);   // k_roll3dbv.hip: k_rollout3db for the layout variants (declared here: snac_dev.h is hashed into profiles/traffic.json)
@@ -162,6 +163,8 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_STEP1D_VAR_MIN  */ {"SNAC_STEP1D_VAR_MIN", 256, "k_step1d takes the 1D layout variants (rows of 8 .. 46 values) from this many envs (1024 envs with the 37-value PPO rows: 5.4 against 6.5 us per tick on the tile kernel, 65 536: 6.9 / 23.0, 524 288 with 8-value L-Net rows: 18.3 / 44.1; r06_step1d.txt)"},
     /* TN_1D_LANE_VAR_MIN */ {"SNAC_1D_LANE_VAR_MIN", 28672, "k_rollout1dl takes the 1D layout variants with rows of more than 16 values from this many envs (37-value PPO rows: 1.75 ms per 750 ticks up to 32 768 envs, 2.19 at 65 536 = 6.8 TB/s; k_rollout1dt's VAR form 1.01 / 2.07 / 4.21 ms at 16 384 / 32 768 / 65 536; r06_1d_lane.txt) ..."},
     /* TN_1D_LANE_VAR_SHORT_MIN */ {"SNAC_1D_LANE_VAR_SHORT_MIN", 49152, "... and those with rows of at most 16 values from this many (8-value L-Net rows: 0.78 ms flat; k_rollout1dt 0.76 at 45 056, 1.05 at 65 536)"},
+    /* TN_RESET_FAST      */ {"SNAC_RESET_FAST", 1, "snac_reset / snac_reset_scalar of every env (no mask), canonical layout, N % 4 == 0, aligned obs, on k_reset: nothing of the old state is read but the episode counter; records zeroed and rows written as runs (0 = the tile kernel k_aux) ..."},
+    /* TN_RESET_FAST_MIN  */ {"SNAC_RESET_FAST_MIN", 256, "... from this many envs"},
 };
 
 int tune(int id) {
@@ -268,6 +271,12 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     if (d->kind == SNAC_ENV_2D && op == OP_ROLLOUT && E == 16 && tune(TN_TILE) == 0 && a.n >= tune(TN_2D_TILE32_MIN)) E = 32;   // one wave of 32 per SIMD beats 1.5 of 16
     const char* const tile_name = op == OP_ROLLOUT ? "k_rollout" : (op == OP_TRANSITION ? "k_transition" : "k_aux");
     g_kernel = tile_name;
+    if (op == OP_AUX && a.aux_op == AUX_RESET && !a.mask && !a.variant && pieces16(a) && !pipeline_off() && tune(TN_RESET_FAST) != 0 && a.n >= tune(TN_RESET_FAST_MIN)) {
+        g_kernel = "k_reset";
+        launch_reset(d, a, s);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? SNAC_OK : fail_hip(e, "kernel launch");
+    }
     switch (d->kind) {
         case SNAC_ENV_1D:
             // rollouts that write every row: the time-parallel kernel while its rate beats the tile kernel's (lane-per-env transition)
