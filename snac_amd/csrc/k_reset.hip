@@ -1,4 +1,4 @@
-// k_reset.hip -- k_reset: snac_reset / snac_reset_scalar of EVERY env of a batch (no mask), the canonical layout (round 6)
+// k_reset.hip -- k_reset: snac_reset / snac_reset_scalar of EVERY env of a batch (no mask), the canonical layout; k_iou: snac_iou (round 6)
 #include "snac_dev.h"
 #include "rows1d.h"
 
@@ -65,6 +65,51 @@ __global__ __launch_bounds__(WPB * 64) void k_reset(const KArgs a) {
     }
 }
 
+// k_iou: snac_iou of a batch (env.iou(): DMP_Env_1D_static.py:138-151, the 2D scripts' boolean IoU script/DQN/2d/DQN_2d_dynamic.py:63-71,
+// DMP_simulator_3d_*.py:257-276), lane = env, no LDS.  k_aux loads every record into LDS first -- also in 3D, where the value comes from the
+// header's running sum alone.  Here: 3D the header; 2D the env's 20 row words against its plan's (popcounts); 1D its 30 heights against the
+// plan's.  The formulas are K::iou's.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_iou(const KArgs a) {
+    const int env = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (env >= a.n) return;
+    Lane s;
+    s.unpack(a.hdr[env]);
+    double v;
+    if constexpr (KIND == 3) {
+        v = (double)s.cross / (double)(s.tb + s.cb - s.cross);
+    } else if constexpr (KIND == 2) {
+        const uint4* const g4 = (const uint4*)a.grid + (size_t)env * 5;
+        const uint32_t* const p = (const uint32_t*)a.plans + (size_t)s.pidx * 20;
+        int inter = 0, uni = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint4 g = g4[i];
+            inter += __popc(g.x & p[4 * i]) + __popc(g.y & p[4 * i + 1]) + __popc(g.z & p[4 * i + 2]) + __popc(g.w & p[4 * i + 3]);
+            uni += __popc(g.x | p[4 * i]) + __popc(g.y | p[4 * i + 1]) + __popc(g.z | p[4 * i + 2]) + __popc(g.w | p[4 * i + 3]);
+        }
+        v = (double)inter / (double)uni;
+    } else {
+        const uint4* const g4 = (const uint4*)a.grid + (size_t)env * 4;
+        const uint32_t* const p = (const uint32_t*)((const int16_t*)a.plans + (size_t)s.pidx * 32);
+        int a1 = 0, a2 = 0, kk = 0;
+        auto cell2 = [&](uint32_t gw, uint32_t pw, bool second) {     // two cells per dword
+            const int g0 = (int)(int16_t)(gw & 0xFFFFu), p0 = (int)(int16_t)(pw & 0xFFFFu);
+            a1 += p0; a2 += g0; kk += max(g0 - p0, 0);
+            if (second) { const int g1 = (int)(int16_t)(gw >> 16), p1 = (int)(int16_t)(pw >> 16); a1 += p1; a2 += g1; kk += max(g1 - p1, 0); }
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 g = g4[i];
+            cell2(g.x, p[4 * i], true); cell2(g.y, p[4 * i + 1], true); cell2(g.z, p[4 * i + 2], true);
+            if (i < 3) cell2(g.w, p[4 * i + 3], true);                // dword 15 holds the record's two padding cells
+        }
+        const int cross = a2 - kk;
+        v = (double)cross / (double)(a1 + a2 - cross);
+    }
+    a.out_f64[env] = v;
+}
+
 template <int KIND, bool DYN, typename OT>
 void launch_r(const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + 63) / 64;
@@ -85,6 +130,13 @@ void launch_reset(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     if (d->kind == SNAC_ENV_1D) launch_rk<1>(d, a, s);
     else if (d->kind == SNAC_ENV_2D) launch_rk<2>(d, a, s);
     else launch_rk<3>(d, a, s);
+}
+
+void launch_iou(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)((a.n + 255) / 256)), block(256);
+    if (d->kind == SNAC_ENV_1D) hipLaunchKernelGGL((k_iou<1>), grid, block, 0, s, a);
+    else if (d->kind == SNAC_ENV_2D) hipLaunchKernelGGL((k_iou<2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_iou<3>), grid, block, 0, s, a);
 }
 
 }  // namespace snac_detail

@@ -7,6 +7,7 @@ void launch_step3dq(const snac_env_desc* d, const KArgs& a, hipStream_t s);     
 void launch_step1d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                    // k_step1d.hip
 void launch_edges1d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                   // k_step1d.hip
 void launch_reset(const snac_env_desc* d, const KArgs& a, hipStream_t s);                     // k_reset.hip
+void launch_iou(const snac_env_desc* d, const KArgs& a, hipStream_t s);                       // k_reset.hip
 void launch_roll2db(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);   // k_roll2db.hip
 void launch_roll2dbv(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);  // k_roll2dbv.hip: the same kernel for the layout variants: k_rollout2db (declared here for the same reason as the next one)
 void launch_roll3dbv(const snac_env_desc* d, const KArgs& a, hipStream_t s);   // k_roll3dbv.hip: k_rollout3db for the layout variants (declared here: snac_dev.h is hashed into profiles/traffic.json)
@@ -165,6 +166,7 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_1D_LANE_VAR_SHORT_MIN */ {"SNAC_1D_LANE_VAR_SHORT_MIN", 49152, "... and those with rows of at most 16 values from this many (8-value L-Net rows: 0.78 ms flat; k_rollout1dt 0.76 at 45 056, 1.05 at 65 536)"},
     /* TN_RESET_FAST      */ {"SNAC_RESET_FAST", 1, "snac_reset / snac_reset_scalar of every env (no mask), canonical layout, N % 4 == 0, aligned obs, on k_reset: nothing of the old state is read but the episode counter; records zeroed and rows written as runs (0 = the tile kernel k_aux) ..."},
     /* TN_RESET_FAST_MIN  */ {"SNAC_RESET_FAST_MIN", 256, "... from this many envs"},
+    /* TN_IOU_FAST        */ {"SNAC_IOU_FAST", 1, "snac_iou on k_iou (lane = env, no LDS; 3D: the header alone) from 256 envs; 0 = the tile kernel k_aux, which loads every record into LDS first"},
 };
 
 int tune(int id) {
@@ -274,6 +276,12 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     if (op == OP_AUX && a.aux_op == AUX_RESET && !a.mask && !a.variant && pieces16(a) && !pipeline_off() && tune(TN_RESET_FAST) != 0 && a.n >= tune(TN_RESET_FAST_MIN)) {
         g_kernel = "k_reset";
         launch_reset(d, a, s);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? SNAC_OK : fail_hip(e, "kernel launch");
+    }
+    if (op == OP_AUX && a.aux_op == AUX_IOU && tune(TN_IOU_FAST) != 0 && a.n >= 256 && (((uintptr_t)a.grid | (uintptr_t)a.plans) & 15) == 0 && !pipeline_off()) {
+        g_kernel = "k_iou";
+        launch_iou(d, a, s);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? SNAC_OK : fail_hip(e, "kernel launch");
     }

@@ -1,4 +1,4 @@
-"""snac_reset timed on the device: all envs reset back to back into a preallocated row tensor, and a masked reset of a quarter of them.
+"""snac_reset timed on the device: all envs reset back to back, a masked reset of a quarter of them, and snac_iou / snac_observe of a batch mid-episode.
 
     gpurun -- python tools/reset_time.py [kind] [N] [reps]
 """
@@ -32,6 +32,25 @@ def main():
         us = a.elapsed_time(b) / reps * 1e3
         rowb = env.obs_dim * 8
         print("%dD reset N=%d %-18s %.1f us  (%s; rows %d B per env: %.2f TB/s written)" % (kind, n, name, us, _lib.lib().snac_last_kernel().decode(), rowb, n * rowb / us / 1e6), flush=True)
+    env.rollout(40, obs=None)                                        # envs mid-episode: boards with bricks
+    for _ in range(10):
+        env.iou()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        env.iou()
+    b.record()
+    torch.cuda.synchronize()
+    print("%dD iou   N=%d %.1f us  (%s)" % (kind, n, a.elapsed_time(b) / reps * 1e3, _lib.lib().snac_last_kernel().decode()), flush=True)
+    for _ in range(10):
+        env.observe()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        env.observe()
+    b.record()
+    torch.cuda.synchronize()
+    print("%dD observe N=%d %.1f us  (%s)" % (kind, n, a.elapsed_time(b) / reps * 1e3, _lib.lib().snac_last_kernel().decode()), flush=True)
 
 
 if __name__ == "__main__":
