@@ -28,7 +28,9 @@ namespace {
 // TE = 32: half-filled tiles (lanes 32 .. 63 idle) -- twice the waves for batches that do not fill the CUs with 64 rows of kilobytes per wave.
 // NTL / NTS (canonical rows only): the records by non-temporal loads / the rows by non-temporal stores -- which pays depends on whether state
 // and rows fit the Infinity Cache: the launch picks one of three forms by batch size (profiles/r06_step_loads.txt)
-template <bool DYN, typename OT, int WPB, bool VAR = false, int TE = 64, bool NTL = true, bool NTS = false>
+// AUX: not a step -- snac_reset with a mask (the masked envs start over, every env reports its observation) and snac_observe on the same loads
+// and rows: no action, no rules, no reward / done; a header is written only for an env that was reset (k_aux: 80 us per masked reset of 524 288 envs).
+template <bool DYN, typename OT, int WPB, bool VAR = false, int TE = 64, bool NTL = true, bool NTS = false, bool AUX = false>
 __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
     using K = K2D<DYN, 64>;
     constexpr int E = TE, GE = K::GE;
@@ -64,23 +66,37 @@ __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
     int episode = 0;
     if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
     const uint64_t gid = (uint64_t)(a.env_id_base + env);
-    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
-    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
-    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
-    if (a.actions && active) act = (int)a.actions[env];
-    if (a.step_size && active) k = (int)a.step_size[env];
-    k = min(max(k, 1), 3);
-    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
-    if (nr) {
-        const int old_pidx = s.pidx, old_tb = s.tb;
-        episode += 1;
-        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
-        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
-        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    int act = 0, k = 1;
+    bool nr;
+    if constexpr (AUX) {
+        nr = active && a.aux_op == AUX_RESET && (a.mask ? a.mask[env] != 0 : true);
+        if (nr) {                                                    // k_aux's reset: the plan row from the indices, the scalar or the counter RNG
+            episode += 1;
+            int pidx;
+            if (a.plan_idx_in) pidx = a.plan_idx_in[env];
+            else if (a.plan_scalar >= 0) pidx = a.plan_scalar;
+            else pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, a.static_plan);
+            K::reset(a, s, min(max(pidx, 0), a.num_plans - 1));
+        }
+    } else {
+        const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+        act = (int)(((w >> 16) * (uint32_t)K::A) >> 16); k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+        if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+        if (a.actions && active) act = (int)a.actions[env];
+        if (a.step_size && active) k = (int)a.step_size[env];
+        k = min(max(k, 1), 3);
+        nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+        if (nr) {
+            const int old_pidx = s.pidx, old_tb = s.tb;
+            episode += 1;
+            const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+            K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+            if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+        }
     }
     const uint32_t* const prow = (const uint32_t*)a.plans + (size_t)s.pidx * GE;
     const int q0 = min(max(s.r - 3, 0), GE - 1), bit = min(max(s.c - 3, 0), 19);
-    const uint32_t pword = prow[q0];                                 // the one dependent load: the plan row under the agent (L2)
+    const uint32_t pword = AUX ? 0u : prow[q0];                      // the one dependent load: the plan row under the agent (L2)
 #pragma unroll
     for (int i = 0; i < 5; ++i) ((uint4*)rec)[i * 64 + lane] = rv[i];
     uint32_t* const mine = rec + lane * GE;
@@ -92,17 +108,23 @@ __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
     const uint32_t row0 = mine[q0];
     const bool was = ((row0 >> bit) & 1u) != 0u, planned = ((pword >> bit) & 1u) != 0u;
     const uint32_t newrow = row0 | (1u << bit);
-    const Rule2D u = rules2d(s, act, k, was, planned, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+    Rule2D u;
+    u.drop = false; u.term = false; u.done = (s.flags & SNAC_FLAG_NEED_RESET) != 0; u.reward = 0;   // AUX: SNAC_TAIL_RECORD outside a step reports the pending-reset flag
+    if constexpr (!AUX) u = rules2d(s, act, k, was, planned, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
     const bool drop = active && u.drop;
     if (drop) mine[q0] = newrow;
     const bool done = active && u.done;
     const int reward = u.reward;
-    s.ep_ret = clamp16(s.ep_ret + reward);
-    s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    if constexpr (!AUX) {
+        s.ep_ret = clamp16(s.ep_ret + reward);
+        s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    }
     if (active) {
-        if (a.reward) a.reward[env] = (float)reward;
-        if (a.done) a.done[env] = done ? 1 : 0;
-        a.hdr[env] = s.pack();
+        if constexpr (!AUX) {
+            if (a.reward) a.reward[env] = (float)reward;
+            if (a.done) a.done[env] = done ? 1 : 0;
+        }
+        if (!AUX || nr) a.hdr[env] = s.pack();
         if (nr) {
             a.episode[env] = episode;
             uint32_t* const gw = (uint32_t*)a.grid + (size_t)env * GE;
@@ -112,7 +134,7 @@ __global__ __launch_bounds__(WPB * 64) void k_step2d(const KArgs a) {
             ((uint32_t*)a.grid)[(size_t)env * GE + q0] = newrow;
         }
     }
-    if (a.stats_on && __builtin_expect(__any(done), 0)) {            // snac_step: episodic sums; the boolean IoU needs board and plan
+    if (!AUX && a.stats_on && __builtin_expect(__any(done), 0)) {    // snac_step: episodic sums; the boolean IoU needs board and plan
         if (done) {
             int inter = 0, uni = 0;
             for (int q = 0; q < GE; ++q) { const uint32_t g = mine[q], p = prow[q]; inter += __popc(g & p); uni += __popc(g | p); }
@@ -526,6 +548,14 @@ __global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(3, 3))
 }  // namespace
 
 namespace snac_detail {
+
+void launch_aux2d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {   // masked reset / observe: the canonical layout, plain loads and rows
+    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
+    const int tiles = (a.n + 63) / 64;
+    const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+    if (dyn) { if (f32) hipLaunchKernelGGL((k_step2d<true, float, 4, false, 64, false, false, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<true, double, 4, false, 64, false, false, true>), grid, block, 0, s, a); }
+    else { if (f32) hipLaunchKernelGGL((k_step2d<false, float, 4, false, 64, false, false, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_step2d<false, double, 4, false, 64, false, false, true>), grid, block, 0, s, a); }
+}
 
 void launch_step2d(const snac_env_desc* d, const KArgs& a, bool half, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;

@@ -20,7 +20,10 @@ namespace {
 // NTL / NTS: the records by non-temporal loads / the rows by non-temporal stores (k_step2d's forms; SNAC_STEP1D_FORM).
 // VAR: the layout variants of snac_env_desc (rows1d.h: rows of a.ld <= 46 values); the staging tiles are dynamic LDS sized for the rows' length
 // (8-value rows: 8.4 KB per wave, 16 waves per CU; 46-value rows: 28 KB, two waves per block).
-template <bool DYN, typename OT, int WPB, bool NTL, bool NTS, bool VAR = false>
+// AUX: not a step -- snac_reset with a mask (the masked envs start over, every env reports its observation) and snac_observe on the same loads
+// and rows: no action, no rules, no reward / done; a header is written only for an env that was reset.  (k_aux loads every record into LDS
+// through two-byte accesses: 45 us per masked reset of 524 288 envs.)
+template <bool DYN, typename OT, int WPB, bool NTL, bool NTS, bool VAR = false, bool AUX = false>
 __global__ __launch_bounds__(WPB * 64) void k_step1d(const KArgs a) {
     using K = K1D<DYN, 64>;
     constexpr int E = 64, GE = K::GE, ES = K::ES, RW = ES / 2;      // 32 cells per record; 34 per bordered row = 17 dwords
@@ -55,22 +58,36 @@ __global__ __launch_bounds__(WPB * 64) void k_step1d(const KArgs a) {
     int episode = 0;
     if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
     const uint64_t gid = (uint64_t)(a.env_id_base + env);
-    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
-    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
-    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
-    if (a.actions && active) act = (int)a.actions[env];
-    if (a.step_size && active) k = (int)a.step_size[env];
-    k = min(max(k, 1), 3);
-    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
-    if (nr) {
-        const int old_pidx = s.pidx, old_tb = s.tb;
-        episode += 1;
-        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
-        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
-        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    int act = 0, k = 1;
+    bool nr;
+    if constexpr (AUX) {
+        nr = active && a.aux_op == AUX_RESET && (a.mask ? a.mask[env] != 0 : true);
+        if (nr) {                                                    // k_aux's reset: the plan row from the indices, the scalar or the counter RNG
+            episode += 1;
+            int pidx;
+            if (a.plan_idx_in) pidx = a.plan_idx_in[env];
+            else if (a.plan_scalar >= 0) pidx = a.plan_scalar;
+            else pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, a.static_plan);
+            K::reset(a, s, min(max(pidx, 0), a.num_plans - 1));
+        }
+    } else {
+        const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+        act = (int)(((w >> 16) * (uint32_t)K::A) >> 16); k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+        if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+        if (a.actions && active) act = (int)a.actions[env];
+        if (a.step_size && active) k = (int)a.step_size[env];
+        k = min(max(k, 1), 3);
+        nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+        if (nr) {
+            const int old_pidx = s.pidx, old_tb = s.tb;
+            episode += 1;
+            const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+            K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+            if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+        }
     }
     const int16_t* const prow = (const int16_t*)a.plans + (size_t)s.pidx * GE;
-    const int pl = (int)prow[min(max(s.r - 2, 0), 29)];              // the one dependent load: the plan's height under the agent (L2)
+    const int pl = AUX ? 0 : (int)prow[min(max(s.r - 2, 0), 29)];    // the one dependent load: the plan's height under the agent (L2)
     // ---- the records into K1D's bordered rows: piece p of env e holds cells 8 p .. 8 p + 7 = bordered 2 + 8 p ..: dwords 1 + 4 p .. of the row;
     // dword 0 (bordered cells 0, 1) and dword 16 (cells 32, 33: the record's two padding cells) are the frame
 #pragma unroll
@@ -88,17 +105,23 @@ __global__ __launch_bounds__(WPB * 64) void k_step1d(const KArgs a) {
     }
     // ---- the 1D step (rules1d, snac_dev.h) on the cell under the agent
     const int r_old = s.r;
-    const Rule1D u = rules1d(s, act, k, (int)mine[r_old], pl, a.ts_done, a.brick_gt);
+    Rule1D u;
+    u.drop = false; u.done = (s.flags & SNAC_FLAG_NEED_RESET) != 0; u.hnew = 0; u.reward = 0;   // AUX: SNAC_TAIL_RECORD outside a step reports the pending-reset flag
+    if constexpr (!AUX) u = rules1d(s, act, k, (int)mine[r_old], pl, a.ts_done, a.brick_gt);
     const bool drop = active && u.drop;
     if (drop) mine[r_old] = (int16_t)u.hnew;
     const bool done = active && u.done;
     const int reward = u.reward;
-    s.ep_ret = clamp16(s.ep_ret + reward);
-    s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    if constexpr (!AUX) {
+        s.ep_ret = clamp16(s.ep_ret + reward);
+        s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    }
     if (active) {
-        if (a.reward) a.reward[env] = (float)reward;
-        if (a.done) a.done[env] = done ? 1 : 0;
-        a.hdr[env] = s.pack();
+        if constexpr (!AUX) {
+            if (a.reward) a.reward[env] = (float)reward;
+            if (a.done) a.done[env] = done ? 1 : 0;
+        }
+        if (!AUX || nr) a.hdr[env] = s.pack();
         if (nr) {
             a.episode[env] = episode;
             uint4* const gw = (uint4*)a.grid + (size_t)env * 4;
@@ -111,7 +134,7 @@ __global__ __launch_bounds__(WPB * 64) void k_step1d(const KArgs a) {
             ((int16_t*)a.grid)[(size_t)env * GE + r_old - 2] = (int16_t)u.hnew;
         }
     }
-    if (a.stats_on && __builtin_expect(__any(done), 0)) {            // snac_step: episodic sums; iou :138-151 needs row and plan
+    if (!AUX && a.stats_on && __builtin_expect(__any(done), 0)) {    // snac_step: episodic sums; iou :138-151 needs row and plan
         if (done) {
             int a1 = 0, a2 = 0, kk = 0;
             for (int i = 0; i < 30; ++i) {
@@ -271,6 +294,12 @@ void launch_e1(const KArgs& a, hipStream_t s) {
 }
 
 template <bool DYN, typename OT>
+void launch_a1(const KArgs& a, hipStream_t s) {                     // masked reset / observe: the canonical layout, plain loads and rows
+    const int tiles = (a.n + 63) / 64;
+    hipLaunchKernelGGL((k_step1d<DYN, OT, 4, false, false, false, true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, a);
+}
+
+template <bool DYN, typename OT>
 void launch_s1(const KArgs& a, hipStream_t s) {
     const int tiles = (a.n + 63) / 64;
     if (a.variant) {                                                 // the layout variants: plain loads and rows; four waves per block while their tiles fit 64 KB
@@ -296,6 +325,12 @@ void launch_step1d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
     if (dyn) f32 ? launch_s1<true, float>(a, s) : launch_s1<true, double>(a, s);
     else f32 ? launch_s1<false, float>(a, s) : launch_s1<false, double>(a, s);
+}
+
+void launch_aux1d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
+    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
+    if (dyn) f32 ? launch_a1<true, float>(a, s) : launch_a1<true, double>(a, s);
+    else f32 ? launch_a1<false, float>(a, s) : launch_a1<false, double>(a, s);
 }
 
 void launch_edges1d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {

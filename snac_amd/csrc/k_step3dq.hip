@@ -22,7 +22,10 @@ namespace {
 // (profiles/r06_step_loads.txt): while the STATE fits (below ~360 000 envs) plain loads keep it there for the next tick and non-temporal
 // rows stay out of its way ("resident": 65 536 envs 12.9 -> 10.4 us per tick); from there to ~600 000 envs the state streams (non-temporal
 // loads) and plain rows do best; beyond, the rows alone overflow the cache and must not go through it.  The launch picks the form.
-template <bool DYN, typename OT, int WPB, bool NTL, bool NTS>
+// AUX: not a step -- snac_reset with a mask (the masked envs start over, every env reports its observation) and snac_observe on the same span
+// loads and rows: no action (the span is the window's seven rows), no rules, no reward / done; a header is written only for an env that was
+// reset (k_aux: 415 us per masked reset of 524 288 envs).
+template <bool DYN, typename OT, int WPB, bool NTL, bool NTS, bool AUX = false>
 __global__ __launch_bounds__(WPB * 64) void k_step3dq(const KArgs a) {
     using K = K3D<DYN, 8>;
     constexpr int E = 16, GE = K::GE, NPC = 26, SPAN = NPC * 16, NIT = (E * NPC + 63) / 64;   // pieces and bytes per env; load instructions per wave
@@ -43,26 +46,40 @@ __global__ __launch_bounds__(WPB * 64) void k_step3dq(const KArgs a) {
     int episode = 0;
     if (active) { s.unpack(a.hdr[env]); episode = a.episode[env]; }
     const uint64_t gid = (uint64_t)(a.env_id_base + env);
-    const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
-    int act = (int)(((w >> 16) * (uint32_t)K::A) >> 16), k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
-    if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
-    if (a.actions && active) act = (int)a.actions[env];
-    if (a.step_size && active) k = (int)a.step_size[env];
-    k = min(max(k, 1), 3);
-    const bool nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
-    if (nr) {
-        const int old_pidx = s.pidx, old_tb = s.tb;
-        episode += 1;
-        const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
-        K::reset(a, s, pidx == old_pidx ? -1 : pidx);
-        if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+    int act = -1, k = 1;                                             // (AUX: no action -- none of the span's extensions below applies)
+    bool nr;
+    if constexpr (AUX) {
+        nr = active && a.aux_op == AUX_RESET && (a.mask ? a.mask[env] != 0 : true);
+        if (nr) {                                                    // k_aux's reset: the plan row from the indices, the scalar or the counter RNG
+            episode += 1;
+            int pidx;
+            if (a.plan_idx_in) pidx = a.plan_idx_in[env];
+            else if (a.plan_scalar >= 0) pidx = a.plan_scalar;
+            else pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, a.static_plan);
+            K::reset(a, s, min(max(pidx, 0), a.num_plans - 1));
+        }
+    } else {
+        const uint32_t w = rng_word(env_keys(a.key_step, gid), a.t0);
+        act = (int)(((w >> 16) * (uint32_t)K::A) >> 16); k = 1 + (int)(((w & 0xffffu) * 3u) >> 16);
+        if (a.use_scalar) { act = a.act_scalar; k = a.k_scalar; }
+        if (a.actions && active) act = (int)a.actions[env];
+        if (a.step_size && active) k = (int)a.step_size[env];
+        k = min(max(k, 1), 3);
+        nr = active && a.auto_reset && (s.flags & SNAC_FLAG_NEED_RESET);
+        if (nr) {
+            const int old_pidx = s.pidx, old_tb = s.tb;
+            episode += 1;
+            const int pidx = pick_plan<K>(a, env_keys(a.key_plan, gid), episode, old_pidx);
+            K::reset(a, s, pidx == old_pidx ? -1 : pidx);
+            if (pidx == old_pidx) { s.pidx = old_pidx; s.tb = old_tb; }
+        }
     }
     const int d = act & 3;
     const int dr = d == 2 ? 1 : (d == 3 ? -1 : 0), dc = d == 0 ? -1 : (d == 1 ? 1 : 0);
     const int tr = s.r + dr - 3, tc = s.c + dc - 3;                  // the build target in plan (interior) coordinates
     const bool inside = (unsigned)tr < 20u && (unsigned)tc < 20u;
     const int tcell = inside ? tr * 20 + tc : 0;
-    const int pl = ((const int16_t*)a.plans)[(size_t)s.pidx * GE + tcell];
+    const int pl = AUX ? 0 : (int)((const int16_t*)a.plans)[(size_t)s.pidx * GE + tcell];
     // ---- the span (k_step3ds): interior rows rlo .. rlo + 9; of them this tick can touch rows qlo .. qhi and columns clo .. chi
     const int rlo = min(max(s.r - 6 - ((act == 3) ? 3 : 0), 0), 10);
     const int boff = rlo * 40, ab = boff & ~15, mis = boff & 15;
@@ -101,22 +118,28 @@ __global__ __launch_bounds__(WPB * 64) void k_step3dq(const KArgs a) {
     // ---- K3D::step by selects (the formulation of k_step3d / k_step3ds / Roll3D::tick), the same in the env's four lanes
     const int n0 = cell_at(qa, ca - 1), n1 = cell_at(qa, ca + 1), n2 = cell_at(qa + 1, ca), n3 = cell_at(qa - 1, ca);   // check_sur: left, right, "up" (row + 1), "down"
     const int c2 = cell_at(qa + 2 * dr, ca + 2 * dc), c3 = cell_at(qa + 3 * dr, ca + 3 * dc);
-    const Rule3D u = rules3d<DYN>(s, act, k, n0, n1, n2, n3, c2, c3, active, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
+    Rule3D u;
+    u.built = false; u.sel = false; u.done = false; u.newh = 0; u.reward0 = 0;
+    if constexpr (!AUX) u = rules3d<DYN>(s, act, k, n0, n1, n2, n3, c2, c3, active, a.ts_done, a.brick_gt);   // the rules: snac_dev.h
     const bool built = u.built;
     const int newh = u.newh;
     s.cross += (built && newh <= pl) ? 1 : 0;
     bool done = u.done;
     const int reward = u.sel ? reward_check3d(newh, pl) : u.reward0;
     done = done && active;
-    s.ep_ret = clamp16(s.ep_ret + reward);
-    s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    if constexpr (!AUX) {
+        s.ep_ret = clamp16(s.ep_ret + reward);
+        s.flags = done ? SNAC_FLAG_NEED_RESET : 0;
+    }
     if (active && part == 0) {                                       // the env's stores, by the first of its lanes
-        if (a.reward) a.reward[env] = (float)reward;
-        if (a.done) a.done[env] = done ? 1 : 0;
-        a.hdr[env] = s.pack();
+        if constexpr (!AUX) {
+            if (a.reward) a.reward[env] = (float)reward;
+            if (a.done) a.done[env] = done ? 1 : 0;
+        }
+        if (!AUX || nr) a.hdr[env] = s.pack();
         if (nr) a.episode[env] = episode;
         if (built && !nr) ((int16_t*)a.grid)[(size_t)env * GE + tcell] = (int16_t)newh;
-        if (a.stats_on && done) {                                    // snac_step: episodic sums
+        if (!AUX && a.stats_on && done) {                            // snac_step: episodic sums
             const double v = K::iou(nullptr, s, 0);
             stat_add(a.stat_episodes + env, 1);
             stat_add(a.stat_return + env, s.ep_ret);
@@ -187,9 +210,21 @@ void launch_q(const KArgs& a, hipStream_t s) {
     }
 }
 
+template <bool DYN, typename OT>
+void launch_qa(const KArgs& a, hipStream_t s) {                     // masked reset / observe: plain span loads and rows
+    const int tiles = (a.n + 15) / 16;
+    hipLaunchKernelGGL((k_step3dq<DYN, OT, 4, false, false, true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, a);
+}
+
 }  // namespace
 
 namespace snac_detail {
+
+void launch_aux3d(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
+    const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;
+    if (dyn) f32 ? launch_qa<true, float>(a, s) : launch_qa<true, double>(a, s);
+    else f32 ? launch_qa<false, float>(a, s) : launch_qa<false, double>(a, s);
+}
 
 void launch_step3dq(const snac_env_desc* d, const KArgs& a, hipStream_t s) {
     const bool dyn = d->dynamic != 0, f32 = d->obs_dtype == SNAC_OBS_F32;

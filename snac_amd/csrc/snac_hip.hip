@@ -8,6 +8,9 @@ void launch_step1d(const snac_env_desc* d, const KArgs& a, hipStream_t s);      
 void launch_edges1d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                   // k_step1d.hip
 void launch_reset(const snac_env_desc* d, const KArgs& a, hipStream_t s);                     // k_reset.hip
 void launch_iou(const snac_env_desc* d, const KArgs& a, hipStream_t s);                       // k_reset.hip
+void launch_aux1d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                     // k_step1d.hip
+void launch_aux2d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                     // k_step.hip
+void launch_aux3d(const snac_env_desc* d, const KArgs& a, hipStream_t s);                     // k_step3dq.hip
 void launch_roll2db(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);   // k_roll2db.hip
 void launch_roll2dbv(const snac_env_desc* d, const KArgs& a, int steppers, hipStream_t s);  // k_roll2dbv.hip: the same kernel for the layout variants: k_rollout2db (declared here for the same reason as the next one)
 void launch_roll3dbv(const snac_env_desc* d, const KArgs& a, hipStream_t s);   // k_roll3dbv.hip: k_rollout3db for the layout variants (declared here: snac_dev.h is hashed into profiles/traffic.json)
@@ -167,6 +170,7 @@ const Knob KNOBS[TN_COUNT] = {
     /* TN_RESET_FAST      */ {"SNAC_RESET_FAST", 1, "snac_reset / snac_reset_scalar of every env (no mask), canonical layout, N % 4 == 0, aligned obs, on k_reset: nothing of the old state is read but the episode counter; records zeroed and rows written as runs (0 = the tile kernel k_aux) ..."},
     /* TN_RESET_FAST_MIN  */ {"SNAC_RESET_FAST_MIN", 256, "... from this many envs"},
     /* TN_IOU_FAST        */ {"SNAC_IOU_FAST", 1, "snac_iou on k_iou (lane = env, no LDS; 3D: the header alone) from 256 envs; 0 = the tile kernel k_aux, which loads every record into LDS first"},
+    /* TN_AUX_STEP        */ {"SNAC_AUX_STEP", 1, "snac_reset with a mask and snac_observe (canonical layout, N % 4 == 0, aligned obs, from 256 envs) on the step kernels' AUX forms (k_step1d / k_step2d / k_step3dq without a step); 0 = the tile kernel k_aux"},
 };
 
 int tune(int id) {
@@ -276,6 +280,14 @@ int launch(Op op, const snac_env_desc* d, const KArgs& a, void* stream) {
     if (op == OP_AUX && a.aux_op == AUX_RESET && !a.mask && !a.variant && pieces16(a) && !pipeline_off() && tune(TN_RESET_FAST) != 0 && a.n >= tune(TN_RESET_FAST_MIN)) {
         g_kernel = "k_reset";
         launch_reset(d, a, s);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? SNAC_OK : fail_hip(e, "kernel launch");
+    }
+    if (op == OP_AUX && (a.aux_op == AUX_RESET || a.aux_op == AUX_OBSERVE) && a.obs && !a.variant && pieces16(a) && !pipeline_off() &&
+        tune(TN_AUX_STEP) != 0 && tune(TN_STEP_STAGE) != 0 && a.n >= 256) {
+        if (d->kind == SNAC_ENV_1D) { g_kernel = "k_step1d"; launch_aux1d(d, a, s); }
+        else if (d->kind == SNAC_ENV_2D) { g_kernel = "k_step2d"; launch_aux2d(d, a, s); }
+        else { g_kernel = "k_step3dq"; launch_aux3d(d, a, s); }
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? SNAC_OK : fail_hip(e, "kernel launch");
     }

@@ -2,7 +2,8 @@
 observation output, from 256 envs): header from K::reset, records zeroed as one run per wave, the constant reset window as rows.  Against
 the CPU oracle for the six classes: dirty state (envs mid-episode, some pending a reset), ragged last waves, float64 / float32, the plan row
 from the counter RNG, from explicit indices and from the scalar form, resets without an observation, and the state AFTER the reset by
-stepping on; a masked reset, an odd batch and an unaligned output stay on the tile kernel with the same results."""
+stepping on; masked resets and observe() on the step kernels' AUX forms; an odd batch and an unaligned output
+stay on the tile kernel with the same results."""
 import numpy as np
 import pytest
 
@@ -77,10 +78,11 @@ def test_whole_batch_resets_match_the_oracle(dim, dyn, f32):
     _state_equal(env, orc)
 
 
-@pytest.mark.parametrize("dim,dyn", [(1, True), (2, True), (3, False)])
-def test_what_stays_on_the_tile_kernel_resets_the_same(dim, dyn):
-    """A masked reset (the other envs report their current observation), an odd batch, an unaligned observation output: k_aux, and the same
-    rows as k_reset gives a twin where both apply."""
+@pytest.mark.parametrize("dim,dyn", [(1, True), (1, False), (2, True), (2, False), (3, False), (3, True)])
+def test_masked_resets_observe_and_what_stays_on_the_tile_kernel(dim, dyn):
+    """A masked reset (the other envs report their current observation) and observe() on the step kernels' AUX forms (no action, no rules; a
+    header written only for an env that was reset); an odd batch and an unaligned observation output: the tile kernel k_aux, with the same rows
+    as k_reset gives a twin where both apply."""
     import torch
 
     n = 2048
@@ -89,12 +91,28 @@ def test_what_stays_on_the_tile_kernel_resets_the_same(dim, dyn):
     assert _kernel() == "k_reset"
     for t in range(12):
         env.step(auto_reset=False); orc.step(t, None, None, auto_reset=False)
+    last = None
+    for t in range(12, 15):
+        last = env.step(auto_reset=False)[0]; orc.step(t, None, None, auto_reset=False)
+    aux = {1: "k_step1d", 2: "k_step2d", 3: "k_step3dq"}[dim]      # the step kernels' AUX forms: a masked reset, an observe
+    assert torch.equal(env.observe(), last) and _kernel() == aux
     mask = np.random.default_rng(1).random(n) < 0.3
     og = env.reset(mask=torch.from_numpy(mask).cuda())
-    assert _kernel() != "k_reset"
+    assert _kernel() == aux
     oc = orc.reset(mask=mask.astype(np.uint8))
     assert helpers.same_bytes(og.cpu().numpy(), oc)
     _state_equal(env, orc)
+    assert torch.equal(env.observe(), og)
+    pidx = np.random.default_rng(2).integers(0, P, n).astype(np.int32)
+    mask2 = np.random.default_rng(3).random(n) < 0.5
+    og = env.reset(mask=torch.from_numpy(mask2).cuda(), plan_idx=torch.from_numpy(pidx).cuda())
+    assert _kernel() == aux
+    oc = orc.reset(mask=mask2.astype(np.uint8), plan_idx=pidx)
+    assert helpers.same_bytes(og.cpu().numpy(), oc)
+    _state_equal(env, orc)
+    for t in range(15, 20):                                          # ... and the state after it steps like the oracle's
+        o, r, d = env.step(auto_reset=True); oo, ro, do = orc.step(t, None, None, auto_reset=True)
+        assert helpers.same_bytes(o.cpu().numpy(), oo) and helpers.same_bytes(r.cpu().numpy(), ro), t
     twin = env.fork(torch.arange(n, device=env.device))
     raw = torch.empty(n * env.obs_dim + 1, dtype=torch.float64, device="cuda")
     with torch.cuda.device(env.device):
