@@ -1,5 +1,5 @@
-"""Which kernel takes which call: snac_rollout (T = 4 ticks, canonical rows into plain memory) and snac_step for every kind, row type and
-layout over a ladder of batch sizes, as the library's dispatch table (snac_hip.hip KNOBS, environment overrides included) decides it on
+"""Which kernel takes which call: snac_rollout (T = 4 ticks, rows into plain memory), snac_step, snac_reset (all envs / with a mask), snac_observe,
+snac_iou and snac_transition (a wave of N / 2 edges) for every kind, row type and layout over a ladder of batch sizes, as the library's dispatch table (snac_hip.hip KNOBS, environment overrides included) decides it on
 this box.  One line per (entry point, kind, rows): the batch sizes at which the kernel CHANGES.  Run it after touching a threshold:
 
     gpurun -- python tools/dispatch_table.py > gpurun_out/dispatch.txt        (copied to profiles/r06_dispatch.txt)
@@ -40,7 +40,7 @@ def main():
     for kind in (1, 2, 3):
         for dt, dn in ((torch.float64, "f64"), (torch.float32, "f32")):
             for layout in (None, "ppo"):
-                roll, step = [], []
+                roll, step, rst, rstm, obsv, iou, edge = [], [], [], [], [], [], []
                 for n in LADDER:
                     if n > top or (layout and n > 262144):           # (the 451-value rows of a million envs are 3.6 GB a tick)
                         continue
@@ -54,10 +54,28 @@ def main():
                     roll.append((n, kernel_of(lambda: env.rollout(T, obs="all", out=buf, reward_out=rew, done_out=done))))
                     out = (buf[0], rew[0], done[0])
                     step.append((n, kernel_of(lambda: env.step(None, None, auto_reset=True, out=out))))
+                    if n <= 524288:                                  # the other calls of the path: reset, reset(mask), observe, iou, one wave of tree edges
+                        mask = (torch.arange(n, device="cuda") % 3 == 0).to(torch.uint8)
+                        rst.append((n, kernel_of(lambda: env.reset())))
+                        rstm.append((n, kernel_of(lambda: env.reset(mask=mask))))
+                        obsv.append((n, kernel_of(lambda: env.observe())))
+                        iou.append((n, kernel_of(lambda: env.iou())))
+                        if not layout and n >= 8:
+                            m = n // 2
+                            src = torch.arange(m, device="cuda", dtype=torch.int32)
+                            dst = (m + torch.arange(m, device="cuda")).to(torch.int32)
+                            acts = torch.zeros(m, dtype=torch.int8, device="cuda")
+                            edge.append((m, kernel_of(lambda: env.transition(acts, None, src, dst, t=0))))
                     del env, buf, rew, done, out
                 tag = "%dD %s %s rows" % (kind, dn, layout or "canonical")
                 print("rollout  %-24s %s" % (tag, changes(roll)), flush=True)
                 print("step     %-24s %s" % (tag, changes(step)), flush=True)
+                print("reset    %-24s %s" % (tag, changes(rst)), flush=True)
+                print("reset(m) %-24s %s" % (tag, changes(rstm)), flush=True)
+                print("observe  %-24s %s" % (tag, changes(obsv)), flush=True)
+                print("iou      %-24s %s" % (tag, changes(iou)), flush=True)
+                if edge:
+                    print("edges    %-24s %s" % (tag, changes(edge)), flush=True)
     env = {k: v for k, v in os.environ.items() if k.startswith("SNAC_")}
     print("# environment overrides in effect:", env or "none")
 
