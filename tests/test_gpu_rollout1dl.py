@@ -174,3 +174,43 @@ def test_layout_variants_of_large_batches(dyn, kw, f32):
     assert _kernel() != "k_rollout1dl" and torch.equal(ou, og) and torch.equal(ru, rg) and torch.equal(du, dg)
     base._end_state(env, orc)
     assert torch.equal(env._hdr, twin._hdr) and torch.equal(env._hdr, third._hdr) and torch.equal(env._grid, third._grid)
+
+
+def test_replay_rings_filled_by_the_lane_kernel():
+    """ReplayRing.collect on a 1D batch of 45 056 + 36 envs: the tick ring and the tile-major ring (launches that write at an offset of the
+    ring and wrap: snac_rollout_tiled's tiled_T / tiled_t0, with the record outputs) hold the same rows, records and samples; the last launch's
+    rows equal the oracle's."""
+    import torch
+    from snac_amd import BatchedDMPEnv, ReplayRing
+
+    n = 45056 + 36
+    table, full = base._tables(True)
+    envs = [BatchedDMPEnv(1, True, n, plans=full, seed=12, total_step=40) for _ in range(2)]
+    orc = helpers.oracle().OracleBatch(1, True, n, table, seed=12)
+    orc.set_total_step(40)
+    orc.reset()
+    orc.rollout(13, t0=0, obs=None, nthreads=16)
+    rings = []
+    for e, layout in zip(envs, ("ticks", "tiled")):
+        e.reset()
+        e.rollout(13, obs=None)                                       # attach in mid-episode
+        rings.append(ReplayRing(e, 24, layout=layout))
+    t0 = 13
+    for T in (17, 20, 24, 7):                                         # launches that straddle the ring's end
+        for r in rings:
+            r.collect(T)
+            assert _kernel() == "k_rollout1dl"
+        oc, rc, dc = orc.rollout(T, t0=t0, nthreads=16)
+        t0 += T
+    a, b = rings
+    for slot in range(24):
+        assert torch.equal(a.obs_at(slot), b.obs_at(slot)), slot
+    for name in ("reward", "done", "action", "step_size", "plan_idx", "first"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert a.head == b.head == (17 + 20 + 24 + 7) % 24
+    for i in range(7):
+        assert helpers.same_bytes(a.obs_at((a.head - 7 + i) % 24).cpu().numpy(), oc[i]), i
+    ga, gb = torch.Generator(device="cuda"), torch.Generator(device="cuda")
+    ga.manual_seed(3); gb.manual_seed(3)
+    sa, sb = a.sample(300, generator=ga), b.sample(300, generator=gb)
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
