@@ -119,20 +119,28 @@ __global__ __launch_bounds__(EB * 64, VLD ? 1 : 16 / EB) void k_rollout1dt(const
             const int last = donem ? (__ffsll((long long)donem) - 1) : (nl - 1);     // the segment's last lane
             const bool in = seg && lane <= last;
             // ---- positions: inclusive scan of x -> min(max(x + d, 2), 31)
-            int sa = 0, slo = -4096, shi = 4096;
-            if (in) { sa = act == 0 ? -k : (act == 1 ? k : 0); slo = 2; shi = 31; }
-            // Hillis-Steele inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then the rows' last lanes to the rows behind them; a
-            // lane without a source composes with the identity (0, -4096, 4096), so no step is conditional
-            auto compose = [&](int pa, int plo, int phi) {               // the earlier ticks first, then this lane's function
-                const int nlo = min(max(plo + sa, slo), shi), nhi = min(max(phi + sa, slo), shi);
-                sa += pa; slo = nlo; shi = nhi;
+            // the clamp pair (lo, hi) travels as two int16 in ONE register: a compose step is three packed instructions (v_pk_add / max / min_i16,
+            // the scalar operand's half picked by op_sel) instead of six (round 6: 66 -> 36 vector instructions per segment; positions are
+            // 2 .. 31, a chunk moves at most 192 cells, the identity is (-4096, 4096): everything fits 16 bits)
+            int sa = 0;
+            uint32_t lh = 0x1000F000u;                               // (lo, hi) = (-4096, 4096): the identity
+            if (in) { sa = act == 0 ? -k : (act == 1 ? k : 0); lh = (31u << 16) | 2u; }
+            auto compose = [&](int pa, uint32_t plh) {               // the earlier ticks first, then this lane's function
+                uint32_t t;
+                asm("v_pk_add_i16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(plh), "v"(sa));          // (plo + sa, phi + sa)
+                asm("v_pk_max_i16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(t), "v"(lh));            // max(., slo)
+                asm("v_pk_min_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t) : "v"(t), "v"(lh));   // min(., shi)
+                sa += pa; lh = t;
             };
-            compose(dpp_from<0x111>(0, sa), dpp_from<0x111>(-4096, slo), dpp_from<0x111>(4096, shi));
-            compose(dpp_from<0x112>(0, sa), dpp_from<0x112>(-4096, slo), dpp_from<0x112>(4096, shi));
-            compose(dpp_from<0x114>(0, sa), dpp_from<0x114>(-4096, slo), dpp_from<0x114>(4096, shi));
-            compose(dpp_from<0x118>(0, sa), dpp_from<0x118>(-4096, slo), dpp_from<0x118>(4096, shi));
-            compose(dpp_from<0x142, 0xa>(0, sa), dpp_from<0x142, 0xa>(-4096, slo), dpp_from<0x142, 0xa>(4096, shi));
-            compose(dpp_from<0x143, 0xc>(0, sa), dpp_from<0x143, 0xc>(-4096, slo), dpp_from<0x143, 0xc>(4096, shi));
+            // Hillis-Steele inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then the rows' last lanes to the rows behind them; a
+            // lane without a source composes with the identity, so no step is conditional
+            compose(dpp_from<0x111>(0, sa), (uint32_t)dpp_from<0x111>((int)0x1000F000u, (int)lh));
+            compose(dpp_from<0x112>(0, sa), (uint32_t)dpp_from<0x112>((int)0x1000F000u, (int)lh));
+            compose(dpp_from<0x114>(0, sa), (uint32_t)dpp_from<0x114>((int)0x1000F000u, (int)lh));
+            compose(dpp_from<0x118>(0, sa), (uint32_t)dpp_from<0x118>((int)0x1000F000u, (int)lh));
+            compose(dpp_from<0x142, 0xa>(0, sa), (uint32_t)dpp_from<0x142, 0xa>((int)0x1000F000u, (int)lh));
+            compose(dpp_from<0x143, 0xc>(0, sa), (uint32_t)dpp_from<0x143, 0xc>((int)0x1000F000u, (int)lh));
+            const int slo = (int)(int16_t)(lh & 0xFFFFu), shi = (int)(int16_t)(lh >> 16);
             const int pos = min(max(pos0 + sa, slo), shi);           // after the tick
             const int prev = dpp_from<0x138>(pos0, pos);
             const int posb = lane == first_lane ? pos0 : prev;       // before the tick: where a drop lands
