@@ -9,10 +9,15 @@
 //                                 plan rows per wave in LDS, refilled through the scalar cache; no vector load in the loop
 //   k_roll2dt.hip   k_rollout2dt  2D rollouts of small and middle batches, time-parallel: one wave per env, lane = tick
 //   k_roll1dt.hip   k_rollout1dt  the same idea for 1D
-//   k_roll1dl.hip   k_rollout1dl  1D rollouts of large batches: lane = env, the headline kernel's shape
+//   k_roll1dl.hip   k_rollout1dl  1D rollouts of large batches: lane = env, the headline kernel's shape (rows1d.h: the 1D rows of a wave as one run)
 //   k_roll3db.hip   k_rollout3db  3D rollouts: one stepper wave (lane = env) and eight writer waves per 64 envs, one barrier per tick
 //   k_roll3d.hip    k_rollout3d   3D rollouts of small / odd batches: 8 envs per wave, software-pipelined round the store stream
-//   k_step.hip      k_step2d / 3d snac_step on identity rows: wide loads, rows through emit_tile
+//   k_step.hip      k_step2d / 3d snac_step on identity rows: wide loads, rows through emit_tile; AUX forms: masked resets and observe without a step
+//   k_step3dq.hip   k_step3dq     the canonical 3D snac_step: 16 envs per wave, four lanes per env
+//   k_step1d.hip    k_step1d, k_edges1d   the 1D snac_step (canonical rows and the layout variants) and 1D tree edges
+//   k_reset.hip     k_reset, k_iou        whole-batch resets without reading the old state; snac_iou lane-per-env
+//   k_nodes2d.hip   k_edges2dp    2D tree edges on node pools of one 128-byte record per node
+//   k_mailbox.hip   k_mailbox     the resident stepper behind the drop-in classes (mailbox_host.h: the host half of its protocol)
 //   k_trans.hip     k_transition2d / 3d, k_edges3d: single steps and tree edges with gathered rows
 //   k_tile{1,2,3}d.hip  the tile kernels k_rollout / k_transition / k_aux (rounds 1-2) behind all of them (templates: k_tile.inc)
 //   k_misc.hip      export / import / equality / plan generators / replay gather, with their entry points
