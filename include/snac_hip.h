@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define SNAC_ABI_VERSION 11
+#define SNAC_ABI_VERSION 12
 
 typedef enum snac_status {
     SNAC_OK = 0,
@@ -486,6 +486,16 @@ int snac_import_state(const snac_env_desc* desc, const snac_state* st, int32_t m
  * rows_a / rows_b: number of rows of the two arrays (indices are clamped). */
 int snac_obs_equal(const snac_env_desc* desc, const void* obs_a, const int32_t* idx_a, int32_t rows_a, const void* obs_b,
                    const int32_t* idx_b, int32_t rows_b, int32_t m, uint8_t* out, void* stream);
+
+/* The "Evaluation" block of the vanilla MCTS procedure (script/MCTS/utils/mcts.py:100-110): from a leaf, default-policy steps until
+ * `terminal` or the horizon, `estimate += reward * gamma**t` in that order.  The steps are a snac_rollout of the forked leaves without
+ * observation rows (reward / done [H][m]); this call does the sums on the device, one leaf per lane, sequentially in t, each product
+ * and each sum rounded to float64 (no fused multiply-add) -- what the reference's python floats do:
+ *     alive = !terminal[i];  for t in 0 .. H - 1 while alive:  est[i] += (double)reward[t][i] * gpow[t];  steps[i] += 1;  alive = !done[t][i]
+ * est [m]: in = the leaf's first reward (the reference's `estimate = reward`), out = the estimate; steps [m] out (may be NULL);
+ * terminal [m] may be NULL (no leaf is terminal); gpow [H] = gamma**t as the CALLER's pow computes it (device memory, like the rest). */
+int snac_discounted_return(int32_t H, int32_t m, const float* reward, const uint8_t* done, const uint8_t* terminal, const double* gpow,
+                           double* est, int64_t* steps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SNAC_OK = 0
-ABI_VERSION = 11
+ABI_VERSION = 12
 ENV_1D, ENV_2D, ENV_3D = 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 OBS_NONE, OBS_ALL, OBS_LAST, OBS_TILED = 0, 1, 2, 3
@@ -22,7 +22,7 @@ TAIL_POSITION, TAIL_PLAN, TAIL_RECORD = 1, 2, 4
 EXPORTS = ("snac_version", "snac_last_error", "snac_env_sizes", "snac_obs_dim", "snac_reset", "snac_reset_scalar", "snac_step",
            "snac_step_scalar", "snac_rollout",
            "snac_rollout_rec", "snac_replay_gather", "snac_make_plans", "snac_observe", "snac_iou", "snac_export_grid", "snac_transition",
-           "snac_import_state", "snac_obs_equal", "snac_plans_from_grids", "snac_mailbox_create", "snac_mailbox_row", "snac_mailbox_touch", "snac_mailbox_step", "snac_mailbox_step_n", "snac_mailbox_reward", "snac_mailbox_done",
+           "snac_import_state", "snac_obs_equal", "snac_discounted_return", "snac_plans_from_grids", "snac_mailbox_create", "snac_mailbox_row", "snac_mailbox_touch", "snac_mailbox_step", "snac_mailbox_step_n", "snac_mailbox_reward", "snac_mailbox_done",
            "snac_mailbox_quit", "snac_mailbox_settle", "snac_mailbox_destroy", "snac_mailbox_stats", "snac_stream_sync", "snac_rollout_tiled", "snac_replay_gather_tiled", "snac_traj_alloc",
            "snac_traj_alloc_ex", "snac_traj_free", "snac_traj_layout", "snac_traj_describe", "snac_traj_reserved_bytes", "snac_last_kernel", "snac_tuning",
            "snac_nodes2d_pack", "snac_nodes2d_unpack", "snac_transition_nodes2d")
@@ -143,6 +143,7 @@ def lib():
         L.snac_mailbox_destroy.argtypes = [vp]
         L.snac_mailbox_stats.argtypes = [vp, C.POINTER(C.c_uint32 * 8)]
         L.snac_obs_equal.argtypes = [C.POINTER(EnvDesc), vp, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
+        L.snac_discounted_return.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
         L.snac_traj_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(vp)]
         L.snac_traj_alloc_ex.argtypes = [C.c_size_t, C.c_int, C.c_size_t, vp, C.POINTER(vp)]
         L.snac_traj_free.argtypes = [vp]

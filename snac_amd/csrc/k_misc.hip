@@ -253,6 +253,33 @@ __global__ __launch_bounds__(256) void k_make_plans(const PArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// default-policy evaluation of tree leaves (script/MCTS/utils/mcts.py:100-110: `estimate += reward * (gamma**t)` while not terminal): the
+// discounted sums of a rollout's reward / done [H][m], one leaf per lane, sequential in t, product and sum each rounded to float64
+// (fp contract(off): no fma -- the reference's python floats round twice).  A wave leaves when all its leaves have ended.
+__global__ __launch_bounds__(256) void k_discount(int H, int m, const float* reward, const uint8_t* done, const uint8_t* terminal, const double* gpow,
+                                                   double* est, int64_t* steps) {
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const bool in = i < m;
+    const int ii = in ? i : 0;
+    bool alive = in && !(terminal && terminal[ii]);
+    double e = est[ii];
+    long long n = 0;
+    for (int t = 0; t < H; ++t) {
+        if (!__any(alive)) break;
+        const size_t at = (size_t)t * (size_t)m + (size_t)ii;
+        const float r = reward[at];
+        const bool d = done[at] != 0;
+        if (alive) {
+#pragma clang fp contract(off)                                      // (hipcc contracts a * b + c into an fma by default, also through __dmul_rn / __dadd_rn: one rounding instead of two)
+            const double p = (double)r * gpow[t];
+            e = e + p;
+            n += 1; alive = !d;
+        }
+    }
+    if (in) { est[i] = e; if (steps) steps[i] = n; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // replay sampling (the step after the env path: script/DQN/2d/DQN_2d_dynamic.py:122-124,145-166 keeps
 // (s, a, r, s', plan) tuples in a python deque and re-assembles float32 minibatches on the host).  The rollout output
 // ring obs[cap][N][D] already holds every s' -- and s is the previous tick's row, or the constant reset observation when
@@ -501,6 +528,17 @@ int snac_obs_equal(const snac_env_desc* d, const void* obs_a, const int32_t* idx
         hipLaunchKernelGGL((k_equal<double>), grid, block, 0, s, (const double*)obs_a, idx_a, rows_a, (const double*)obs_b, idx_b, rows_b, m, D, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "equal launch");
+    return SNAC_OK;
+}
+
+int snac_discounted_return(int32_t H, int32_t m, const float* reward, const uint8_t* done, const uint8_t* terminal, const double* gpow,
+                           double* est, int64_t* steps, void* stream) {
+    if (H < 0 || m < 0) return fail(SNAC_ERR_ARG, "H and m must be >= 0");
+    if (m == 0) return SNAC_OK;
+    if (!est || (H > 0 && (!reward || !done || !gpow))) return fail(SNAC_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_discount, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, H, m, reward, done, terminal, gpow, est, steps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "discounted return launch");
     return SNAC_OK;
 }
 

@@ -35,7 +35,7 @@ def test_raw_c_abi_reset_step_rollout_iou():
 
     L = C.CDLL(os.path.join(helpers.ROOT, "snac_amd", "libsnac_hip.so"))
     L.snac_last_error.restype = C.c_char_p
-    assert L.snac_version() == 11
+    assert L.snac_version() == 12
     sz = Sizes()
     assert L.snac_env_sizes(2, 1, C.byref(sz)) == 0 and (sz.obs_dim, sz.grid_elems, sz.grid_elem_bytes) == (51, 20, 4)
 

@@ -464,3 +464,56 @@ def test_large_waves_of_3d_edges_through_lds(dyn, f32):
     o2, r2, d2 = twin.transition(acts[: m - 2], None, src[: m - 2], dst[: m - 2], t=7)
     assert _lib.lib().snac_last_kernel() == b"k_transition3d"
     assert torch.equal(o1[: m - 2], o2) and torch.equal(r1[: m - 2], r2) and torch.equal(d1[: m - 2], d2)
+
+
+@pytest.mark.gpu
+def test_discounted_return_equals_the_python_loop_bit_for_bit():
+    """snac_discounted_return (round 6: the sums of BatchedDMPEnv.evaluate on the device) against the reference's loop in python floats
+    (script/MCTS/utils/mcts.py:100-110: `estimate += reward * (gamma**t)` while not terminal) on random reward / done arrays: rewards that
+    do not sum exactly (-1, 5, 10, -100 times powers of 0.9 / 0.99: two roundings per step, no fused multiply-add), terminal leaves, leaves
+    that never end, a horizon of zero, steps = NULL."""
+    import ctypes as C
+
+    import torch
+    from snac_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(4)
+    for H, m, gamma in ((37, 300, 0.9), (600, 1000, 0.99), (1, 5, 0.5), (0, 7, 0.9)):
+        reward = rng.choice(np.array([-100.0, -1.0, 0.0, 1.0, 5.0, 10.0], np.float32), size=(H, m))
+        done = (rng.random((H, m)) < 0.02)
+        terminal = rng.random(m) < 0.1
+        first = rng.integers(-1, 11, m).astype(np.float64)
+        want, steps_want = first.copy(), np.zeros(m, np.int64)
+        for i in range(m):
+            estimate, term, t = float(first[i]), bool(terminal[i]), 0
+            while (not term) and t < H:
+                estimate += float(reward[t, i]) * (gamma ** t)
+                term = bool(done[t, i])
+                t += 1
+            want[i], steps_want[i] = estimate, t
+        r = torch.from_numpy(reward).cuda().contiguous() if H else torch.empty((0, m), dtype=torch.float32, device="cuda")
+        d = torch.from_numpy(done.astype(np.uint8)).cuda().contiguous() if H else torch.empty((0, m), dtype=torch.uint8, device="cuda")
+        tm = torch.from_numpy(terminal.astype(np.uint8)).cuda()
+        gp = torch.tensor([gamma ** t for t in range(H)], dtype=torch.float64).cuda()
+        est = torch.from_numpy(first).cuda()
+        steps = torch.empty(m, dtype=torch.int64, device="cuda")
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t.numel() else None  # noqa: E731
+        _lib.check(L.snac_discounted_return(H, m, vp(r), vp(d), vp(tm), vp(gp), vp(est), vp(steps), None))
+        torch.cuda.synchronize()
+        assert est.cpu().numpy().tobytes() == want.tobytes(), (H, m)
+        assert np.array_equal(steps.cpu().numpy(), steps_want)
+        est2 = torch.from_numpy(first).cuda()
+        _lib.check(L.snac_discounted_return(H, m, vp(r), vp(d), None, vp(gp), vp(est2), None, None))   # no terminal leaves, no step counts
+        torch.cuda.synchronize()
+        want2 = first.copy()
+        for i in range(m):
+            estimate, term, t = float(first[i]), False, 0
+            while (not term) and t < H:
+                estimate += float(reward[t, i]) * (gamma ** t)
+                term = bool(done[t, i])
+                t += 1
+            want2[i] = estimate
+        assert est2.cpu().numpy().tobytes() == want2.tobytes()
+    assert L.snac_discounted_return(-1, 4, None, None, None, None, None, None, None) != 0
+    assert L.snac_discounted_return(3, 4, None, None, None, None, None, None, None) != 0
