@@ -248,6 +248,8 @@ def _extra_row(e):
         us = e["us_per_tick"]
     elif "us_per_step" in e:
         us = e["us_per_step"]
+    elif "us_per_call" in e:
+        us = e["us_per_call"]
     else:
         us = e.get("us_per_vector_step")
     name = e.get("kernel") or ("mailbox" if str(e.get("path", "")).startswith("mailbox") else "launch")
@@ -908,6 +910,17 @@ def main():
                          "frac": gbs / HBM_PEAK_GBS, "launches": GROUPS * reps, "timing": spread[-1],
                          "note": "device time per tick, launches enqueued back to back" + ("" if nn >= 262144 else "; at this batch size a tick is the launch gap (about 2.5 us) plus its bytes at the rate of a plain copy (2D: 38 MB = 6.0 us, 3D: 51 MB = 8.1 us)")}
 
+        def reset_cfg(name, kind, nn, reps):
+            """snac_reset of every env (row a1 of the path: reset()): header, episode counter, the record zeroed, the reset observation written --
+            bytes per env: row + 16 + 4 + 4 (episode counter in and out) + the record (64 / 80 / 800)."""
+            e = BatchedDMPEnv(kind, True, nn, device=dev, seed=1)
+            e.reset()
+            ms = timed(lambda: e.reset(), reps)
+            algb = e.obs_dim * 8 + 24 + {1: 64, 2: 80, 3: 800}[kind]
+            gbs = algb * nn / (ms * 1e-3) / 1e9
+            res[name] = {"kernel": last_kernel(), "us_per_call": ms * 1e3, "envs_per_s": nn / (ms * 1e-3), "alg_bytes_per_env": algb, "achieved_GBs": gbs,
+                         "frac": gbs / HBM_PEAK_GBS, "launches": GROUPS * reps, "timing": spread[-1], "note": "reset() of the whole batch, rows allocated by the call"}
+
         def default_alloc_cfg(name, reps):
             """The headline pass as a user calls it -- env.rollout(T) with NO out= --: the observation tensor comes from the cache of
             measured trajectory blocks (snac_amd/trajmem.py cached_empty: built on the first call, recycled afterwards)."""
@@ -964,6 +977,8 @@ def main():
         step_cfg("step_1d_dynamic_n524288", 1, 524288, 200)
         step_cfg("step_2d_ppo_layout_n65536", 2, 65536, 100, layout="ppo")   # what a trainer that steps 65 536 envs per tick reads: 451-value rows
         step_cfg("step_3d_ppo_layout_n65536", 3, 65536, 100, layout="ppo")
+        reset_cfg("reset_2d_n524288", 2, 524288, 50)                # k_reset since the end of round 6 (the tile kernel k_aux before: 81 / 412 us)
+        reset_cfg("reset_3d_n524288", 3, 524288, 30)
         for kind in (1, 2, 3):                                      # (1D: k_edges1d since the end of round 6; the tile kernel before: 54 us)
             edges_cfg("transition_%dd_524288_edges" % kind, kind, 524288, 20)
         edges_cfg("transition_2d_nodes_524288_edges", 2, 524288, 20, nodes=True)
