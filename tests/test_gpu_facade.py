@@ -134,7 +134,7 @@ def test_invalid_action_raises_like_the_reference():
         _cls(1, False)(plan_choose=5).reset()
 
 
-@pytest.mark.parametrize("n", [24, 200])                              # one resident wave; four (round 6: up to 256 envs)
+@pytest.mark.parametrize("n", [24, 200, 260])                         # one resident wave; four (round 6: up to 256 envs); beyond: the launch path (rows in page-locked host memory)
 @pytest.mark.parametrize("name,kind", [("1DStatic", (1, False)), ("2DDynamic", (2, True)), ("3DDynamic", (3, True))])
 def test_vectorized_wrapper_follows_the_reference_loop(name, kind, n):
     """multiprocess.py:78-84 with N independent envs: seed, reset, T ticks of np.random actions.  The oracle side
@@ -149,7 +149,7 @@ def test_vectorized_wrapper_follows_the_reference_loop(name, kind, n):
     plans = make_plans(name, 0)
     np.random.seed(seed)
     env = VectorizedEnvWrapper(plans, num_envs=n)
-    assert env._mrows is not None                                     # the resident waves, not the launch path
+    assert (env._mrows is not None) == (n <= 256)                     # the resident waves up to 256 envs, the launch path beyond
     obs = env.reset()
     A = env.action_dim
     table = np.ascontiguousarray(plans[2].reshape(len(plans[2]), -1), np.int32)
